@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: radar frames/s of the range -> Doppler -> angle FFT chain on synthetic
+256 x 128 x 12 ADC cubes (BASELINE.json configs[1], sharded per frame as in configs[4]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  Every rank holds its own shard of `--frames` cubes resident in HBM (generated on
+the device by mmw_synth_cubes before the timed region), a step is one pass of the chain over that shard.
+Frames are independent, so there is NO data-path collective (weak scaling): torch.distributed (gloo) is
+used only for the barriers around the timed region and the max-over-ranks of the elapsed time.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V, S, C, A = 12, 256, 128, 64
+CUBE_BYTES = V * S * C * 8                      # complex64 input cube
+OUT_BYTES = A * S * C * 8                       # complex64 angle-range-Doppler cube
+ALGO_BYTES_PER_FRAME = CUBE_BYTES + OUT_BYTES   # 19,922,944 B
+HBM_PEAK_GBS = 8000.0                           # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(seconds: float = 12.0):
+    """Oracle (float64 NumPy restatement of the reference chain) timed on one host core."""
+    from mmwave_radar_processing_amd import synth
+    from oracle import oracle_np as O
+    cubes = [synth.synth_cube(1000 + i) for i in range(4)]
+    O.fft3d_windowed(cubes[0], A)               # warm numpy's FFT plan cache
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.fft3d_windowed(cubes[n % len(cubes)], A)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 8:
+            break
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames of the same synthetic 12x256x128 workload through oracle_np.fft3d_windowed "
+                      f"(float64 NumPy, single thread) in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=1250, help="frames resident per GPU (10k-frame batch / 8 GPUs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist   # control plane only: barrier + max of the elapsed time
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    from mmwave_radar_processing_amd import _lib
+    ndev = _lib.device_count()
+    ctx = _lib.Context(local_rank % ndev)
+    info = _lib.device_info(ctx.device)
+    F = args.frames
+    d_in = ctx.alloc(F * CUBE_BYTES)
+    d_out = ctx.alloc(F * OUT_BYTES)
+    # distinct frames per rank: seed0 offsets by the rank's first global frame index
+    _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 7_000_000 + rank * F, 8, 30.0))
+    ctx.sync()
+
+    def step():
+        _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_profile:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_stop()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    ctx.profile_enable(False)
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_frames = world * F * args.steps
+        value = total_frames / elapsed
+        out = {
+            "metric": "radar frames/s on 256x128x12 ADC cube (range+Doppler+angle FFT chain, fp32)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "IWR1843 synthetic 256x128x(4Rx x 3Tx) cube: Hann range FFT + Doppler FFT + "
+                                   "64-bin angle FFT -> complex64 [64,256,128] (BASELINE configs[1])",
+                       "frames_per_gpu": F, "cube": [V, S, C], "angle_bins": A,
+                       "sharding": f"frame-sharded x{world}, no collective",
+                       "chunk_frames": int(os.environ.get("MMW_CHAIN_CHUNK", "8")),
+                       "device": info["name"], "arch": info["arch"]},
+            "hip_event_ms_per_step_rank0": ev_ms / args.steps,
+            "chain_hbm_frac_of_8TBs": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),
+        }
+        if not args.no_profile:
+            ang_ms, ang_n = ctx.profile_get("angle")
+            rd_ms, rd_n = ctx.profile_get("rd")
+            if ang_n:
+                frames_per_launch = F * args.steps / ang_n
+                avg_s = ang_ms * 1e-3 / ang_n
+                achieved = frames_per_launch * ALGO_BYTES_PER_FRAME / avg_s / 1e9
+                traffic = None
+                if os.path.exists(args.traffic_json):
+                    with open(args.traffic_json) as fh:
+                        traffic = json.load(fh).get("angle_bytes_per_launch")
+                out["roofline"] = {"bound": "hbm", "kernel": "k_angle64 (angle FFT, reads V planes / writes 64)",
+                                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                   "avg_launch_us": avg_s * 1e6, "launches": ang_n,
+                                   "frames_per_launch": frames_per_launch,
+                                   "algorithmic_bytes_per_launch": frames_per_launch * ALGO_BYTES_PER_FRAME}
+            if rd_n:
+                fpl = F * args.steps / rd_n
+                avg_s = rd_ms * 1e-3 / rd_n
+                out["rd_kernel"] = {"avg_launch_us": avg_s * 1e6, "launches": rd_n,
+                                    "achieved_GBs": fpl * 2 * CUBE_BYTES / avg_s / 1e9,
+                                    "algorithmic_bytes_per_launch": fpl * 2 * CUBE_BYTES}
+        # one-frame parity gate on the bench's own data (not timed)
+        from oracle import oracle_np as O
+        cube0 = d_in.download((V, S, C), np.complex64)
+        got0 = d_out.download((A, S, C), np.complex64)
+        ref0 = O.fft3d_windowed(cube0, A)
+        out["parity_max_rel_err_frame0"] = float(np.max(np.abs(got0 - ref0)) / np.max(np.abs(ref0)))
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

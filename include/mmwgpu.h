@@ -1,0 +1,177 @@
+/*
+ * mmwgpu.h -- C ABI of libmmwgpu.so: MI355X (gfx950) range-Doppler-angle + CFAR hot path.
+ *
+ * Drop-in boundary for davidmhunt/mmwave_radar_processing.  The reference has no FFI
+ * (SURVEY.md section 8b): its boundary is the Python class protocol
+ * `processor.process(adc_cube, **kw)` / `detector.detect(x)`.  This header is what a
+ * ctypes binding for that protocol binds; every entry point cites the reference
+ * call (file:line, relative to mmwave_radar_processing/) whose NumPy arithmetic it replaces.
+ * INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Every function returns an int
+ *     status (MMW_OK == 0, negative == error); mmw_last_error() gives the text
+ *     of the calling thread's last failure.
+ *   - complex64 = interleaved (re, im) float pairs.  Cube layout is the reference's:
+ *     [frame][virtRx V][sample S][chirp C], C-order, chirp fastest
+ *     (processors/_processor.py:58).
+ *   - Pointers named d_* are DEVICE pointers obtained from mmw_malloc; h_* are host.
+ *   - All compute entry points enqueue on the context's HIP stream and return
+ *     without synchronising unless they take a host output pointer; call
+ *     mmw_sync() before reading device results through mmw_memcpy_d2h (which
+ *     synchronises itself).
+ *   - One context per host thread; contexts are not thread-safe.
+ */
+#ifndef MMWGPU_H
+#define MMWGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMW_OK                 0
+#define MMW_ERR_INVALID       -1   /* bad argument (shape, null pointer, unsupported size)   */
+#define MMW_ERR_HIP           -2   /* HIP runtime error, see mmw_last_error()               */
+#define MMW_ERR_NOMEM         -3   /* device allocation failed                              */
+#define MMW_ERR_TRUNCATED     -4   /* detection output capacity too small; counts are exact */
+#define MMW_ERR_UNSUPPORTED   -5   /* valid request this build has no kernel for            */
+
+typedef struct mmw_ctx mmw_ctx;
+
+/* CFAR kinds: string keys of detectors/detector_registry.py:15-27 */
+#define MMW_CFAR_CA 0
+#define MMW_CFAR_OS 1
+#define MMW_CFAR_GO 2
+#define MMW_CFAR_SO 3
+
+/* ---------------------------------------------------------------- lifecycle */
+const char *mmw_version(void);
+const char *mmw_last_error(void);
+int mmw_device_count(int *count);
+/* Device name and gcnArchName into caller buffers (for fail-loud checks and reports). */
+int mmw_device_info(int device, char *name, int name_len, char *arch, int arch_len,
+                    int *num_cu, size_t *total_mem);
+int mmw_ctx_create(mmw_ctx **out, int device);
+int mmw_ctx_destroy(mmw_ctx *ctx);
+int mmw_sync(mmw_ctx *ctx);
+
+/* ---------------------------------------------------------------- memory */
+int mmw_malloc(mmw_ctx *ctx, void **d_ptr, size_t bytes);
+int mmw_free(mmw_ctx *ctx, void *d_ptr);
+int mmw_memcpy_h2d(mmw_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int mmw_memcpy_d2h(mmw_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int mmw_memset(mmw_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+/* ---------------------------------------------------------------- timing (HIP events on the ctx stream) */
+int mmw_timer_start(mmw_ctx *ctx);
+int mmw_timer_stop(mmw_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */
+
+/* ---------------------------------------------------------------- input staging
+ * mmw_synth_cubes: fill d_cubes[n_frames][V][S][C] complex64 with the synthetic
+ *   point-target + noise workload directly in HBM (counter-based RNG; integer-valued
+ *   I/Q like SURVEY.md 8d).  Benchmark input only -- parity tests download these
+ *   cubes and hand the SAME bytes to the oracle.
+ * mmw_virtual_array_reformat: raw [F][num_rx][S][num_tx*loops] -> [F][num_rx*num_tx][S][loops]
+ *   replaces VirtualArrayReformatter.process (processors/virtual_array_reformater.py:44-65). */
+int mmw_synth_cubes(mmw_ctx *ctx, void *d_cubes, int n_frames, int V, int S, int C,
+                    uint64_t seed0, int num_targets, float noise_sigma);
+int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, int n_frames,
+                               int num_rx, int num_tx, int S, int loops);
+
+/* ---------------------------------------------------------------- FFT chain
+ * mmw_range_doppler: d_out[F][V][S][C] c64 = fftshift_C( FFT_S FFT_C( hann(S) hann(C) x ) )
+ *   replaces RangeDopplerProcessor.process (processors/range_doppler_resp.py:49-110) and
+ *   RangeDopplerDetector._compute_range_doppler_response (range_doppler_detection/range_doppler_detector.py:62-80).
+ *   If d_mag_f32 != NULL also writes |out| [F][V][S][C] float32 (return_magnitude=True path).
+ * mmw_range_doppler_mag64: double-precision |RD| of ONE virtual antenna, d_mag[F][S][C] float64.
+ *   This is the CFAR input plane (range_doppler_detector.py:78 uses rx 0 only); computed
+ *   end-to-end in float64 so detection indices are bit-exact against the float64 reference.
+ * mmw_angle_fft: d_out[F][A][S][C] c64 = fftshift_A FFT_A( zero-pad_{V->A}( hann(V) rd ) )
+ *   last stage of RangeAngleProcessorDBSEnhanced.compute_3d_windowed_fft
+ *   (processors/range_angle_resp_dbs_enhanced.py:175-196).  If magnitude != 0 the output is
+ *   float32 |.| [F][A][S][C] instead (perform/process_dbs_enhanced :293).
+ * mmw_chain3d: mmw_range_doppler followed by mmw_angle_fft, chunked so the RD intermediate
+ *   stays cache-resident; d_rd may be NULL (internal scratch) or [F][V][S][C] to keep it.
+ *   Replaces compute_3d_windowed_fft (:137-198) end to end. */
+int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_mag_f32,
+                      int n_frames, int V, int S, int C);
+int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag,
+                            int n_frames, int V, int S, int C, int rx_idx);
+int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames,
+                  int V, int S, int C, int A, int magnitude);
+int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames,
+                int V, int S, int C, int A, int magnitude);
+
+/* mmw_range_profile: d_out[F][S] float32 = mean_rx | FFT_S( hann(S) x[:, :, chirp] ) |
+ *   replaces RangeProcessor.coarse_fft (processors/range_resp.py:32-57).
+ * mmw_range_angle: d_out[F][S][A] float32 = | fftshift_A fft2( pad_A( (win) x[rx, :, chirp].T ) ) |
+ *   replaces RangeAngleProcessor.process (processors/range_angle_resp.py:55-122); the window is
+ *   applied over ALL V antennas before the subset h_rx[n_rx] is taken (:96-101); n_rx == 0 = all. */
+int mmw_range_profile(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames,
+                      int V, int S, int C, int chirp_idx);
+/* float64 variant feeding the 1-D range CFAR of RangeDopplerDetectorSequential
+ * (processors/range_doppler_detection/range_doppler_detector_sequential.py:84-91). */
+int mmw_range_profile_f64(mmw_ctx *ctx, const void *d_cubes, double *d_out, int n_frames,
+                          int V, int S, int C, int chirp_idx);
+int mmw_range_angle(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames,
+                    int V, int S, int C, int A, int chirp_idx, const int *h_rx, int n_rx,
+                    int perform_windowing);
+
+/* ---------------------------------------------------------------- CFAR detectors (float64, like the reference)
+ * mmw_cfar2d: thresholds/noise [F][R][D] float64 and det mask [F][R][D] uint8 for
+ *   BaseCFAR2D.detect + Ca/OsCFAR2D._compute_thresholds (detectors/base.py:208-230,
+ *   ca_cfar.py:85-155, os_cfar.py:134-195).  CA: scale = alpha = N(pfa^(-1/N)-1) computed by the
+ *   caller (base.py:281-293), k_rank ignored.  OS: scale = alpha, k_rank 1-based (os_cfar.py:131-132).
+ *   Valid region only; elsewhere threshold = +inf, noise = 0; decision X > T strict.
+ *   d_thr / d_noise may be NULL when only the mask is wanted.
+ * mmw_cfar1d: same for Ca/Os/Go/SoCFAR1D (ca_cfar.py:11-77, os_cfar.py:29-86, go_so_cfar.py:11-123)
+ *   over n_rows independent rows of length L.
+ * mmw_compact2d: ordered (row-major, == np.where, base.py:229-230) compaction of the mask into
+ *   d_dets[F][cap][2] int32 (row, col) and d_counts[F] int32.  Counts are exact even when
+ *   a frame overflows cap (status MMW_ERR_TRUNCATED is reported by mmw_detect_* wrappers). */
+int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, uint8_t *d_mask,
+               int n_frames, int R, int D, int kind, int train_r, int train_d,
+               int guard_r, int guard_d, double scale, int k_rank);
+int mmw_cfar1d(mmw_ctx *ctx, const double *d_x, double *d_thr, double *d_noise, uint8_t *d_mask,
+               int n_rows, int L, int kind, int num_train, int num_guard, double scale, int k_rank);
+int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t *d_counts,
+                  int n_frames, int R, int D, int cap);
+
+/* ---------------------------------------------------------------- point cloud
+ * mmw_angle_argmax: for each detection (r, v) of frame f gather rd[f][ant[i]][r][v], zero-pad to A,
+ *   FFT, optional fftshift, |.|, first-max argmax -> d_idx[F][cap] int32.
+ *   replaces PointCloudGenerator._compute_angle_estimation (processors/point_cloud_generator.py:143-214). */
+int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, const int32_t *d_counts,
+                     int32_t *d_idx, int n_frames, int V, int S, int C, int cap,
+                     const int *h_ant, int n_ant, int A, int shift);
+
+/* ---------------------------------------------------------------- beamformers
+ * mmw_bartlett: delay-and-sum steering-matrix contraction on MFMA,
+ *   Y[s][t] = FFT_S( hann(S) * sum_e X[s][e] hamming(E)[e] exp(j 2 pi d_t . p_e / lambda) )
+ *   d_X [S][E] c64, d_P [3][E] float64, d_dirs [3][T] float64, d_out [S][T] c64.
+ *   replaces compute_synthetic_response / compute_response_at_steering_angle
+ *   (processors/simple_synthetic_array_beamformer_processor_multiFrame.py:499-585).
+ * mmw_capon: MVDR spectrum on a V-element half-wavelength ULA; NO upstream implementation exists
+ *    -- definition in DESIGN.md; d_X [V][R][K] c64, d_out [R][T] float32. */
+int mmw_bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs,
+                 void *d_out, int S, int E, int T, double lambda_m);
+int mmw_capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out,
+              int V, int R, int K, int T, double delta);
+
+/* ---------------------------------------------------------------- element-wise helpers */
+int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n);
+
+/* ---------------------------------------------------------------- per-kernel timing hook for bench.py
+ * Average duration (ms) of the most recent launch group of the named kernel family measured
+ * with HIP events on the ctx stream: "rd", "angle", "cfar".  Enabled by mmw_profile_enable(1). */
+int mmw_profile_enable(mmw_ctx *ctx, int on);
+int mmw_profile_get(mmw_ctx *ctx, const char *family, float *total_ms, int *launches);
+int mmw_profile_reset(mmw_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMWGPU_H */

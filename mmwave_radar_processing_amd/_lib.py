@@ -1,0 +1,260 @@
+"""ctypes binding of ``libmmwgpu.so`` (C ABI in ``include/mmwgpu.h``).
+
+This is the ONLY compute backend of the package: there is no NumPy fallback.
+If the shared library is missing, or no gfx950 device is visible, every
+processor / detector raises ``MmwGpuError`` -- loudly, by design.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmwgpu.so")
+
+MMW_OK = 0
+MMW_ERR_TRUNCATED = -4
+CFAR_CA, CFAR_OS, CFAR_GO, CFAR_SO = 0, 1, 2, 3
+
+
+class MmwGpuError(RuntimeError):
+    """Raised for any non-zero status of the C ABI, or when the HIP library cannot be used."""
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_vp, _i, _d, _f, _sz = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+# name -> argtypes; every function returns int except the two string getters
+_SIGNATURES = {
+    "mmw_device_count": [_ip],
+    "mmw_device_info": [_i, C.c_char_p, _i, C.c_char_p, _i, _ip, C.POINTER(_sz)],
+    "mmw_ctx_create": [C.POINTER(_vp), _i],
+    "mmw_ctx_destroy": [_vp],
+    "mmw_sync": [_vp],
+    "mmw_malloc": [_vp, C.POINTER(_vp), _sz],
+    "mmw_free": [_vp, _vp],
+    "mmw_memcpy_h2d": [_vp, _vp, _vp, _sz],
+    "mmw_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "mmw_memset": [_vp, _vp, _i, _sz],
+    "mmw_timer_start": [_vp],
+    "mmw_timer_stop": [_vp, C.POINTER(_f)],
+    "mmw_synth_cubes": [_vp, _vp, _i, _i, _i, _i, C.c_uint64, _i, _f],
+    "mmw_virtual_array_reformat": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_range_doppler": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "mmw_range_doppler_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_angle_fft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "mmw_chain3d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "mmw_range_profile": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_range_profile_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_range_angle": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _i, _i],
+    "mmw_cfar2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i],
+    "mmw_cfar1d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i],
+    "mmw_compact2d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "mmw_angle_argmax": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i],
+    "mmw_bartlett": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d],
+    "mmw_capon": [_vp, _vp, C.POINTER(_d), _vp, _i, _i, _i, _i, _d],
+    "mmw_abs_c64": [_vp, _vp, _vp, _sz],
+    "mmw_profile_enable": [_vp, _i],
+    "mmw_profile_get": [_vp, C.c_char_p, C.POINTER(_f), _ip],
+    "mmw_profile_reset": [_vp],
+}
+EXPORTED = tuple(sorted(list(_SIGNATURES) + ["mmw_version", "mmw_last_error"]))
+
+
+def load_library():
+    """dlopen the in-tree HIP library and declare prototypes; raises if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MmwGpuError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mmwave_radar_processing_amd/csrc` (needs hipcc, --offload-arch=gfx950)")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the host
+            raise MmwGpuError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, args in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        lib.mmw_version.restype = C.c_char_p
+        lib.mmw_last_error.restype = C.c_char_p
+        _lib = lib
+        return lib
+
+
+def check(status: int, ok_truncated: bool = False) -> int:
+    if status == MMW_OK or (ok_truncated and status == MMW_ERR_TRUNCATED):
+        return status
+    msg = load_library().mmw_last_error().decode("utf-8", "replace")
+    if status == -1:
+        raise ValueError(msg)       # the reference raises ValueError for bad arguments
+    raise MmwGpuError(f"libmmwgpu status {status}: {msg}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load_library().mmw_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info(device: int = 0) -> dict:
+    name = C.create_string_buffer(256)
+    arch = C.create_string_buffer(256)
+    ncu = C.c_int(0)
+    mem = C.c_size_t(0)
+    check(load_library().mmw_device_info(device, name, 256, arch, 256, C.byref(ncu), C.byref(mem)))
+    return dict(name=name.value.decode(), arch=arch.value.decode(), num_cu=ncu.value, total_mem=mem.value)
+
+
+class DeviceBuffer:
+    """A block of HBM owned by a Context; ``ptr`` is the raw device address."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(ctx.lib.mmw_malloc(ctx.handle, C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def at(self, byte_offset: int) -> int:
+        return self.ptr + int(byte_offset)
+
+    def upload(self, arr: np.ndarray, byte_offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        if byte_offset + arr.nbytes > self.nbytes:
+            raise ValueError("upload exceeds device buffer")
+        check(self.ctx.lib.mmw_memcpy_h2d(self.ctx.handle, self.ptr + byte_offset, arr.ctypes.data, arr.nbytes))
+
+    def download(self, shape, dtype, byte_offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if byte_offset + out.nbytes > self.nbytes:
+            raise ValueError("download exceeds device buffer")
+        check(self.ctx.lib.mmw_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + byte_offset, out.nbytes))
+        return out
+
+    def zero(self):
+        check(self.ctx.lib.mmw_memset(self.ctx.handle, self.ptr, 0, self.nbytes))
+
+    def free(self):
+        if self.ptr:
+            check(self.ctx.lib.mmw_free(self.ctx.handle, self.ptr))
+            self.ptr = 0
+
+
+class Context:
+    """One HIP device + stream.  Not thread-safe; one per host thread (include/mmwgpu.h)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        if device_count() < 1:
+            raise MmwGpuError("no HIP device visible: the MI355X HIP path is the only backend")
+        h = C.c_void_p()
+        check(self.lib.mmw_ctx_create(C.byref(h), int(device)))
+        self.handle = h
+        self.device = int(device)
+        self._cache = {}
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def cached(self, key, nbytes: int) -> DeviceBuffer:
+        """Grow-only named buffer, reused across process() calls of one processor."""
+        buf = self._cache.get(key)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                buf.free()
+            buf = self.alloc(nbytes)
+            self._cache[key] = buf
+        return buf
+
+    def sync(self):
+        check(self.lib.mmw_sync(self.handle))
+
+    def timer_start(self):
+        check(self.lib.mmw_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0)
+        check(self.lib.mmw_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on: bool = True):
+        check(self.lib.mmw_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        check(self.lib.mmw_profile_reset(self.handle))
+
+    def profile_get(self, family: str):
+        ms, n = C.c_float(0), C.c_int(0)
+        check(self.lib.mmw_profile_get(self.handle, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self.handle:
+            self.lib.mmw_ctx_destroy(self.handle)
+            self.handle = None
+            self._cache = {}
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BufferSet:
+    """Grow-only named device buffers owned by one processor / detector object."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._bufs = {}
+
+    def get(self, name: str, nbytes: int) -> DeviceBuffer:
+        buf = self._bufs.get(name)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                buf.free()
+            buf = self.ctx.alloc(max(int(nbytes), 16))
+            self._bufs[name] = buf
+        return buf
+
+    def free(self):
+        for buf in self._bufs.values():
+            try:
+                buf.free()
+            except Exception:
+                pass
+        self._bufs = {}
+
+    def __del__(self):
+        if getattr(self.ctx, "handle", None):
+            self.free()
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    """Process-wide context on ``$MMW_DEVICE`` (else ``$LOCAL_RANK``, else 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("MMW_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = device_count()
+        if n < 1:
+            raise MmwGpuError("no HIP device visible: the MI355X HIP path is the only backend")
+        _default_ctx = Context(dev % n)
+    return _default_ctx
+
+
+def int_array(values):
+    vals = [int(v) for v in values]
+    return (C.c_int * max(1, len(vals)))(*vals), len(vals)

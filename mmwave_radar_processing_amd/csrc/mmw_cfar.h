@@ -1,0 +1,224 @@
+// CFAR detectors in float64 and ordered compaction of the detection mask.
+//
+// Thresholds reproduce the reference's arithmetic bit for bit when given the same float64 input:
+// the training-cell sums are accumulated in the ORDER NumPy uses for the reference's expressions
+// (probed against numpy 2.2.6 in the build container; the pairwise kernel is unchanged since 1.x):
+//   CaCFAR2D (detectors/ca_cfar.py:134-136)  np.sum(windows*mask, axis=(2,3)):
+//       per window row an 8-accumulator pairwise sum over Wd entries (masked entries are +0.0),
+//       rows added sequentially, then / N.
+//   CaCFAR1D (ca_cfar.py:51-54)  np.mean(windows[:, mask], axis=1): the fancy-indexed copy is
+//       F-ordered, so the reduction is a plain left-to-right sum over [left cells, right cells], / N.
+//   Go/SoCFAR1D (go_so_cfar.py:43-55)  np.mean over contiguous views: pairwise sum per side, / num_train.
+//   OsCFAR (os_cfar.py:68-73,176-177)  np.partition(...)[k-1] == the k-th smallest: exact selection.
+// Decision rule X > T strict; outside the valid region T = +inf, noise = 0 (ca_cfar.py:96-97,144-153).
+#pragma once
+#include "mmw_ctx.h"
+
+namespace mmw {
+
+// NumPy's pairwise_sum (numpy/core/src/umath/loops_utils.h.src) for n <= 128 * 2^DEPTH.
+template <int DEPTH, typename G> __device__ double np_pairwise(G get, int lo, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += get(lo + i);
+        return res;
+    }
+    if (n <= 128 || DEPTH == 0) {
+        double r0 = get(lo + 0), r1 = get(lo + 1), r2 = get(lo + 2), r3 = get(lo + 3);
+        double r4 = get(lo + 4), r5 = get(lo + 5), r6 = get(lo + 6), r7 = get(lo + 7);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+            r0 += get(lo + i + 0); r1 += get(lo + i + 1); r2 += get(lo + i + 2); r3 += get(lo + i + 3);
+            r4 += get(lo + i + 4); r5 += get(lo + i + 5); r6 += get(lo + i + 6); r7 += get(lo + i + 7);
+        }
+        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res += get(lo + i);
+        return res;
+    }
+    if constexpr (DEPTH > 0) {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise<DEPTH - 1>(get, lo, n2) + np_pairwise<DEPTH - 1>(get, lo + n2, n - n2);
+    }
+    return 0.0;
+}
+
+// order-preserving key of a double (total order, negatives included)
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unkey(unsigned long long k) {
+    unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// k-th smallest (1-based) of the values get(0..n) by bitwise bisection on the ordered key.
+template <typename G> __device__ double kth_smallest(G get, int n, int k) {
+    unsigned long long prefix = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+        const unsigned long long cand = prefix | (1ull << bit);
+        int below = 0;
+        for (int i = 0; i < n; ++i) below += (f64_key(get(i)) < cand) ? 1 : 0;
+        if (below < k) prefix = cand;
+    }
+    return f64_unkey(prefix);
+}
+
+struct Cfar2dArgs {
+    const double *X;
+    double *thr, *noise;
+    uint8_t *mask;
+    int R, D;
+    int kind;
+    int tr, td, gr, gd;
+    double scale;
+    int k_rank;
+};
+
+constexpr int CFAR_TR = 16, CFAR_TC = 16;
+
+__global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *tile = reinterpret_cast<double *>(smem);
+    const int hr = p.tr + p.gr, hd = p.td + p.gd;
+    const int TW = CFAR_TC + 2 * hd, TH = CFAR_TR + 2 * hr;
+    const long plane = (long)p.R * p.D;
+    const double *X = p.X + (long)blockIdx.z * plane;
+    const int r0 = blockIdx.y * CFAR_TR, c0 = blockIdx.x * CFAR_TC;
+    for (int t = threadIdx.x; t < TW * TH; t += CFAR_TR * CFAR_TC) {
+        const int rr = r0 - hr + t / TW, cc = c0 - hd + t % TW;
+        tile[t] = (rr >= 0 && rr < p.R && cc >= 0 && cc < p.D) ? X[(long)rr * p.D + cc] : 0.0;
+    }
+    __syncthreads();
+    const int lr = threadIdx.x / CFAR_TC, lc = threadIdx.x % CFAR_TC;
+    const int r = r0 + lr, c = c0 + lc;
+    if (r >= p.R || c >= p.D) return;
+    const long o = (long)blockIdx.z * plane + (long)r * p.D + c;
+    double thr = INFINITY, est = 0.0;
+    const bool valid = r >= hr && r < p.R - hr && c >= hd && c < p.D - hd;
+    if (valid) {
+        const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
+        const int ntrain = Wr * Wd - (2 * p.gr + 1) * (2 * p.gd + 1);
+        // window row wr, column wd (both relative to the window's top-left corner)
+        auto cell = [&](int wr, int wd) { return tile[(lr + wr) * TW + lc + wd]; };
+        auto guarded = [&](int wr, int wd) {
+            return wr >= p.tr && wr <= p.tr + 2 * p.gr && wd >= p.td && wd <= p.td + 2 * p.gd;
+        };
+        if (p.kind == MMW_CFAR_CA) {
+            double sum = 0.0;
+            for (int wr = 0; wr < Wr; ++wr)
+                sum += np_pairwise<2>([&](int wd) { return guarded(wr, wd) ? 0.0 : cell(wr, wd); }, 0, Wd);
+            est = sum / (double)ntrain;
+        } else {  // OS: k-th smallest of the training cells
+            auto train = [&](int i) {
+                // enumerate training cells in row-major window order, skipping the guard block
+                const int gw = 2 * p.gd + 1, g0 = p.tr * Wd;                 // cells before the guard rows
+                const int per_guard_row = Wd - gw, gspan = (2 * p.gr + 1) * per_guard_row;
+                int wr, wd;
+                if (i < g0) { wr = i / Wd; wd = i % Wd; }
+                else if (i < g0 + gspan) {
+                    const int q = i - g0;
+                    wr = p.tr + q / per_guard_row;
+                    wd = q % per_guard_row;
+                    if (wd >= p.td) wd += gw;
+                } else {
+                    const int q = i - g0 - gspan;
+                    wr = p.tr + 2 * p.gr + 1 + q / Wd;
+                    wd = q % Wd;
+                }
+                return cell(wr, wd);
+            };
+            est = kth_smallest(train, ntrain, p.k_rank);
+        }
+        thr = p.scale * est;
+    }
+    if (p.thr) p.thr[o] = thr;
+    if (p.noise) p.noise[o] = est;
+    if (p.mask) p.mask[o] = (tile[(lr + hr) * TW + lc + hd] > thr) ? 1 : 0;
+}
+
+struct Cfar1dArgs {
+    const double *x;
+    double *thr, *noise;
+    uint8_t *mask;
+    int n_rows, L;
+    int kind, T, G;
+    double scale;
+    int k_rank;
+};
+
+__global__ __launch_bounds__(256) void k_cfar1d(Cfar1dArgs p) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)p.n_rows * p.L) return;
+    const int i = (int)(gid % p.L);
+    const double *x = p.x + (gid - i);
+    const int half = p.T + p.G;
+    double thr = INFINITY, est = 0.0;
+    if (i >= half && i < p.L - half) {
+        const double *w = x + (i - half);          // window start
+        const int rs = p.T + 2 * p.G + 1;            // start of the right training cells
+        if (p.kind == MMW_CFAR_CA) {
+            double s = 0.0;
+            for (int q = 0; q < p.T; ++q) s += w[q];
+            for (int q = 0; q < p.T; ++q) s += w[rs + q];
+            est = s / (double)(2 * p.T);
+        } else if (p.kind == MMW_CFAR_OS) {
+            est = kth_smallest([&](int q) { return q < p.T ? w[q] : w[rs + q - p.T]; }, 2 * p.T, p.k_rank);
+        } else {
+            const double ml = np_pairwise<2>([&](int q) { return w[q]; }, 0, p.T) / (double)p.T;
+            const double mr = np_pairwise<2>([&](int q) { return w[rs + q]; }, 0, p.T) / (double)p.T;
+            est = (p.kind == MMW_CFAR_GO) ? fmax(ml, mr) : fmin(ml, mr);
+        }
+        thr = p.scale * est;
+    }
+    if (p.thr) p.thr[gid] = thr;
+    if (p.noise) p.noise[gid] = est;
+    if (p.mask) p.mask[gid] = (x[i] > thr) ? 1 : 0;
+}
+
+// Ordered compaction: one workgroup per frame, each thread owns a contiguous run of cells so the
+// emitted (row, col) list is in np.where's row-major order (detectors/base.py:229-230).
+__global__ __launch_bounds__(1024) void k_compact2d(const uint8_t *mask, int32_t *dets, int32_t *counts,
+                                                    int R, int D, int cap) {
+    __shared__ int wave_tot[16];
+    __shared__ int wave_off[16];
+    const long cells = (long)R * D;
+    const uint8_t *m = mask + (long)blockIdx.x * cells;
+    const int per = (int)((cells + 1023) / 1024);
+    const long lo = (long)threadIdx.x * per;
+    const long hi = lo + per < cells ? lo + per : cells;
+    int cnt = 0;
+    for (long i = lo; i < hi; ++i) cnt += m[i] ? 1 : 0;
+    // wave-level inclusive scan, then scan of the 16 wave totals
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < 16; ++w) {
+            wave_off[w] = run;
+            run += wave_tot[w];
+        }
+        counts[blockIdx.x] = run;
+    }
+    __syncthreads();
+    int pos = wave_off[wave] + incl - cnt;
+    int32_t *out = dets + (long)blockIdx.x * cap * 2;
+    for (long i = lo; i < hi; ++i) {
+        if (m[i]) {
+            if (pos < cap) {
+                out[2 * pos] = (int32_t)(i / D);
+                out[2 * pos + 1] = (int32_t)(i % D);
+            }
+            ++pos;
+        }
+    }
+}
+
+}  // namespace mmw

@@ -1,0 +1,192 @@
+// Context, error plumbing and cached device tables (twiddles, windows) for libmmwgpu.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/mmwgpu.h"
+#include "mmw_fft.h"
+
+namespace mmw {
+
+inline thread_local std::string g_last_error;
+
+inline int set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define MMW_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return mmw::set_error(MMW_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+                                  hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+#define MMW_REQUIRE(cond, ...)                                                               \
+    do {                                                                                     \
+        if (!(cond)) return mmw::set_error(MMW_ERR_INVALID, __VA_ARGS__);                    \
+    } while (0)
+
+#define MMW_TRY(expr)                                                                        \
+    do {                                                                                     \
+        int rc_ = (expr);                                                                    \
+        if (rc_ != MMW_OK) return rc_;                                                       \
+    } while (0)
+
+struct ProfileSlot {
+    double total_ms = 0.0;
+    int launches = 0;
+};
+
+enum TableKind { TAB_TWIDDLE = 0, TAB_HANN = 1, TAB_HAMMING = 2 };
+
+struct PendingSpan {
+    const char *family;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace mmw
+
+struct mmw_ctx {
+    int device = 0;
+    int num_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;      // mmw_timer_*
+    bool profiling = false;                     // per-family kernel timing (mmw_profile_*)
+    std::map<std::string, mmw::ProfileSlot> prof;
+    std::vector<hipEvent_t> ev_pool;            // idle events
+    std::vector<mmw::PendingSpan> ev_pending;   // recorded, not yet read back
+    // (kind, N, is_double) -> device table
+    std::map<std::tuple<int, int, int>, void *> tables;
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::vector<void *> owned;  // mmw_malloc'ed blocks still alive (freed at destroy)
+};
+
+namespace mmw {
+
+// np.hanning / np.hamming: w[i] = a + b*cos(pi*(2i-(M-1))/(M-1)), M == 1 -> 1.0
+// (the reference builds its windows with these: processors/range_doppler_resp.py:62,66;
+//  simple_synthetic_array_beamformer_processor_multiFrame.py:537,567)
+inline double np_window(int kind, int i, int M) {
+    if (M == 1) return 1.0;
+    const double n = (double)(1 - M + 2 * i);
+    const double c = std::cos(M_PI * n / (double)(M - 1));
+    return kind == TAB_HANN ? 0.5 + 0.5 * c : 0.54 + 0.46 * c;
+}
+
+template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **out) {
+    const auto key = std::make_tuple(kind, N, (int)(sizeof(T) == 8));
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return MMW_OK;
+    }
+    const size_t elems = (kind == TAB_TWIDDLE) ? 2 * (size_t)N : (size_t)N;
+    std::vector<T> h(elems);
+    if (kind == TAB_TWIDDLE) {
+        for (int m = 0; m < N; ++m) {
+            // exact octant symmetries keep W^0, W^(N/4), ... exact
+            const long double ang = -2.0L * M_PIl * (long double)m / (long double)N;
+            long double c = cosl(ang), s = sinl(ang);
+            if ((4 * m) % N == 0) {  // quarter turns are exact
+                const int q = (4 * m) / N;
+                c = (q == 0) ? 1.0L : (q == 2 ? -1.0L : 0.0L);
+                s = (q == 1) ? -1.0L : (q == 3 ? 1.0L : 0.0L);
+            }
+            h[2 * m] = (T)c;
+            h[2 * m + 1] = (T)s;
+        }
+    } else {
+        for (int i = 0; i < N; ++i) h[i] = (T)np_window(kind, i, N);
+    }
+    void *d = nullptr;
+    if (hipMalloc(&d, elems * sizeof(T)) != hipSuccess)
+        return set_error(MMW_ERR_NOMEM, "hipMalloc(%zu) for table failed", elems * sizeof(T));
+    MMW_HIP(hipMemcpyAsync(d, h.data(), elems * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    MMW_HIP(hipStreamSynchronize(ctx->stream));  // h goes out of scope
+    ctx->tables[key] = d;
+    *out = d;
+    return MMW_OK;
+}
+
+inline int ensure_scratch(mmw_ctx *ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return MMW_OK;
+    if (ctx->scratch) {
+        MMW_HIP(hipStreamSynchronize(ctx->stream));
+        MMW_HIP(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    if (hipMalloc(&ctx->scratch, bytes) != hipSuccess)
+        return set_error(MMW_ERR_NOMEM, "hipMalloc(%zu) for scratch failed", bytes);
+    ctx->scratch_bytes = bytes;
+    return MMW_OK;
+}
+
+// Profiling bracket: records an event pair around a launch group on the ctx stream WITHOUT a host
+// sync, so the timed region is not perturbed; mmw_profile_get drains the pairs afterwards.
+inline hipEvent_t take_event(mmw_ctx *ctx) {
+    if (!ctx->ev_pool.empty()) {
+        hipEvent_t e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+inline void drain_profile(mmw_ctx *ctx) {
+    for (auto &sp : ctx->ev_pending) {
+        float ms = 0.f;
+        if (sp.e0 && sp.e1 && hipEventSynchronize(sp.e1) == hipSuccess &&
+            hipEventElapsedTime(&ms, sp.e0, sp.e1) == hipSuccess) {
+            auto &s = ctx->prof[sp.family];
+            s.total_ms += ms;
+            s.launches += 1;
+        }
+        if (sp.e0) ctx->ev_pool.push_back(sp.e0);
+        if (sp.e1) ctx->ev_pool.push_back(sp.e1);
+    }
+    ctx->ev_pending.clear();
+}
+
+struct ProfScope {
+    mmw_ctx *ctx;
+    PendingSpan span;
+    bool on;
+    ProfScope(mmw_ctx *c, const char *f) : ctx(c), span{f, nullptr, nullptr}, on(c->profiling) {
+        if (!on) return;
+        span.e0 = take_event(ctx);
+        span.e1 = take_event(ctx);
+        if (span.e0) (void)hipEventRecord(span.e0, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        if (span.e1) (void)hipEventRecord(span.e1, ctx->stream);
+        ctx->ev_pending.push_back(span);
+    }
+};
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(MMW_ERR_HIP, "launch %s failed: %s", what, hipGetErrorString(e));
+    return MMW_OK;
+}
+
+}  // namespace mmw

@@ -1,0 +1,155 @@
+// Small kernels around the FFT chain: synthetic input generation in HBM, TDM de-interleave,
+// |.|, range-profile averaging and the per-detection angle FFT + argmax of the point cloud.
+#pragma once
+#include "mmw_ctx.h"
+
+namespace mmw {
+
+// ------------------------------------------------------------------ counter-based RNG
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(unsigned long long h) {           // (0, 1]
+    return ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+constexpr int SYNTH_MAX_TARGETS = 16;
+
+// One thread per cube element.  Target parameters are re-derived per thread from (seed0 + frame, k)
+// so no parameter buffer is needed; values are rounded to integers like a 16-bit ADC.
+__global__ __launch_bounds__(256) void k_synth(float2 *cubes, long total, int V, int S, int C,
+                                                unsigned long long seed0, int num_targets, float sigma) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % C);
+    const int s = (int)((gid / C) % S);
+    const int v = (int)((gid / ((long)C * S)) % V);
+    const unsigned long long f = (unsigned long long)(gid / ((long)C * S * V));
+    const unsigned long long fs = mix64(seed0 + f);
+    float re = 0.f, im = 0.f;
+    for (int k = 0; k < num_targets; ++k) {
+        const unsigned long long b = mix64(fs ^ (0x1000ull * (k + 1)));
+        const float f_r = 0.02f + 0.43f * u01(mix64(b + 1));
+        const float f_d = -0.45f + 0.90f * u01(mix64(b + 2));
+        const float f_a = -0.40f + 0.80f * u01(mix64(b + 3));
+        const float amp = 20.f + 380.f * u01(mix64(b + 4));
+        const float phi = u01(mix64(b + 5));
+        float ph = f_r * (float)s;
+        ph -= floorf(ph);
+        float t = f_d * (float)c;
+        ph += t - floorf(t);
+        t = f_a * (float)v;
+        ph += t - floorf(t) + phi;
+        ph -= floorf(ph);
+        float sn, cs;
+        sincospif(2.0f * ph, &sn, &cs);
+        re += amp * cs;
+        im += amp * sn;
+    }
+    const unsigned long long h = mix64(fs ^ mix64((unsigned long long)gid * 2 + 0x51ull));
+    const float u1 = u01(h), u2 = u01(mix64(h + 7));
+    const float rad = sigma * sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    cubes[gid] = make_float2(rintf(re + rad * cs), rintf(im + rad * sn));
+}
+
+// raw[F][num_rx][S][num_tx*loops] -> virt[F][num_tx*num_rx][S][loops]; virtual antenna t*num_rx + r
+// takes every num_tx-th chirp starting at t (processors/virtual_array_reformater.py:53-63).
+__global__ __launch_bounds__(256) void k_reformat(const float2 *raw, float2 *virt, long total,
+                                                   int num_rx, int num_tx, int S, int loops) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int l = (int)(gid % loops);
+    const int s = (int)((gid / loops) % S);
+    const int va = (int)((gid / ((long)loops * S)) % (num_rx * num_tx));
+    const long f = gid / ((long)loops * S * num_rx * num_tx);
+    const int t = va / num_rx, r = va % num_rx;
+    virt[gid] = raw[((f * num_rx + r) * S + s) * ((long)num_tx * loops) + (long)l * num_tx + t];
+}
+
+__global__ __launch_bounds__(256) void k_abs_c64(const float2 *in, float *out, size_t n) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid < n) {
+        const float2 v = in[gid];
+        out[gid] = hypotf(v.x, v.y);
+    }
+}
+
+// out[f][s] = mean_v |spec[f][v][s]|   (processors/range_resp.py:55-57; np.mean over axis 0 adds the
+// antenna rows in order, which the loop reproduces)
+template <typename T>
+__global__ __launch_bounds__(256) void k_mean_abs_over_v(const cplx<T> *spec, T *out, int F, int V, int S) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)F * S) return;
+    const int s = (int)(gid % S);
+    const long f = gid / S;
+    T acc = (T)0;
+    for (int v = 0; v < V; ++v) {
+        const cplx<T> x = spec[(f * V + v) * S + s];
+        if constexpr (sizeof(T) == 8) acc += hypot(x.x, x.y);
+        else acc += hypotf(x.x, x.y);
+    }
+    out[gid] = acc / (T)V;
+}
+
+constexpr int MAX_ANT = 32;
+struct AntList {
+    int n;
+    int idx[MAX_ANT];
+};
+
+// One wave per detection: gather rd[f][ant[i]][r][v], lane k evaluates angle bins k, k+64, ... of the
+// zero-padded A-point DFT, first-max argmax over the (optionally fftshifted) response.
+// (processors/point_cloud_generator.py:168-214; np.argmax returns the FIRST maximum.)
+__global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const int32_t *dets, const int32_t *counts,
+                                                       int32_t *out_idx, int V, int S, int C, int cap,
+                                                       AntList ants, int A, int shift, const float2 *twA) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int det = blockIdx.x * 4 + wave;
+    const int f = blockIdx.y;
+    int n_det = counts[f];
+    if (n_det > cap) n_det = cap;
+    if (det >= n_det) return;
+    const int r = dets[((long)f * cap + det) * 2], v = dets[((long)f * cap + det) * 2 + 1];
+    float2 x[MAX_ANT];
+#pragma unroll
+    for (int i = 0; i < MAX_ANT; ++i)
+        x[i] = (i < ants.n) ? rd[(((long)f * V + ants.idx[i]) * S + r) * C + v] : make_float2(0.f, 0.f);
+    float best = -1.f;
+    int best_idx = 0x7fffffff;
+    for (int k = lane; k < A; k += 64) {
+        float re = 0.f, im = 0.f;
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_ANT; ++i) {
+            if (i < ants.n) {
+                const float2 w = twA[t];
+                re += x[i].x * w.x - x[i].y * w.y;
+                im += x[i].x * w.y + x[i].y * w.x;
+                t += k;
+                if (t >= A) t -= A;
+            }
+        }
+        const float m = hypotf(re, im);
+        const int kk = shift ? (k + A / 2) % A : k;
+        if (m > best || (m == best && kk < best_idx)) {
+            best = m;
+            best_idx = kk;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d, 64);
+        const int oi = __shfl_xor(best_idx, d, 64);
+        if (ob > best || (ob == best && oi < best_idx)) {
+            best = ob;
+            best_idx = oi;
+        }
+    }
+    if (lane == 0) out_idx[(long)f * cap + det] = best_idx;
+}
+
+}  // namespace mmw

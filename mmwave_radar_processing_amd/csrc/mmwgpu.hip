@@ -1,0 +1,531 @@
+// libmmwgpu.so -- extern "C" entry points declared in include/mmwgpu.h.
+#include "mmw_ctx.h"
+#include "mmw_fft_generic.h"
+#include "mmw_fft_fused.h"
+#include "mmw_cfar.h"
+#include "mmw_misc.h"
+#include "mmw_beamform.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+using namespace mmw;
+
+namespace {
+
+int env_int(const char *name, int dflt) {
+    const char *s = std::getenv(name);
+    return (s && *s) ? std::atoi(s) : dflt;
+}
+
+bool fused_rd_ok(int, int) { return false; }
+
+int abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
+    if (n == 0) return MMW_OK;
+    hipLaunchKernelGGL(k_abs_c64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float2 *)d_in, d_out, n);
+    return check_launch("abs_c64");
+}
+
+// Range FFT (windows on both axes folded into the load) then in-place Doppler FFT + fftshift.
+int range_doppler_generic(mmw_ctx *ctx, const void *d_cubes, void *d_out, int F, int V, int S, int C) {
+    FftArgs a{};
+    a.in = d_cubes;
+    a.out = d_out;
+    a.outer = F * V;
+    a.inner = C;
+    a.n_in = S;
+    a.in_outer_stride = a.out_outer_stride = (long)S * C;
+    a.in_axis_stride = a.out_axis_stride = C;
+    a.in_inner_stride = a.out_inner_stride = 1;
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &a.win_axis));
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, C, &a.win_inner));
+    a.scale = 1.0;
+    MMW_TRY((launch_fft_axis<float, float>(ctx, a, S, false)));
+    FftArgs b{};
+    b.in = d_out;
+    b.out = d_out;  // each workgroup reads its rows completely before it writes them
+    b.outer = F * V * S;
+    b.inner = 1;
+    b.n_in = C;
+    b.in_outer_stride = b.out_outer_stride = C;
+    b.in_axis_stride = b.out_axis_stride = 1;
+    b.scale = 1.0;
+    b.shift = 1;
+    return launch_fft_axis<float, float>(ctx, b, C, true);
+}
+
+template <typename T>
+int range_profile_impl(mmw_ctx *ctx, const void *d_cubes, T *d_out, int n_frames, int V, int S, int C,
+                       int chirp_idx) {
+    MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0, "bad shape");
+    MMW_REQUIRE(chirp_idx >= -C && chirp_idx < C, "chirp_idx %d out of range", chirp_idx);
+    if (chirp_idx < 0) chirp_idx += C;  // numpy negative indexing
+    if (n_frames == 0) return MMW_OK;
+    MMW_TRY(ensure_scratch(ctx, (size_t)n_frames * V * S * sizeof(cplx<T>)));
+    FftArgs a{};
+    a.in = (const cplx<float> *)d_cubes + chirp_idx;
+    a.out = ctx->scratch;
+    a.outer = n_frames * V;
+    a.inner = 1;
+    a.n_in = S;
+    a.in_outer_stride = (long)S * C;
+    a.in_axis_stride = C;
+    a.in_inner_stride = 1;
+    a.out_outer_stride = S;
+    a.out_axis_stride = 1;
+    a.out_inner_stride = 1;
+    MMW_TRY(get_table<T>(ctx, TAB_HANN, S, &a.win_axis));
+    a.scale = 1.0;
+    MMW_TRY((launch_fft_axis<T, float>(ctx, a, S, false)));
+    const long n = (long)n_frames * S;
+    hipLaunchKernelGGL((k_mean_abs_over_v<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const cplx<T> *)ctx->scratch, d_out, n_frames, V, S);
+    return check_launch("mean_abs_over_v");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mmw_version(void) { return "mmwgpu 0.1 (gfx950)"; }
+const char *mmw_last_error(void) { return g_last_error.c_str(); }
+
+int mmw_device_count(int *count) {
+    MMW_REQUIRE(count, "count is null");
+    MMW_HIP(hipGetDeviceCount(count));
+    return MMW_OK;
+}
+
+int mmw_device_info(int device, char *name, int name_len, char *arch, int arch_len, int *num_cu,
+                    size_t *total_mem) {
+    hipDeviceProp_t prop;
+    MMW_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) snprintf(name, name_len, "%s", prop.name);
+    if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+    if (num_cu) *num_cu = prop.multiProcessorCount;
+    if (total_mem) *total_mem = prop.totalGlobalMem;
+    return MMW_OK;
+}
+
+int mmw_ctx_create(mmw_ctx **out, int device) {
+    MMW_REQUIRE(out, "out is null");
+    int n = 0;
+    MMW_HIP(hipGetDeviceCount(&n));
+    MMW_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
+    MMW_HIP(hipSetDevice(device));
+    mmw_ctx *c = new mmw_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    MMW_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount;
+    MMW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MMW_HIP(hipEventCreate(&c->t0));
+    MMW_HIP(hipEventCreate(&c->t1));
+    *out = c;
+    return MMW_OK;
+}
+
+int mmw_ctx_destroy(mmw_ctx *ctx) {
+    if (!ctx) return MMW_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->tables) (void)hipFree(kv.second);
+    for (void *p : ctx->owned) (void)hipFree(p);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipEventDestroy(ctx->t0);
+    (void)hipEventDestroy(ctx->t1);
+    drain_profile(ctx);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MMW_OK;
+}
+
+int mmw_sync(mmw_ctx *ctx) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_HIP(hipStreamSynchronize(ctx->stream));
+    return MMW_OK;
+}
+
+int mmw_malloc(mmw_ctx *ctx, void **d_ptr, size_t bytes) {
+    MMW_REQUIRE(ctx && d_ptr, "null argument");
+    MMW_HIP(hipSetDevice(ctx->device));
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess)
+        return set_error(MMW_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    ctx->owned.push_back(p);
+    *d_ptr = p;
+    return MMW_OK;
+}
+
+int mmw_free(mmw_ctx *ctx, void *d_ptr) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    if (!d_ptr) return MMW_OK;
+    auto it = std::find(ctx->owned.begin(), ctx->owned.end(), d_ptr);
+    MMW_REQUIRE(it != ctx->owned.end(), "pointer was not allocated by this context");
+    MMW_HIP(hipStreamSynchronize(ctx->stream));
+    MMW_HIP(hipFree(d_ptr));
+    ctx->owned.erase(it);
+    return MMW_OK;
+}
+
+int mmw_memcpy_h2d(mmw_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    MMW_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "null argument");
+    if (!bytes) return MMW_OK;
+    MMW_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MMW_HIP(hipStreamSynchronize(ctx->stream));
+    return MMW_OK;
+}
+
+int mmw_memcpy_d2h(mmw_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    MMW_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "null argument");
+    if (!bytes) return MMW_OK;
+    MMW_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MMW_HIP(hipStreamSynchronize(ctx->stream));
+    return MMW_OK;
+}
+
+int mmw_memset(mmw_ctx *ctx, void *d_dst, int value, size_t bytes) {
+    MMW_REQUIRE(ctx && (bytes == 0 || d_dst), "null argument");
+    if (!bytes) return MMW_OK;
+    MMW_HIP(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return MMW_OK;
+}
+
+int mmw_timer_start(mmw_ctx *ctx) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_HIP(hipEventRecord(ctx->t0, ctx->stream));
+    return MMW_OK;
+}
+
+int mmw_timer_stop(mmw_ctx *ctx, float *elapsed_ms) {
+    MMW_REQUIRE(ctx && elapsed_ms, "null argument");
+    MMW_HIP(hipEventRecord(ctx->t1, ctx->stream));
+    MMW_HIP(hipEventSynchronize(ctx->t1));
+    MMW_HIP(hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+    return MMW_OK;
+}
+
+int mmw_profile_enable(mmw_ctx *ctx, int on) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    ctx->profiling = on != 0;
+    return MMW_OK;
+}
+
+int mmw_profile_reset(mmw_ctx *ctx) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    drain_profile(ctx);
+    ctx->prof.clear();
+    return MMW_OK;
+}
+
+int mmw_profile_get(mmw_ctx *ctx, const char *family, float *total_ms, int *launches) {
+    MMW_REQUIRE(ctx && family, "null argument");
+    drain_profile(ctx);
+    auto it = ctx->prof.find(family);
+    if (total_ms) *total_ms = it == ctx->prof.end() ? 0.f : (float)it->second.total_ms;
+    if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return MMW_OK;
+}
+
+// ------------------------------------------------------------------ input staging
+int mmw_synth_cubes(mmw_ctx *ctx, void *d_cubes, int n_frames, int V, int S, int C, uint64_t seed0,
+                    int num_targets, float noise_sigma) {
+    MMW_REQUIRE(ctx && d_cubes, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0, "bad shape");
+    MMW_REQUIRE(num_targets >= 0 && num_targets <= SYNTH_MAX_TARGETS, "num_targets must be 0..%d", SYNTH_MAX_TARGETS);
+    const long total = (long)n_frames * V * S * C;
+    if (!total) return MMW_OK;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (float2 *)d_cubes, total, V, S, C, (unsigned long long)seed0, num_targets, noise_sigma);
+    return check_launch("synth");
+}
+
+int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, int n_frames, int num_rx,
+                               int num_tx, int S, int loops) {
+    MMW_REQUIRE(ctx && d_raw && d_virt, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && num_rx > 0 && num_tx > 0 && S > 0 && loops > 0, "bad shape");
+    const long total = (long)n_frames * num_rx * num_tx * S * loops;
+    if (!total) return MMW_OK;
+    hipLaunchKernelGGL(k_reformat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float2 *)d_raw, (float2 *)d_virt, total, num_rx, num_tx, S, loops);
+    return check_launch("reformat");
+}
+
+// ------------------------------------------------------------------ FFT chain
+int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_mag_f32, int n_frames, int V,
+                      int S, int C) {
+    MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0, "bad shape");
+    if (n_frames == 0) return MMW_OK;
+    {
+        ProfScope ps(ctx, "rd");
+        if (fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
+            MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C));
+        else
+            MMW_TRY(range_doppler_generic(ctx, d_cubes, d_out, n_frames, V, S, C));
+    }
+    if (d_mag_f32) MMW_TRY(abs_c64(ctx, d_out, (float *)d_mag_f32, (size_t)n_frames * V * S * C));
+    return MMW_OK;
+}
+
+int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S,
+                            int C, int rx_idx) {
+    MMW_REQUIRE(ctx && d_cubes && d_mag, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && rx_idx >= 0 && rx_idx < V, "bad shape / rx_idx");
+    if (n_frames == 0) return MMW_OK;
+    ProfScope ps(ctx, "rd64");
+    MMW_TRY(ensure_scratch(ctx, (size_t)n_frames * S * C * sizeof(cplx<double>)));
+    FftArgs a{};
+    a.in = (const cplx<float> *)d_cubes + (long)rx_idx * S * C;
+    a.out = ctx->scratch;
+    a.outer = n_frames;
+    a.inner = C;
+    a.n_in = S;
+    a.in_outer_stride = (long)V * S * C;
+    a.out_outer_stride = (long)S * C;
+    a.in_axis_stride = a.out_axis_stride = C;
+    a.in_inner_stride = a.out_inner_stride = 1;
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &a.win_axis));
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &a.win_inner));
+    a.scale = 1.0;
+    MMW_TRY((launch_fft_axis<double, float>(ctx, a, S, false)));
+    FftArgs b{};
+    b.in = ctx->scratch;
+    b.out = d_mag;
+    b.outer = n_frames * S;
+    b.inner = 1;
+    b.n_in = C;
+    b.in_outer_stride = b.out_outer_stride = C;
+    b.in_axis_stride = b.out_axis_stride = 1;
+    b.scale = 1.0;
+    b.shift = 1;
+    b.magnitude = 1;
+    return launch_fft_axis<double, double>(ctx, b, C, true);
+}
+
+int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
+                  int magnitude) {
+    MMW_REQUIRE(ctx && d_rd && d_out, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
+    if (n_frames == 0) return MMW_OK;
+    ProfScope ps(ctx, "angle");
+    const long bins = (long)S * C;
+    if (A == 64 && bins % 2 == 0 && n_frames <= 65535 && !env_int("MMW_NO_FUSED_ANGLE", 0) &&
+        (V == 4 || V == 8 || V == 12 || V == 16)) {
+        float h[16];
+        for (int i = 0; i < V; ++i) h[i] = (float)np_window(TAB_HANN, i, V);
+        switch (V) {
+            case 4: return launch_angle64<4>(ctx, d_rd, d_out, n_frames, bins, magnitude != 0, h);
+            case 8: return launch_angle64<8>(ctx, d_rd, d_out, n_frames, bins, magnitude != 0, h);
+            case 12: return launch_angle64<12>(ctx, d_rd, d_out, n_frames, bins, magnitude != 0, h);
+            default: return launch_angle64<16>(ctx, d_rd, d_out, n_frames, bins, magnitude != 0, h);
+        }
+    }
+    FftArgs a{};
+    a.in = d_rd;
+    a.out = d_out;
+    a.outer = n_frames;
+    a.inner = (int)bins;
+    a.n_in = V;
+    a.in_outer_stride = (long)V * bins;
+    a.out_outer_stride = (long)A * bins;
+    a.in_axis_stride = a.out_axis_stride = bins;
+    a.in_inner_stride = a.out_inner_stride = 1;
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, V, &a.win_axis));
+    a.scale = 1.0;
+    a.shift = 1;
+    a.magnitude = magnitude != 0;
+    return launch_fft_axis<float, float>(ctx, a, A, false);
+}
+
+int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames, int V, int S, int C,
+                int A, int magnitude) {
+    MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
+    int chunk = env_int("MMW_CHAIN_CHUNK", 8);
+    if (chunk < 1) chunk = 1;
+    const size_t cube_elems = (size_t)V * S * C;
+    const size_t out_elem_bytes = magnitude ? sizeof(float) : sizeof(cplx<float>);
+    void *rd_scratch = nullptr;
+    if (!d_rd) {
+        // the FFT kernels may use ctx->scratch themselves only on the float64 path, not here
+        MMW_TRY(ensure_scratch(ctx, (size_t)chunk * cube_elems * sizeof(cplx<float>)));
+        rd_scratch = ctx->scratch;
+    }
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, n_frames - f0);
+        const char *in = (const char *)d_cubes + (size_t)f0 * cube_elems * sizeof(cplx<float>);
+        char *rd = d_rd ? (char *)d_rd + (size_t)f0 * cube_elems * sizeof(cplx<float>) : (char *)rd_scratch;
+        char *out = (char *)d_out + (size_t)f0 * A * S * C * out_elem_bytes;
+        MMW_TRY(mmw_range_doppler(ctx, in, rd, nullptr, nf, V, S, C));
+        MMW_TRY(mmw_angle_fft(ctx, rd, out, nf, V, S, C, A, magnitude));
+    }
+    return MMW_OK;
+}
+
+int mmw_range_profile(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C,
+                      int chirp_idx) {
+    return range_profile_impl<float>(ctx, d_cubes, d_out, n_frames, V, S, C, chirp_idx);
+}
+
+int mmw_range_profile_f64(mmw_ctx *ctx, const void *d_cubes, double *d_out, int n_frames, int V, int S, int C,
+                          int chirp_idx) {
+    return range_profile_impl<double>(ctx, d_cubes, d_out, n_frames, V, S, C, chirp_idx);
+}
+
+int mmw_range_angle(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int A,
+                    int chirp_idx, const int *h_rx, int n_rx, int perform_windowing) {
+    MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A > 0, "bad shape");
+    MMW_REQUIRE(chirp_idx >= -C && chirp_idx < C, "chirp_idx %d out of range", chirp_idx);
+    MMW_REQUIRE(n_rx >= 0 && (n_rx == 0 || h_rx), "bad rx list");
+    if (chirp_idx < 0) chirp_idx += C;
+    std::vector<int> rx;
+    if (n_rx == 0)
+        for (int v = 0; v < V; ++v) rx.push_back(v);
+    else
+        for (int i = 0; i < n_rx; ++i) {
+            int r = h_rx[i];
+            if (r < 0) r += V;
+            MMW_REQUIRE(r >= 0 && r < V, "rx index %d out of range", h_rx[i]);
+            rx.push_back(r);
+        }
+    const int n_sel = (int)rx.size();
+    MMW_REQUIRE(n_sel <= A, "more antennas (%d) than angle bins (%d)", n_sel, A);
+    if (n_frames == 0) return MMW_OK;
+    MMW_TRY(ensure_scratch(ctx, (size_t)n_frames * n_sel * S * sizeof(cplx<float>)));
+    for (int i = 0; i < n_sel; ++i) {
+        FftArgs a{};
+        a.in = (const cplx<float> *)d_cubes + (long)rx[i] * S * C + chirp_idx;
+        a.out = (cplx<float> *)ctx->scratch + (long)i * S;
+        a.outer = n_frames;
+        a.inner = 1;
+        a.n_in = S;
+        a.in_outer_stride = (long)V * S * C;
+        a.in_axis_stride = C;
+        a.in_inner_stride = 1;
+        a.out_outer_stride = (long)n_sel * S;
+        a.out_axis_stride = 1;
+        a.out_inner_stride = 1;
+        a.scale = 1.0;
+        if (perform_windowing) {
+            MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &a.win_axis));
+            a.scale = np_window(TAB_HANN, rx[i], V);   // hann over ALL V antennas, then the subset
+        }
+        MMW_TRY((launch_fft_axis<float, float>(ctx, a, S, false)));
+    }
+    FftArgs b{};
+    b.in = ctx->scratch;
+    b.out = d_out;
+    b.outer = n_frames;
+    b.inner = S;
+    b.n_in = n_sel;
+    b.in_outer_stride = (long)n_sel * S;
+    b.in_axis_stride = S;
+    b.in_inner_stride = 1;
+    b.out_outer_stride = (long)S * A;
+    b.out_axis_stride = 1;
+    b.out_inner_stride = A;
+    b.scale = 1.0;
+    b.shift = 1;
+    b.magnitude = 1;
+    return launch_fft_axis<float, float>(ctx, b, A, false);
+}
+
+// ------------------------------------------------------------------ CFAR
+int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, uint8_t *d_mask, int n_frames,
+               int R, int D, int kind, int train_r, int train_d, int guard_r, int guard_d, double scale,
+               int k_rank) {
+    MMW_REQUIRE(ctx && d_X, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && R > 0 && D > 0, "bad shape");
+    MMW_REQUIRE(train_r >= 0 && train_d >= 0 && guard_r >= 0 && guard_d >= 0, "negative window size");
+    MMW_REQUIRE(kind == MMW_CFAR_CA || kind == MMW_CFAR_OS, "2-D CFAR kind must be CA or OS");
+    MMW_REQUIRE(n_frames <= 65535, "at most 65535 frames per call");
+    const int hr = train_r + guard_r, hd = train_d + guard_d;
+    const long ntrain = (long)(2 * hr + 1) * (2 * hd + 1) - (long)(2 * guard_r + 1) * (2 * guard_d + 1);
+    if (kind == MMW_CFAR_OS) MMW_REQUIRE(k_rank >= 1 && k_rank <= ntrain, "k_rank must be between 1 and %ld, got %d", ntrain, k_rank);
+    MMW_REQUIRE(2 * hd + 1 <= 512, "Doppler window too wide for the exact summation order");
+    const size_t lds = (size_t)(CFAR_TR + 2 * hr) * (CFAR_TC + 2 * hd) * sizeof(double);
+    if (lds > 64 * 1024) return set_error(MMW_ERR_UNSUPPORTED, "CFAR window %dx%d too large for the LDS tile", 2 * hr + 1, 2 * hd + 1);
+    if (n_frames == 0) return MMW_OK;
+    ProfScope ps(ctx, "cfar");
+    Cfar2dArgs a{d_X, d_thr, d_noise, d_mask, R, D, kind, train_r, train_d, guard_r, guard_d, scale, k_rank};
+    dim3 grid((D + CFAR_TC - 1) / CFAR_TC, (R + CFAR_TR - 1) / CFAR_TR, n_frames);
+    hipLaunchKernelGGL(k_cfar2d, grid, dim3(CFAR_TR * CFAR_TC), lds, ctx->stream, a);
+    return check_launch("cfar2d");
+}
+
+int mmw_cfar1d(mmw_ctx *ctx, const double *d_x, double *d_thr, double *d_noise, uint8_t *d_mask, int n_rows,
+               int L, int kind, int num_train, int num_guard, double scale, int k_rank) {
+    MMW_REQUIRE(ctx && d_x, "null argument");
+    MMW_REQUIRE(n_rows >= 0 && L > 0 && num_train >= 0 && num_guard >= 0, "bad shape");
+    MMW_REQUIRE(kind >= MMW_CFAR_CA && kind <= MMW_CFAR_SO, "unknown CFAR kind %d", kind);
+    MMW_REQUIRE(num_train <= 512, "num_train too large for the exact summation order");
+    if (kind == MMW_CFAR_OS)
+        MMW_REQUIRE(k_rank >= 1 && k_rank <= 2 * num_train, "k_rank must be between 1 and %d, got %d", 2 * num_train, k_rank);
+    if (n_rows == 0) return MMW_OK;
+    Cfar1dArgs a{d_x, d_thr, d_noise, d_mask, n_rows, L, kind, num_train, num_guard, scale, k_rank};
+    const long total = (long)n_rows * L;
+    hipLaunchKernelGGL(k_cfar1d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    return check_launch("cfar1d");
+}
+
+int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t *d_counts, int n_frames,
+                  int R, int D, int cap) {
+    MMW_REQUIRE(ctx && d_mask && d_dets && d_counts, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && R > 0 && D > 0 && cap >= 0, "bad shape");
+    if (n_frames == 0) return MMW_OK;
+    ProfScope ps(ctx, "compact");
+    hipLaunchKernelGGL(k_compact2d, dim3(n_frames), dim3(1024), 0, ctx->stream, d_mask, d_dets, d_counts, R, D, cap);
+    return check_launch("compact2d");
+}
+
+// ------------------------------------------------------------------ point cloud
+int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, const int32_t *d_counts,
+                     int32_t *d_idx, int n_frames, int V, int S, int C, int cap, const int *h_ant, int n_ant,
+                     int A, int shift) {
+    MMW_REQUIRE(ctx && d_rd && d_dets && d_counts && d_idx, "null argument");
+    MMW_REQUIRE(n_frames >= 0 && n_frames <= 65535 && V > 0 && S > 0 && C > 0 && cap >= 0 && A > 0, "bad shape");
+    MMW_REQUIRE(n_ant >= 1 && n_ant <= MAX_ANT && n_ant <= A && h_ant, "antenna list must have 1..%d entries (<= A)", MAX_ANT);
+    AntList ants{};
+    ants.n = n_ant;
+    for (int i = 0; i < n_ant; ++i) {
+        int a = h_ant[i];
+        if (a < 0) a += V;
+        MMW_REQUIRE(a >= 0 && a < V, "antenna index %d out of range", h_ant[i]);
+        ants.idx[i] = a;
+    }
+    if (n_frames == 0 || cap == 0) return MMW_OK;
+    const void *twA = nullptr;
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, A, &twA));
+    ProfScope ps(ctx, "argmax");
+    dim3 grid((cap + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_angle_argmax, grid, dim3(256), 0, ctx->stream, (const float2 *)d_rd, d_dets, d_counts, d_idx,
+                       V, S, C, cap, ants, A, shift, (const float2 *)twA);
+    return check_launch("angle_argmax");
+}
+
+int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
+    MMW_REQUIRE(ctx && (n == 0 || (d_in && d_out)), "null argument");
+    return abs_c64(ctx, d_in, d_out, n);
+}
+
+// ------------------------------------------------------------------ beamformers
+int mmw_bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int S,
+                 int E, int T, double lambda_m) {
+    MMW_REQUIRE(ctx && d_X && d_P && d_dirs && d_out, "null argument");
+    MMW_REQUIRE(S > 0 && E > 0 && T > 0 && lambda_m > 0, "bad shape");
+    return bartlett(ctx, d_X, d_P, d_dirs, d_out, S, E, T, lambda_m);
+}
+
+int mmw_capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out, int V, int R, int K, int T,
+              double delta) {
+    MMW_REQUIRE(ctx && d_X && h_thetas && d_out, "null argument");
+    MMW_REQUIRE(V > 0 && V <= 16 && R > 0 && K > 0 && T > 0, "bad shape (V <= 16)");
+    return capon(ctx, d_X, h_thetas, d_out, V, R, K, T, delta);
+}
+
+}  // extern "C"

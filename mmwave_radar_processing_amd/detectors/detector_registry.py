@@ -1,0 +1,14 @@
+"""String keys -> detector classes (reference: mmwave_radar_processing/detectors/detector_registry.py:15-27)."""
+from .ca_cfar import CaCFAR1D, CaCFAR2D
+from .go_so_cfar import GoCFAR1D, SoCFAR1D
+from .os_cfar import OsCFAR1D, OsCFAR2D
+
+_REGISTRY = {
+    "ca_cfar_1d": CaCFAR1D, "ca_cfar_2d": CaCFAR2D,
+    "os_cfar_1d": OsCFAR1D, "os_cfar_2d": OsCFAR2D,
+    "go_cfar_1d": GoCFAR1D, "so_cfar_1d": SoCFAR1D,
+}
+
+
+def get_detector_registry():
+    return dict(_REGISTRY)

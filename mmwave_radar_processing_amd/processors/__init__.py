@@ -1,0 +1,10 @@
+from ._processor import _Processor
+from .virtual_array_reformater import VirtualArrayReformatter
+from .range_resp import RangeProcessor
+from .range_doppler_resp import RangeDopplerProcessor
+from .range_angle_resp import RangeAngleProcessor
+from .range_angle_resp_dbs_enhanced import RangeAngleProcessorDBSEnhanced
+from .point_cloud_generator import PointCloudGenerator
+
+__all__ = ["_Processor", "VirtualArrayReformatter", "RangeProcessor", "RangeDopplerProcessor",
+           "RangeAngleProcessor", "RangeAngleProcessorDBSEnhanced", "PointCloudGenerator"]

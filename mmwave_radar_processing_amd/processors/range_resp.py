@@ -1,0 +1,33 @@
+"""Coarse range profile (reference: mmwave_radar_processing/processors/range_resp.py:8-57,153-164).
+
+Only the FFT hot path is accelerated; the reference's ZoomFFT / scipy peak
+picking (:59-150) belongs to the altimeter path that SURVEY.md marks out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib
+from ._processor import _Processor
+
+
+class RangeProcessor(_Processor):
+    def __init__(self, config_manager, **kwargs):
+        self.num_range_bins = None
+        self.range_bins = None
+        super().__init__(config_manager)
+
+    def configure(self):
+        cm = self.config_manager
+        self.num_range_bins = cm.get_num_adc_samples(profile_idx=0)
+        self.range_bins = np.arange(start=0, step=cm.range_res_m, stop=cm.range_max_m - cm.range_res_m / 2)
+
+    def coarse_fft(self, adc_cube: np.ndarray, chirp_idx: int = 0) -> np.ndarray:
+        """mean over rx of |FFT_S(hann(S) * x[:, :, chirp_idx])| -> float64 (S,)."""
+        ctx, bufs, d_cube, (V, S, C) = self._upload_cube(adc_cube)
+        d_out = bufs.get("profile", S * 4)
+        _lib.check(ctx.lib.mmw_range_profile(ctx.handle, d_cube.ptr, d_out.ptr, 1, V, S, C, int(chirp_idx)))
+        return d_out.download((S,), np.float32).astype(np.float64)
+
+    def process(self, adc_cube: np.ndarray, chirp_idx: int = 0, **kwargs) -> np.ndarray:
+        return self.coarse_fft(adc_cube, chirp_idx)

@@ -1,0 +1,358 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle and the committed golden fixtures.
+
+Tolerances (BASELINE.json north_star): spectra max|gpu-ref| / max|ref| <= 1e-5 (fp32 GPU vs the float64
+reference); CFAR detection indices bit-exact (values AND order); float64 CFAR thresholds bit-exact when the
+float64 input is identical.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from mmwave_radar_processing_amd import synth, _lib
+from mmwave_radar_processing_amd.config_managers import ConfigManager
+from mmwave_radar_processing_amd.detectors import (CaCFAR1D, CaCFAR2D, GoCFAR1D, SoCFAR1D, OsCFAR1D, OsCFAR2D,
+                                                   get_detector_registry)
+from mmwave_radar_processing_amd.processors import (PointCloudGenerator, RangeAngleProcessor,
+                                                    RangeAngleProcessorDBSEnhanced, RangeDopplerProcessor,
+                                                    RangeProcessor, VirtualArrayReformatter)
+from mmwave_radar_processing_amd.processors.range_doppler_detection import (
+    RangeDopplerDetector2D, RangeDopplerDetectorSequential, get_range_doppler_detector_registry)
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+SPEC_TOL = 1e-5
+CFAR = {"num_train": (4, 4), "num_guard": (2, 2), "pfa": 1e-5}
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+
+
+def make_cm(text):
+    cm = ConfigManager()
+    cm.load_cfg_text(text)
+    return cm
+
+
+def sample_cfg_text():
+    with open(os.path.join(GOLDEN, "cfg_scalars.json")) as f:
+        return "\n".join(json.load(f)["6843_RadVel_ods_20Hz.cfg"]["lines"])
+
+
+SHAPES = [((12, 32, 16), 101), ((12, 64, 32), 5), ((12, 256, 128), 0), ((12, 63, 70), 202),
+          ((4, 128, 64), 9), ((8, 512, 8), 10), ((3, 100, 30), 12)]
+
+
+def test_device_is_gfx950():
+    assert "gfx950" in _lib.device_info(0)["arch"]
+
+
+@pytest.mark.parametrize("shape,seed", SHAPES)
+def test_range_doppler_matches_oracle(shape, seed):
+    V, S, C = shape
+    cm = make_cm(synth.synth_cfg_text(num_samples=S, num_loops=C))
+    cube = synth.synth_cube(seed, shape)
+    ref = O.range_doppler(cube)
+    p = RangeDopplerProcessor(cm)
+    got = p.process(cube, rx_idx=-1, return_magnitude=False)
+    assert got.dtype == np.complex128 and got.shape == shape
+    assert rel_err(got, ref) <= SPEC_TOL
+    mag = p.process(cube, rx_idx=V - 1, return_magnitude=True)
+    assert mag.dtype == np.float64 and mag.shape == (S, C)
+    assert rel_err(mag, np.abs(ref[V - 1])) <= SPEC_TOL
+    # unknown kwargs are swallowed (plugin host re-passes ctor params)
+    assert p.process(cube, rx_idx=0, some_yaml_key=3).shape == (S, C)
+
+
+def test_range_doppler_golden_small(golden):
+    g = golden("small_chain.npz")
+    cm = make_cm(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    p = RangeDopplerProcessor(cm)
+    assert rel_err(p.process(cube, rx_idx=-1, return_magnitude=False), g["p2_rd"]) <= SPEC_TOL
+    assert rel_err(p.process(cube, rx_idx=3, return_magnitude=True), g["p2_rd_mag_rx3"]) <= SPEC_TOL
+    np.testing.assert_array_equal(p.range_bins, g["p2_range_bins"])
+    np.testing.assert_array_equal(p.vel_bins, g["p2_vel_bins"])
+
+
+@pytest.mark.parametrize("shape,seed,A", [((12, 32, 16), 101, 64), ((12, 256, 128), 1, 64), ((12, 63, 70), 202, 64),
+                                          ((12, 64, 32), 5, 32), ((8, 64, 32), 6, 64), ((5, 16, 8), 7, 20)])
+def test_chain3d_matches_oracle(shape, seed, A):
+    V, S, C = shape
+    cm = make_cm(synth.synth_cfg_text(num_samples=S, num_loops=C))
+    cube = synth.synth_cube(seed, shape)
+    p = RangeAngleProcessorDBSEnhanced(cm, num_angle_bins_range_angle_response=A)
+    got = p.compute_3d_windowed_fft(cube)
+    ref = O.fft3d_windowed(cube, A)
+    assert got.shape == (A, S, C) and got.dtype == np.complex128
+    assert rel_err(got, ref) <= SPEC_TOL
+
+
+def test_chain3d_and_dbs_golden(golden):
+    g = golden("small_chain.npz")
+    cm = make_cm(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    p = RangeAngleProcessorDBSEnhanced(cm, num_angle_bins_range_angle_response=64,
+                                       num_angle_bins_dbs_enhanced_response=40)
+    assert rel_err(p.compute_3d_windowed_fft(cube), g["p2_fft3d"]) <= SPEC_TOL
+    np.testing.assert_array_equal(p.angle_bins_dbs_enhanced, g["p2_dbs_angle_bins"])
+    out = p.process(cube, velocity_ned=g["p2_dbs_vel"])
+    assert out.shape == g["p2_dbs"].shape and rel_err(out, g["p2_dbs"]) <= SPEC_TOL
+    slow = p.process(cube, velocity_ned=np.zeros(3), chirp_idx=2)       # below min_vel_dbs -> plain range-angle
+    assert rel_err(slow, g["p2_ra_all"]) <= SPEC_TOL
+
+
+def test_headline_frames_golden(golden):
+    """(12,256,128): detections bit-exact, point cloud, RD / 3-D spectra samples vs the reference's outputs."""
+    g = golden("frames_256.npz")
+    cm = make_cm(synth.SYNTH_CFG_256x128x12)
+    pcg = PointCloudGenerator(cm, az_antenna_idxs=list(range(8)), el_antenna_idxs=[8, 9, 10, 11],
+                              detector_type="range_doppler_detector_2d",
+                              detector_params={"cfar_type": "ca_cfar_2d", "cfar_params": CFAR}, num_angle_bins=64)
+    dbs = RangeAngleProcessorDBSEnhanced(cm)
+    np.testing.assert_array_equal(pcg.angle_bins, g["angle_bins"])
+    for s in g["seeds"]:
+        cube = synth.synth_cube(int(s))
+        pc = pcg.process(cube)
+        det = pcg.detector
+        np.testing.assert_array_equal(det.dets, g[f"s{s}_dets"])
+        assert det.dets.dtype == np.int64
+        assert rel_err(det.rng_dop_resp_raw[:, ::8, ::8], g[f"s{s}_rd_sample"]) <= SPEC_TOL
+        np.testing.assert_allclose(det.detector.thresholds[::4, ::4], g[f"s{s}_thr_sample"], rtol=1e-12)
+        np.testing.assert_allclose(det.detector.noise_estimates[::4, ::4], g[f"s{s}_noise_sample"], rtol=1e-12, atol=1e-300)
+        if s < 2:
+            np.testing.assert_allclose(det.rng_dop_resp, g[f"s{s}_mag0"], rtol=0, atol=1e-12 * np.max(g[f"s{s}_mag0"]))
+        assert pc.shape == g[f"s{s}_pc"].shape
+        np.testing.assert_allclose(pc, g[f"s{s}_pc"], atol=1e-5 * cm.range_max_m)
+        f3 = dbs.compute_3d_windowed_fft(cube)
+        m = np.abs(g[f"s{s}_fft3d_checksum"][2])
+        assert np.max(np.abs(f3[::4, ::8, ::8] - g[f"s{s}_fft3d_sample"])) / m <= SPEC_TOL
+    det2 = RangeDopplerDetector2D(cm, cfar_type="ca_cfar_2d", cfar_params=CFAR)
+    d = det2.process(synth.synth_cube(77, num_targets=0))
+    assert d.shape == (0, 2) and d.dtype == np.int64
+
+
+@pytest.mark.parametrize("seed", [20, 21, 22, 23, 24, 25])
+def test_detector_and_point_cloud_vs_oracle(seed):
+    cm = make_cm(synth.SYNTH_CFG_256x128x12)
+    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    cube = synth.synth_cube(seed)
+    az, el = list(range(8)), [8, 9, 10, 11]
+    pcg = PointCloudGenerator(cm, az_antenna_idxs=az, el_antenna_idxs=el,
+                              detector_params={"cfar_type": "ca_cfar_2d", "cfar_params": CFAR})
+    pc = pcg.process(cube)
+    pc_ref, dets_ref, az_i, el_i = O.point_cloud(cube, sc, az, el)
+    np.testing.assert_array_equal(pcg.detector.dets, dets_ref)
+    raw = O.range_doppler(cube)
+    got_az, got_el = pcg._compute_angle_estimation(pcg.detector.rng_dop_resp_raw, dets_ref[:, 0], dets_ref[:, 1])
+    # argmax indices identical, except where the oracle's two best bins tie to within fp32 resolution
+    for got, ant, shift, ref_i in ((got_az, az, True, az_i), (got_el, el, False, el_i)):
+        _, resp = O.angle_argmax(raw, dets_ref[:, 0], dets_ref[:, 1], ant, 64, shift)
+        gi = np.array([int(np.where(pcg.angle_bins == a)[0][0]) for a in got])
+        bad = np.where(gi != ref_i)[0]
+        for b in bad:
+            assert abs(resp[b, gi[b]] - resp[b, ref_i[b]]) <= 1e-5 * resp[b, ref_i[b]]
+        assert len(bad) <= 1
+    ok = np.all(np.isclose(pc, pc_ref, atol=1e-5 * sc["range_max_m"]), axis=1)
+    assert ok.sum() >= len(ok) - 1
+
+
+def test_sample_cfg_non_pow2_pipeline(golden):
+    """BASELINE config 1 substitute: the shipped 6843 ODS 20 Hz cfg (12,63,70) end to end on the GPU."""
+    g = golden("small_chain.npz")
+    cm = make_cm(sample_cfg_text())
+    raw = synth.synth_raw_cube(202, 4, 3, 63, 70)
+    virt = VirtualArrayReformatter(cm).process(raw)
+    assert virt.dtype == np.complex128 and virt.shape == (12, 63, 70)
+    np.testing.assert_array_equal(virt[:, ::7, ::9], g["np2_virt_sample"])
+    det = RangeDopplerDetector2D(cm, cfar_type="ca_cfar_2d", cfar_params=CFAR)
+    dets = det.process(virt)
+    np.testing.assert_array_equal(dets, g["np2_dets"])
+    assert rel_err(det.rng_dop_resp_raw[:, ::3, ::5], g["np2_rd_sample"]) <= SPEC_TOL
+    np.testing.assert_allclose(det.rng_dop_resp, g["np2_mag0"], rtol=0, atol=1e-12 * np.max(g["np2_mag0"]))
+    assert det.rng_dop_resp_raw.shape == (12, 63, 70) and det.rng_dop_resp.shape == (63, 70)
+    f3 = RangeAngleProcessorDBSEnhanced(cm).compute_3d_windowed_fft(virt)
+    m = np.abs(g["np2_fft3d_checksum"][2])
+    assert np.max(np.abs(f3[::4, ::3, ::5] - g["np2_fft3d_sample"])) / m <= SPEC_TOL
+    raw3 = synth.synth_raw_cube(303, 4, 3, 16, 8)
+    cm3 = make_cm(synth.synth_cfg_text(num_samples=16, num_loops=8))
+    np.testing.assert_array_equal(VirtualArrayReformatter(cm3).process(raw3), g["var_small"])
+
+
+def test_range_profile_and_range_angle(golden):
+    g = golden("small_chain.npz")
+    cm = make_cm(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    assert rel_err(RangeProcessor(cm).process(cube, chirp_idx=5), g["p2_range_profile_c5"]) <= SPEC_TOL
+    rap = RangeAngleProcessor(cm, num_angle_bins=64)
+    np.testing.assert_array_equal(rap.range_bins, g["p2_ra_range_bins"])
+    np.testing.assert_array_equal(rap.angle_bins, g["p2_angle_bins"])
+    assert rel_err(rap.process(cube, chirp_idx=2), g["p2_ra_all"]) <= SPEC_TOL
+    assert rel_err(rap.process(cube, chirp_idx=0, rx_antennas=[0, 3, 4, 7]), g["p2_ra_sub"]) <= SPEC_TOL
+    assert rel_err(rap.process(cube, chirp_idx=1, rx_antennas=np.array([1, 2]), perform_windowing=False),
+                   g["p2_ra_nowin"]) <= SPEC_TOL
+    # headline and odd shapes against the oracle
+    for shape, seed in (((12, 256, 128), 3), ((12, 63, 70), 4)):
+        cmx = make_cm(synth.synth_cfg_text(num_samples=shape[1], num_loops=shape[2]))
+        c = synth.synth_cube(seed, shape)
+        assert rel_err(RangeProcessor(cmx).process(c, chirp_idx=7), O.range_profile(c, 7)) <= SPEC_TOL
+        assert rel_err(RangeAngleProcessor(cmx).process(c, chirp_idx=3, rx_antennas=[0, 3, 4, 7]),
+                       O.range_angle(c, 64, 3, [0, 3, 4, 7])) <= SPEC_TOL
+
+
+def test_cfar_known_answers_bit_exact(golden):
+    """Reference's verify_detectors_manual.py facts; thresholds bit-exact because the float64 input is identical."""
+    g = golden("cfar_known.npz")
+    np.random.seed(42)
+    x = np.random.exponential(scale=1.0, size=100)
+    x[50] = 10.0
+    dets = {"ca": CaCFAR1D(10, 2, 1e-3), "go": GoCFAR1D(10, 2, 1e-3), "so": SoCFAR1D(10, 2, 1e-3),
+            "os": OsCFAR1D(10, 2, rho=0.75, alpha=5.0), "os_ascalled": OsCFAR1D(10, 2, 15, 5.0)}
+    for name, d in dets.items():
+        out = d.detect(x)
+        assert isinstance(out, list)
+        np.testing.assert_array_equal(np.array(out, dtype=np.int64), g[f"1d_{name}_dets"])
+        np.testing.assert_array_equal(d.thresholds, g[f"1d_{name}_thr"])
+        np.testing.assert_array_equal(d.noise_estimates, g[f"1d_{name}_noise"])
+        assert d.detections.dtype == bool
+    assert dets["ca"].detect(x) == [50] and dets["os_ascalled"].k_rank == 20
+    X = np.random.exponential(scale=1.0, size=(50, 50))
+    X[25, 25] = 15.0
+    d2 = {"ca": CaCFAR2D((5, 5), (2, 2), 1e-4), "os": OsCFAR2D((5, 5), (2, 2), rho=0.8, alpha=5.0),
+          "os_yaml": OsCFAR2D([5, 5], [3, 2], rho=0.7, alpha=2)}
+    for name, d in d2.items():
+        out = d.detect(X)
+        np.testing.assert_array_equal(np.array(out, dtype=np.int64).reshape(-1, 2), g[f"2d_{name}_dets"])
+        np.testing.assert_array_equal(d.thresholds, g[f"2d_{name}_thr"])
+        np.testing.assert_array_equal(d.noise_estimates, g[f"2d_{name}_noise"])
+    assert d2["ca"].detect(X) == [(25, 25)] and d2["os"].k_rank == 160
+    assert CaCFAR2D((4, 4), (2, 2), 1e-5).detect(np.ones((5, 5))) == []          # window larger than map
+    assert CaCFAR1D(10, 2, 1e-3).detect(np.ones(7)) == []
+    assert CaCFAR1D.compute_alpha_ca(20, 1e-3) == 8.250750892455088
+    with pytest.raises(ValueError):
+        CaCFAR1D(1, 1, 1e-3).detect(np.ones((3, 3)))
+    with pytest.raises(ValueError):
+        CaCFAR2D((1, 1), (1, 1), 1e-3).detect(np.ones(9))
+    assert sorted(get_detector_registry()) == ["ca_cfar_1d", "ca_cfar_2d", "go_cfar_1d", "os_cfar_1d",
+                                               "os_cfar_2d", "so_cfar_1d"]
+
+
+@pytest.mark.parametrize("params", [((4, 4), (2, 2)), ((5, 5), (3, 2)), ((8, 4), (2, 1)), ((1, 1), (0, 0)),
+                                    ((2, 9), (1, 3))])
+def test_cfar2d_random_maps_bit_exact(params):
+    rng = np.random.default_rng(hash(params) % 1000)
+    X = rng.exponential(1.0, (70, 45)) * 1e3
+    X[rng.integers(0, 70, 12), rng.integers(0, 45, 12)] *= 40
+    tr, gd = params
+    for det, ref in ((CaCFAR2D(tr, gd, 1e-3), O.ca_cfar_2d(X, tr, gd, 1e-3)),
+                     (OsCFAR2D(tr, gd, rho=0.7, alpha=3.0), O.os_cfar_2d(X, tr, gd, 0.7, 3.0))):
+        out = det.detect(X)
+        assert [tuple(map(int, t)) for t in out] == ref[2]
+        np.testing.assert_array_equal(det.thresholds, ref[0])
+        np.testing.assert_array_equal(det.noise_estimates, ref[1])
+
+
+@pytest.mark.parametrize("t,g", [(10, 2), (5, 3), (16, 4), (3, 1), (70, 2), (140, 3)])
+def test_cfar1d_random_bit_exact(t, g):
+    rng = np.random.default_rng(t * 10 + g)
+    x = rng.exponential(1.0, 600)
+    x[rng.integers(0, 600, 9)] *= 30
+    cases = ((CaCFAR1D(t, g, 1e-3), O.ca_cfar_1d(x, t, g, 1e-3)), (GoCFAR1D(t, g, 1e-3), O.go_cfar_1d(x, t, g, 1e-3)),
+             (SoCFAR1D(t, g, 1e-3), O.so_cfar_1d(x, t, g, 1e-3)),
+             (OsCFAR1D(t, g, rho=0.6, alpha=2.5), O.os_cfar_1d(x, t, g, 0.6, 2.5)))
+    for det, ref in cases:
+        assert det.detect(x) == ref[2]
+        np.testing.assert_array_equal(det.thresholds, ref[0])
+        np.testing.assert_array_equal(det.noise_estimates, ref[1])
+
+
+def test_sequential_detector_vs_oracle():
+    cm = make_cm(synth.SYNTH_CFG_256x128x12)
+    cube = synth.synth_cube(31)
+    rp = dict(num_train=5, num_guard=3, rho=0.6, alpha=2)
+    vp = dict(num_train=5, num_guard=2, rho=0.7, alpha=3)
+    det = RangeDopplerDetectorSequential(cm, "os_cfar_1d", rp, "os_cfar_1d", vp)
+    got = det.process(cube)
+    prof = O.range_profile(cube, 0)
+    rows = O.os_cfar_1d(prof, 5, 3, 0.6, 2)[2]
+    mag = np.abs(O.range_doppler(cube)[0])
+    ref = [(r, d) for r in rows for d in O.os_cfar_1d(mag[r], 5, 2, 0.7, 3)[2]]
+    ref = np.array(ref, dtype=int) if ref else np.empty((0, 2), dtype=int)
+    np.testing.assert_array_equal(got, ref)
+    assert got.shape[0] > 0
+
+
+def test_reference_point_cloud_angle_tests():
+    """tests/test_point_cloud_angles.py of the reference, against this package's classes."""
+    from unittest.mock import MagicMock
+    cm = MagicMock(spec=ConfigManager)
+    cm.vel_max_m_s, cm.vel_res_m_s, cm.range_max_m, cm.range_res_m = 10.0, 0.1, 50.0, 0.5
+    cm.num_rx_antennas, cm.num_tx_antennas = 4, 3
+    params = {"cfar_type": "ca_cfar_2d", "cfar_params": {"num_train": (2, 2), "num_guard": (1, 1), "pfa": 1e-5}}
+    raw = np.random.rand(4, 10, 10) + 1j * np.random.rand(4, 10, 10)
+    zeros = np.zeros(5, dtype=int)
+    for az, el in (([], [0, 1]), ([0, 1], []), ([], [])):
+        pc_gen = PointCloudGenerator(config_manager=cm, az_antenna_idxs=az, el_antenna_idxs=el,
+                                     detector_type="range_doppler_detector_2d", detector_params=params,
+                                     num_angle_bins=64)
+        pc_gen.configure()
+        a, e = pc_gen._compute_angle_estimation(raw, zeros, zeros)
+        assert a.shape == (5,) and e.shape == (5,)
+        if not az:
+            assert np.all(a == 0.0)
+        if not el:
+            assert np.all(e == 0.0)
+        if el:
+            i, _ = O.angle_argmax(raw, zeros, zeros, el, 64, False)
+            np.testing.assert_array_equal(e, pc_gen.angle_bins[i])
+    with pytest.raises(ValueError):
+        PointCloudGenerator(cm, [0], [1], detector_type="nope")
+    with pytest.raises(ValueError):
+        PointCloudGenerator(cm, "01", [1])
+    with pytest.raises(ValueError):
+        RangeDopplerDetector2D(cm, cfar_type="nope")
+    assert "range_doppler_detector_2d" in get_range_doppler_detector_registry()
+
+
+def test_compaction_order_and_truncation():
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(3)
+    F, R, D, cap = 3, 37, 29, 50
+    mask = (rng.random((F, R, D)) < 0.02).astype(np.uint8)
+    mask[1] = 0
+    mask[2] = rng.random((R, D)) < 0.2          # overflows cap
+    d_m, d_d, d_c = ctx.alloc(mask.nbytes), ctx.alloc(F * cap * 8), ctx.alloc(F * 4)
+    d_m.upload(mask)
+    _lib.check(ctx.lib.mmw_compact2d(ctx.handle, d_m.ptr, d_d.ptr, d_c.ptr, F, R, D, cap))
+    counts = d_c.download((F,), np.int32)
+    dets = d_d.download((F, cap, 2), np.int32)
+    for f in range(F):
+        rows, cols = np.where(mask[f])
+        assert counts[f] == len(rows)
+        n = min(cap, len(rows))
+        np.testing.assert_array_equal(dets[f, :n, 0], rows[:n])
+        np.testing.assert_array_equal(dets[f, :n, 1], cols[:n])
+    assert counts[1] == 0 and counts[2] > cap
+    for b in (d_m, d_d, d_c):
+        b.free()
+
+
+def test_synth_kernel_frames_feed_the_oracle():
+    """Bench input path: cubes generated in HBM are integer-valued, and the chain on them matches the oracle."""
+    ctx = _lib.default_context()
+    F, V, S, C, A = 3, 12, 256, 128, 64
+    n = V * S * C
+    d_in, d_out = ctx.alloc(F * n * 8), ctx.alloc(F * A * S * C * 8)
+    _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 1234, 8, 30.0))
+    _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+    cubes = d_in.download((F, V, S, C), np.complex64)
+    assert np.all(cubes.real == np.rint(cubes.real)) and np.all(cubes.imag == np.rint(cubes.imag))
+    assert 20 < np.std(cubes.real) < 2000 and not np.array_equal(cubes[0], cubes[1])
+    out = d_out.download((F, A, S, C), np.complex64)
+    for f in (0, 2):
+        assert rel_err(out[f], O.fft3d_windowed(cubes[f], A)) <= SPEC_TOL
+    d_in.free()
+    d_out.free()
