@@ -164,6 +164,12 @@ int mmw_capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_ou
 /* ---------------------------------------------------------------- element-wise helpers */
 int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n);
 
+/* ---------------------------------------------------------------- diagnostics
+ * In-situ HBM ceiling on the same device: mode 0 = 16-B/lane copy, 1 = write only, 2 = read only,
+ * grid-stride over `blocks` workgroups of 256 (0 = 8 per CU).  Used by tools/kbench.py to state what
+ * a known-good streaming kernel reaches next to the hot-path kernels. */
+int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks);
+
 /* ---------------------------------------------------------------- per-kernel timing hook for bench.py
  * Average duration (ms) of the most recent launch group of the named kernel family measured
  * with HIP events on the ctx stream: "rd", "angle", "cfar".  Enabled by mmw_profile_enable(1). */

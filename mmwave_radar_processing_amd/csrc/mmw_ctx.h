@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -182,6 +183,17 @@ struct ProfScope {
         ctx->ev_pending.push_back(span);
     }
 };
+
+// tuning knob read once per process from the environment (experiments only; defaults are the product path)
+inline int tune_int(const char *name, int dflt) {
+    static std::map<std::string, int> cache;
+    auto it = cache.find(name);
+    if (it != cache.end()) return it->second;
+    const char *s = std::getenv(name);
+    const int v = (s && *s) ? std::atoi(s) : dflt;
+    cache[name] = v;
+    return v;
+}
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

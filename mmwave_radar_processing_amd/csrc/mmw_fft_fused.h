@@ -18,18 +18,22 @@ struct AngleWin {
     float h[16];
 };
 
-template <int VIN, bool MAG>
-__global__ __launch_bounds__(256) void k_angle64(const float4 *__restrict__ rd, void *__restrict__ out,
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// NT: streaming (non-temporal) stores for the write-once output cube
+template <int VIN, bool MAG, bool NT>
+__global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, void *__restrict__ out,
                                                   long pairs_per_frame, AngleWin win) {
     // grid.x covers pairs of adjacent bins of one frame; grid.y = frame
     const long pair = (long)blockIdx.x * 256 + threadIdx.x;
     if (pair >= pairs_per_frame) return;
     const long f = blockIdx.y;
-    const float4 *src = rd + f * VIN * pairs_per_frame + pair;
+    const f32x4 *src = rd + f * VIN * pairs_per_frame + pair;
     cplx<float> xa[VIN], xb[VIN];
 #pragma unroll
     for (int v = 0; v < VIN; ++v) {
-        const float4 t = src[(long)v * pairs_per_frame];
+        const f32x4 t = src[(long)v * pairs_per_frame];
         const float h = win.h[v];
         xa[v] = {t.x * h, t.y * h};
         xb[v] = {t.z * h, t.w * h};
@@ -59,9 +63,13 @@ __global__ __launch_bounds__(256) void k_angle64(const float4 *__restrict__ rd, 
             const cplx<float> va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
             const long o = (f * 64 + a) * pairs_per_frame + pair;
             if constexpr (MAG) {
-                reinterpret_cast<float2 *>(out)[o] = make_float2(hypotf(va.x, va.y), hypotf(vb.x, vb.y));
+                const f32x2 m = {hypotf(va.x, va.y), hypotf(vb.x, vb.y)};
+                if constexpr (NT) __builtin_nontemporal_store(m, reinterpret_cast<f32x2 *>(out) + o);
+                else reinterpret_cast<f32x2 *>(out)[o] = m;
             } else {
-                reinterpret_cast<float4 *>(out)[o] = make_float4(va.x, va.y, vb.x, vb.y);
+                const f32x4 q = {va.x, va.y, vb.x, vb.y};   // one 16-B store per lane: 1 KiB per wave instruction
+                if constexpr (NT) __builtin_nontemporal_store(q, reinterpret_cast<f32x4 *>(out) + o);
+                else reinterpret_cast<f32x4 *>(out)[o] = q;
             }
         });
     });
@@ -73,16 +81,140 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)F);
-    if (mag)
-        hipLaunchKernelGGL((k_angle64<VIN, true>), grid, dim3(256), 0, ctx->stream, (const float4 *)rd, out, pairs, w);
-    else
-        hipLaunchKernelGGL((k_angle64<VIN, false>), grid, dim3(256), 0, ctx->stream, (const float4 *)rd, out, pairs, w);
+    const bool nt = tune_int("MMW_ANGLE_NT", 0) != 0;
+#define MMW_ANGLE_LAUNCH(MAGV, NTV) \
+    hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w)
+    if (mag && nt) MMW_ANGLE_LAUNCH(true, true);
+    else if (mag) MMW_ANGLE_LAUNCH(true, false);
+    else if (nt) MMW_ANGLE_LAUNCH(false, true);
+    else MMW_ANGLE_LAUNCH(false, false);
+#undef MMW_ANGLE_LAUNCH
     return check_launch("angle64");
 }
 
-// fused range-Doppler kernel: filled in below once measured
-inline int launch_rd_fused(mmw_ctx *, const void *, void *, int, int, int) {
-    return set_error(MMW_ERR_UNSUPPORTED, "fused RD kernel not built");
+// ------------------------------------------------------------------ fused range-Doppler, 256 x 128
+// k_rd_fused_256x128: one workgroup (1024 threads = 16 waves) transforms one [256 samples][128 chirps]
+// plane in a single pass over HBM (reads 256 KiB, writes 256 KiB; algorithmic 6.29 MB/frame for 12 planes).
+// The plane does not fit LDS (256 KiB > 160 KiB): it lives in REGISTERS (32 complex per thread) and moves
+// through LDS three times, half a plane (128 range rows) at a time:
+//   step 0   lane <-> chirp pair, wave <-> sample phase j: 16 coalesced 1-KiB row loads, Hann(S) x Hann(C),
+//            16-point range FFT over n1 (samples 16*n1 + j) in registers, twiddle W256^(j*k1) (wave-uniform).
+//   X1       exchange over j  -> second 16-point range FFT: rows kr = k1 + 16*k2 of the half are complete.
+//   X2       transpose to row-major (pitch 152 keeps the strided reads bank-conflict free).
+//   Doppler  16-point FFT over chirps 8*n1 + j8, twiddle W128^(j8*k1d), X3 exchange in place inside the
+//            wave's own 8 rows, 8-point FFT, fftshift folded into the store index (128-B store segments).
+// Range FFT = processors/range_doppler_resp.py:99-101 axis -2, Doppler = axis -1, shift = :98,103.
+constexpr int RD_S = 256, RD_C = 128, RD_PITCH = 152;
+constexpr int RD_LDS_MAIN = 128 * RD_PITCH;                       // complex elements (>= 8*16*128 for X1)
+constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8;           // + W128 table
+
+__global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
+                                                            int planes, const float *__restrict__ hann_s,
+                                                            const float *__restrict__ hann_c,
+                                                            const cplx<float> *__restrict__ tw256,
+                                                            const cplx<float> *__restrict__ tw128) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
+    cplx<float> *tw128_l = lds + RD_LDS_MAIN;
+    const int t = threadIdx.x;
+    const int l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (t < 128) tw128_l[t] = tw128[t];
+    const float hc0 = hann_c[2 * l], hc1 = hann_c[2 * l + 1];
+
+    {
+        const int plane = blockIdx.x;
+        const f32x4 *src = in + (long)plane * (RD_S * RD_C / 2);
+        cplx<float> *dst = out + (long)plane * (RD_S * RD_C);
+        // ---- step 0: load, window, range pass 1 (n = 16*n1 + w)
+        cplx<float> y0[16], y1[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int n = 16 * n1 + w;
+            const f32x4 v = src[n * (RD_C / 2) + l];
+            const float hs = hann_s[n];
+            y0[n1] = {v.x * (hs * hc0), v.y * (hs * hc0)};
+            y1[n1] = {v.z * (hs * hc1), v.w * (hs * hc1)};
+        }
+        RegFFT<16, float>::run(y0);
+        RegFFT<16, float>::run(y1);
+        static_for<2>([&](auto H) {
+            constexpr int h = decltype(H)::value;
+            // ---- X1: [k1l][j = w][c], twiddle applied on the way out
+            static_for<8>([&](auto K) {
+                constexpr int k1l = decltype(K)::value;
+                constexpr int k1 = 8 * h + k1l;
+                const cplx<float> tw = tw256[w * k1];
+                constexpr int br = bitrev<16>(k1);
+                const cplx<float> a = y0[br] * tw, b = y1[br] * tw;
+                *reinterpret_cast<f32x4 *>(&lds[(k1l * 16 + w) * 128 + 2 * l]) = f32x4{a.x, a.y, b.x, b.y};
+            });
+            __syncthreads();
+            const int k1l = w & 7, c = 64 * (w >> 3) + l;
+            cplx<float> b[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) b[j] = lds[(k1l * 16 + j) * 128 + c];
+            RegFFT<16, float>::run(b);
+            __syncthreads();
+            // ---- X2: row-major [rl = k1l + 8*k2][c], pitch 152
+            static_for<16>([&](auto K) {
+                constexpr int k2 = decltype(K)::value;
+                lds[(k1l + 8 * k2) * RD_PITCH + c] = b[bitrev<16>(k2)];
+            });
+            __syncthreads();
+            // ---- Doppler pass 1: thread (rl, j8), chirps 8*n1 + j8
+            const int rl = t >> 3, j8 = t & 7;
+            cplx<float> d[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) d[n1] = lds[rl * RD_PITCH + 8 * n1 + j8];
+            RegFFT<16, float>::run(d);
+            // X3 in place: only this wave reads/writes rows 8w .. 8w+7 from here on
+            static_for<16>([&](auto K) {
+                constexpr int k1d = decltype(K)::value;
+                lds[rl * RD_PITCH + k1d * 9 + j8] = d[bitrev<16>(k1d)] * tw128_l[j8 * k1d];
+            });
+            __syncthreads();
+            // ---- Doppler pass 2 + store (two (row, k1d) units per lane)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = l + 64 * u;
+                const int k1d = idx & 15, row = 8 * w + (idx >> 4);
+                cplx<float> e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) e[q] = lds[row * RD_PITCH + k1d * 9 + q];
+                RegFFT<8, float>::run(e);
+                const int kr = 8 * h + (row & 7) + 16 * (row >> 3);
+                static_for<8>([&](auto K) {
+                    constexpr int k2d = decltype(K)::value;
+                    const int kk = (k1d + 16 * k2d) ^ 64;       // fftshift over the 128 Doppler bins
+                    dst[kr * RD_C + kk] = e[bitrev<8>(k2d)];
+                });
+            }
+            __syncthreads();
+        });
+    }
+}
+
+inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
+
+inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C) {
+    if (!rd_fused_supported(S, C)) return set_error(MMW_ERR_UNSUPPORTED, "fused RD kernel is 256x128 only");
+    const void *hs, *hc, *t256, *t128;
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_S, &hs));
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_C, &hc));
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 256, &t256));
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 128, &t128));
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_fused_256x128),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
+        attr_set = true;
+    }
+    const int blocks = planes;   // one plane per workgroup: a persistent plane loop made hipcc hoist and spill
+    hipLaunchKernelGGL(k_rd_fused_256x128, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
+                       (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                       (const cplx<float> *)t256, (const cplx<float> *)t128);
+    return check_launch("rd_fused");
 }
 
 }  // namespace mmw

@@ -210,22 +210,42 @@ __global__ __launch_bounds__(256) void k_dft_direct(FftArgs p, int N, int B) {
 }
 
 // ------------------------------------------------------------------ dispatch
+template <typename T, typename TIN, int N, int R1, int R2, int B>
+int launch_contig_b(mmw_ctx *ctx, const FftArgs &p) {
+    const size_t lds = (size_t)B * R1 * (R2 + 1) * sizeof(cplx<T>);
+    const long blocks = ((long)p.outer + B - 1) / B;
+    hipLaunchKernelGGL((k_fft_contig<T, TIN, N, R1, R2, B>), dim3((unsigned)blocks), dim3(B * R2), lds, ctx->stream, p);
+    return check_launch("fft_contig");
+}
+
+template <typename T, typename TIN, int N, int R1, int R2, int B>
+int launch_strided_b(mmw_ctx *ctx, const FftArgs &p) {
+    const size_t lds = (size_t)N * B * sizeof(cplx<T>);
+    const long tiles = (p.inner + B - 1) / B;
+    hipLaunchKernelGGL((k_fft_strided<T, TIN, N, R1, R2, B>), dim3((unsigned)(tiles * p.outer)), dim3(B * R2), lds,
+                       ctx->stream, p);
+    return check_launch("fft_strided");
+}
+
 template <typename T, typename TIN, int N, int R1, int R2>
 int launch_pow2(mmw_ctx *ctx, const FftArgs &p, bool contiguous) {
     if (contiguous) {
         constexpr int B = contig_tile(R1, R2, (int)sizeof(cplx<T>));
-        const size_t lds = (size_t)B * R1 * (R2 + 1) * sizeof(cplx<T>);
-        const long blocks = ((long)p.outer + B - 1) / B;
-        hipLaunchKernelGGL((k_fft_contig<T, TIN, N, R1, R2, B>), dim3((unsigned)blocks), dim3(B * R2), lds,
-                           ctx->stream, p);
+        if constexpr (sizeof(T) == 4 && N == 128) {   // tuning experiment
+            const int tb = tune_int("MMW_TUNE_CONTIG_B", B);
+            if (tb == 8) return launch_contig_b<T, TIN, N, R1, R2, 8>(ctx, p);
+            if (tb == 16) return launch_contig_b<T, TIN, N, R1, R2, 16>(ctx, p);
+        }
+        return launch_contig_b<T, TIN, N, R1, R2, B>(ctx, p);
     } else {
         constexpr int B = strided_tile(N, (int)sizeof(cplx<T>));
-        const size_t lds = (size_t)N * B * sizeof(cplx<T>);
-        const long tiles = (p.inner + B - 1) / B;
-        hipLaunchKernelGGL((k_fft_strided<T, TIN, N, R1, R2, B>), dim3((unsigned)(tiles * p.outer)),
-                           dim3(B * R2), lds, ctx->stream, p);
+        if constexpr (sizeof(T) == 4 && N == 256) {   // tuning experiment
+            const int tb = tune_int("MMW_TUNE_STRIDED_B", B);
+            if (tb == 8) return launch_strided_b<T, TIN, N, R1, R2, 8>(ctx, p);
+            if (tb == 16) return launch_strided_b<T, TIN, N, R1, R2, 16>(ctx, p);
+        }
+        return launch_strided_b<T, TIN, N, R1, R2, B>(ctx, p);
     }
-    return check_launch("fft_pow2");
 }
 
 // contiguous == true: the axis is the fastest-varying index (in_axis_stride == 1, inner == 1,

@@ -96,6 +96,20 @@ __global__ __launch_bounds__(256) void k_mean_abs_over_v(const cplx<T> *spec, T 
     out[gid] = acc / (T)V;
 }
 
+// ------------------------------------------------------------------ in-situ HBM ceiling (diagnostics)
+// mode 0: dst = src (16 B/lane copy)   1: dst = const (write only)   2: read only (sum kept live)
+typedef float diag_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_diag_membw(const diag_f4 *src, diag_f4 *dst, size_t n_vec, int mode) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    diag_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += stride) {
+        if (mode == 0) dst[i] = src[i];
+        else if (mode == 1) dst[i] = diag_f4{1.f, 2.f, 3.f, 4.f};
+        else acc += src[i];
+    }
+    if (mode == 2 && acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[0] = acc;
+}
+
 constexpr int MAX_ANT = 32;
 struct AntList {
     int n;

@@ -18,7 +18,7 @@ int env_int(const char *name, int dflt) {
     return (s && *s) ? std::atoi(s) : dflt;
 }
 
-bool fused_rd_ok(int, int) { return false; }
+bool fused_rd_ok(int S, int C) { return rd_fused_supported(S, C); }
 
 int abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
     if (n == 0) return MMW_OK;
@@ -511,6 +511,14 @@ int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, cons
 int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
     MMW_REQUIRE(ctx && (n == 0 || (d_in && d_out)), "null argument");
     return abs_c64(ctx, d_in, d_out, n);
+}
+
+int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks) {
+    MMW_REQUIRE(ctx && d_src && d_dst && bytes % 16 == 0 && mode >= 0 && mode <= 2, "bad argument");
+    if (blocks <= 0) blocks = ctx->num_cu * 8;
+    hipLaunchKernelGGL(k_diag_membw, dim3(blocks), dim3(256), 0, ctx->stream, (const diag_f4 *)d_src,
+                       (diag_f4 *)d_dst, bytes / 16, mode);
+    return check_launch("diag_membw");
 }
 
 // ------------------------------------------------------------------ beamformers

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark (HIP events on the ctx stream): angle FFT, range-Doppler, float64 CFAR plane,
+CA-CFAR + compaction, next to the in-situ copy / write / read ceilings of the same device.
+
+    python tools/kbench.py [--frames 512] [--reps 10]
+Prints one JSON object; `GB/s` figures use ALGORITHMIC bytes: a kernel's compulsory read + write.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmwave_radar_processing_amd import _lib  # noqa: E402
+
+V, S, C, A = 12, 256, 128, 64
+
+
+def timeit(ctx, fn, reps):
+    fn()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_stop() / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    F = args.frames
+    ctx = _lib.Context(0)
+    L = ctx.lib
+    cube_b, out_b = V * S * C * 8, A * S * C * 8
+    d_in, d_rd, d_out = ctx.alloc(F * cube_b), ctx.alloc(F * cube_b), ctx.alloc(F * out_b)
+    _lib.check(L.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 99, 8, 30.0))
+    res = {"frames": F}
+    want = set(args.only.split(",")) if args.only else None
+
+    def run(name, fn, bytes_moved):
+        if want and name not in want:
+            return
+        ms = timeit(ctx, fn, args.reps)
+        res[name] = {"ms": round(ms, 4), "us_per_frame": round(1e3 * ms / F, 3),
+                     "GBs": round(bytes_moved / ms / 1e6, 1)}
+
+    nbytes = F * out_b
+    half = (nbytes // 32) * 16
+    run("diag_copy", lambda: _lib.check(L.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr + half, half, 0, 0)), 2 * half)
+    run("diag_write", lambda: _lib.check(L.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr, nbytes, 1, 0)), nbytes)
+    run("diag_read", lambda: _lib.check(L.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr, nbytes, 2, 0)), nbytes)
+    run("rd", lambda: _lib.check(L.mmw_range_doppler(ctx.handle, d_in.ptr, d_rd.ptr, None, F, V, S, C)), F * 2 * cube_b)
+    run("angle", lambda: _lib.check(L.mmw_angle_fft(ctx.handle, d_rd.ptr, d_out.ptr, F, V, S, C, A, 0)), F * (cube_b + out_b))
+    run("angle_mag", lambda: _lib.check(L.mmw_angle_fft(ctx.handle, d_rd.ptr, d_out.ptr, F, V, S, C, A, 1)),
+        F * (cube_b + out_b // 2))
+    run("chain3d", lambda: _lib.check(L.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0)),
+        F * (cube_b + out_b))
+    d_mag = ctx.alloc(F * S * C * 8)
+    run("rd_mag64", lambda: _lib.check(L.mmw_range_doppler_mag64(ctx.handle, d_in.ptr, d_mag.ptr, F, V, S, C, 0)),
+        F * (S * C * 8 + S * C * 8))
+    d_thr, d_noise, d_mask = ctx.alloc(F * S * C * 8), ctx.alloc(F * S * C * 8), ctx.alloc(F * S * C)
+    alpha = 144 * (1e-5 ** (-1.0 / 144) - 1.0)
+    run("cfar2d_ca", lambda: _lib.check(L.mmw_cfar2d(ctx.handle, d_mag.ptr, d_thr.ptr, d_noise.ptr, d_mask.ptr, F, S, C,
+                                                     0, 4, 4, 2, 2, alpha, 0)), F * S * C * (8 + 8 + 8 + 1))
+    run("cfar2d_ca_maskonly", lambda: _lib.check(L.mmw_cfar2d(ctx.handle, d_mag.ptr, None, None, d_mask.ptr, F, S, C,
+                                                              0, 4, 4, 2, 2, alpha, 0)), F * S * C * (8 + 1))
+    cap = 1024
+    d_dets, d_cnt = ctx.alloc(F * cap * 8), ctx.alloc(F * 4)
+    run("compact2d", lambda: _lib.check(L.mmw_compact2d(ctx.handle, d_mask.ptr, d_dets.ptr, d_cnt.ptr, F, S, C, cap)),
+        F * S * C)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
