@@ -123,7 +123,7 @@ def main():
                                    "64-bin angle FFT -> complex64 [64,256,128] (BASELINE configs[1])",
                        "frames_per_gpu": F, "cube": [V, S, C], "angle_bins": A,
                        "sharding": f"frame-sharded x{world}, no collective",
-                       "chunk_frames": int(os.environ.get("MMW_CHAIN_CHUNK", "8")),
+                       "chunk_frames": int(os.environ.get("MMW_CHAIN_CHUNK", "1024")),
                        "device": info["name"], "arch": info["arch"]},
             "hip_event_ms_per_step_rank0": ev_ms / args.steps,
             "chain_hbm_frac_of_8TBs": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),

@@ -19,14 +19,24 @@
 
 namespace mmw {
 
-template <typename T> struct cplx { T x, y; };
+// Complex numbers are native 2-wide vectors (re, im): + - and scalar * are the built-in element-wise
+// operators, which hipcc lowers to v_pk_add_f32 / v_pk_mul_f32 on the register pair without shuffles.
+// The complex product is the named function cmul (the built-in vector * is element-wise!).
+#if defined(__clang__)
+template <typename T> using cplx = T __attribute__((ext_vector_type(2)));
+#else
+template <typename T> struct cplx_s {
+    T x, y;
+    cplx_s operator+(cplx_s b) const { return {x + b.x, y + b.y}; }
+    cplx_s operator-(cplx_s b) const { return {x - b.x, y - b.y}; }
+    cplx_s operator*(T s) const { return {x * s, y * s}; }
+};
+template <typename T> using cplx = cplx_s<T>;
+#endif
 
-template <typename T> MMW_HD cplx<T> operator+(cplx<T> a, cplx<T> b) { return {a.x + b.x, a.y + b.y}; }
-template <typename T> MMW_HD cplx<T> operator-(cplx<T> a, cplx<T> b) { return {a.x - b.x, a.y - b.y}; }
-template <typename T> MMW_HD cplx<T> operator*(cplx<T> a, cplx<T> b) {
-    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+template <typename T> MMW_HD cplx<T> cmul(cplx<T> a, cplx<T> b) {
+    return cplx<T>{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
-template <typename T> MMW_HD cplx<T> operator*(cplx<T> a, T s) { return {a.x * s, a.y * s}; }
 
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
 constexpr bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -44,21 +54,21 @@ template <int N, int K, typename T> MMW_HD cplx<T> mul_w(cplx<T> a) {
     if constexpr (k == 0) {
         return a;
     } else if constexpr (4 * k == N) {
-        return {a.y, -a.x};
+        return cplx<T>{a.y, -a.x};
     } else if constexpr (2 * k == N) {
-        return {-a.x, -a.y};
+        return cplx<T>{-a.x, -a.y};
     } else if constexpr (4 * k == 3 * N) {
-        return {-a.y, a.x};
+        return cplx<T>{-a.y, a.x};
     } else if constexpr (8 * k == N) {
         constexpr T r = (T)0.70710678118654752440;
-        return {(a.x + a.y) * r, (a.y - a.x) * r};
+        return cplx<T>{(a.x + a.y) * r, (a.y - a.x) * r};
     } else if constexpr (8 * k == 3 * N) {
         constexpr T r = (T)0.70710678118654752440;
-        return {(a.y - a.x) * r, -(a.x + a.y) * r};
+        return cplx<T>{(a.y - a.x) * r, -(a.x + a.y) * r};
     } else {
         constexpr T c = (T)twc::C64[k * (64 / N)];
         constexpr T s = (T)twc::S64[k * (64 / N)];
-        return {a.x * c + a.y * s, a.y * c - a.x * s};
+        return cplx<T>{a.x * c + a.y * s, a.y * c - a.x * s};
     }
 }
 

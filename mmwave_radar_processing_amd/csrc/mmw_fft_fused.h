@@ -35,15 +35,15 @@ __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, v
     for (int v = 0; v < VIN; ++v) {
         const f32x4 t = src[(long)v * pairs_per_frame];
         const float h = win.h[v];
-        xa[v] = {t.x * h, t.y * h};
-        xb[v] = {t.z * h, t.w * h};
+        xa[v] = cplx<float>{t.x, t.y} * h;
+        xb[v] = cplx<float>{t.z, t.w} * h;
     }
     static_for<8>([&](auto K1) {
         constexpr int k1 = decltype(K1)::value;
         cplx<float> za[8], zb[8];
         static_for<8>([&](auto N2) {
             constexpr int n2 = decltype(N2)::value;
-            cplx<float> ya = {0.f, 0.f}, yb = {0.f, 0.f};
+            cplx<float> ya = cplx<float>{0.f, 0.f}, yb = cplx<float>{0.f, 0.f};
             if constexpr (n2 < VIN) {
                 ya = xa[n2];
                 yb = xb[n2];
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
             const int n = 16 * n1 + w;
             const f32x4 v = src[n * (RD_C / 2) + l];
             const float hs = hann_s[n];
-            y0[n1] = {v.x * (hs * hc0), v.y * (hs * hc0)};
-            y1[n1] = {v.z * (hs * hc1), v.w * (hs * hc1)};
+            y0[n1] = cplx<float>{v.x, v.y} * (hs * hc0);
+            y1[n1] = cplx<float>{v.z, v.w} * (hs * hc1);
         }
         RegFFT<16, float>::run(y0);
         RegFFT<16, float>::run(y1);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
                 constexpr int k1 = 8 * h + k1l;
                 const cplx<float> tw = tw256[w * k1];
                 constexpr int br = bitrev<16>(k1);
-                const cplx<float> a = y0[br] * tw, b = y1[br] * tw;
+                const cplx<float> a = cmul(y0[br], tw), b = cmul(y1[br], tw);
                 *reinterpret_cast<f32x4 *>(&lds[(k1l * 16 + w) * 128 + 2 * l]) = f32x4{a.x, a.y, b.x, b.y};
             });
             __syncthreads();
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
             // X3 in place: only this wave reads/writes rows 8w .. 8w+7 from here on
             static_for<16>([&](auto K) {
                 constexpr int k1d = decltype(K)::value;
-                lds[rl * RD_PITCH + k1d * 9 + j8] = d[bitrev<16>(k1d)] * tw128_l[j8 * k1d];
+                lds[rl * RD_PITCH + k1d * 9 + j8] = cmul(d[bitrev<16>(k1d)], tw128_l[j8 * k1d]);
             });
             __syncthreads();
             // ---- Doppler pass 2 + store (two (row, k1d) units per lane)

@@ -78,18 +78,18 @@ __global__ __launch_bounds__(B *R2) void k_fft_strided(FftArgs p) {
 #pragma unroll
     for (int n1 = 0; n1 < R1; ++n1) {
         const int n = R2 * n1 + j;
-        cplx<T> v = {(T)0, (T)0};
+        cplx<T> v = cplx<T>{(T)0, (T)0};
         if (active && n < p.n_in) {
             const cplx<TIN> x = in[(long)outer * p.in_outer_stride + (long)n * p.in_axis_stride + i * p.in_inner_stride];
             const T w = wa ? wa[n] * sc : sc;
-            v = {(T)x.x * w, (T)x.y * w};
+            v = cplx<T>{(T)x.x, (T)x.y} * w;
         }
         a[n1] = v;
     }
     RegFFT<R1, T>::run(a);
     static_for<R1>([&](auto K1) {
         constexpr int k1 = decltype(K1)::value;
-        lds[(k1 * R2 + j) * B + b] = a[bitrev<R1>(k1)] * tw[j * k1];
+        lds[(k1 * R2 + j) * B + b] = cmul(a[bitrev<R1>(k1)], tw[j * k1]);
     });
     __syncthreads();
 #pragma unroll
@@ -131,18 +131,18 @@ __global__ __launch_bounds__(B *R2) void k_fft_contig(FftArgs p) {
 #pragma unroll
     for (int n1 = 0; n1 < R1; ++n1) {
         const int n = R2 * n1 + j;
-        cplx<T> v = {(T)0, (T)0};
+        cplx<T> v = cplx<T>{(T)0, (T)0};
         if (active && n < p.n_in) {
             const cplx<TIN> x = in[row * p.in_outer_stride + (long)n * p.in_axis_stride];
             const T w = wa ? wa[n] * sc : sc;
-            v = {(T)x.x * w, (T)x.y * w};
+            v = cplx<T>{(T)x.x, (T)x.y} * w;
         }
         a[n1] = v;
     }
     RegFFT<R1, T>::run(a);
     static_for<R1>([&](auto K1) {
         constexpr int k1 = decltype(K1)::value;
-        lds[(b * R1 + k1) * P + j] = a[bitrev<R1>(k1)] * tw[j * k1];
+        lds[(b * R1 + k1) * P + j] = cmul(a[bitrev<R1>(k1)], tw[j * k1]);
     });
     __syncthreads();
 #pragma unroll
@@ -185,21 +185,21 @@ __global__ __launch_bounds__(256) void k_dft_direct(FftArgs p, int N, int B) {
     T sc = (T)p.scale;
     if (active && wi) sc *= wi[i];
     for (int n = kq; n < p.n_in; n += KT) {
-        cplx<T> v = {(T)0, (T)0};
+        cplx<T> v = cplx<T>{(T)0, (T)0};
         if (active) {
             const cplx<TIN> xi = in[(long)outer * p.in_outer_stride + (long)n * p.in_axis_stride + i * p.in_inner_stride];
             const T w = wa ? wa[n] * sc : sc;
-            v = {(T)xi.x * w, (T)xi.y * w};
+            v = cplx<T>{(T)xi.x, (T)xi.y} * w;
         }
         x[n * B + b] = v;
     }
     __syncthreads();
     if (!active) return;
     for (int k = kq; k < N; k += KT) {
-        cplx<T> acc = {(T)0, (T)0};
+        cplx<T> acc = cplx<T>{(T)0, (T)0};
         int idx = 0;
         for (int n = 0; n < p.n_in; ++n) {
-            acc = acc + x[n * B + b] * tw[idx];
+            acc = acc + cmul(x[n * B + b], tw[idx]);
             idx += k;
             if (idx >= N) idx -= N;
         }

@@ -98,13 +98,28 @@ __global__ __launch_bounds__(256) void k_mean_abs_over_v(const cplx<T> *spec, T 
 
 // ------------------------------------------------------------------ in-situ HBM ceiling (diagnostics)
 // mode 0: dst = src (16 B/lane copy)   1: dst = const (write only)   2: read only (sum kept live)
+// mode 3: write only, non-temporal   4: write only, 4 stores in flight per lane   5: copy, 4 in flight
 typedef float diag_f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_diag_membw(const diag_f4 *src, diag_f4 *dst, size_t n_vec, int mode) {
     const size_t stride = (size_t)gridDim.x * 256;
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     diag_f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += stride) {
+    const diag_f4 k = {1.f, 2.f, 3.f, 4.f};
+    if (mode == 4 || mode == 5) {
+        for (size_t i = i0; i + 3 * stride < n_vec; i += 4 * stride) {
+            if (mode == 4) {
+                dst[i] = k; dst[i + stride] = k; dst[i + 2 * stride] = k; dst[i + 3 * stride] = k;
+            } else {
+                const diag_f4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+                dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+            }
+        }
+        return;
+    }
+    for (size_t i = i0; i < n_vec; i += stride) {
         if (mode == 0) dst[i] = src[i];
-        else if (mode == 1) dst[i] = diag_f4{1.f, 2.f, 3.f, 4.f};
+        else if (mode == 1) dst[i] = k;
+        else if (mode == 3) __builtin_nontemporal_store(k, dst + i);
         else acc += src[i];
     }
     if (mode == 2 && acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[0] = acc;

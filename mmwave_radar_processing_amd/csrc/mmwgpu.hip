@@ -345,7 +345,7 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
                 int A, int magnitude) {
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
-    int chunk = env_int("MMW_CHAIN_CHUNK", 8);
+    int chunk = env_int("MMW_CHAIN_CHUNK", 1024);
     if (chunk < 1) chunk = 1;
     const size_t cube_elems = (size_t)V * S * C;
     const size_t out_elem_bytes = magnitude ? sizeof(float) : sizeof(cplx<float>);
@@ -514,7 +514,7 @@ int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
 }
 
 int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks) {
-    MMW_REQUIRE(ctx && d_src && d_dst && bytes % 16 == 0 && mode >= 0 && mode <= 2, "bad argument");
+    MMW_REQUIRE(ctx && d_src && d_dst && bytes % 16 == 0 && mode >= 0 && mode <= 5, "bad argument");
     if (blocks <= 0) blocks = ctx->num_cu * 8;
     hipLaunchKernelGGL(k_diag_membw, dim3(blocks), dim3(256), 0, ctx->stream, (const diag_f4 *)d_src,
                        (diag_f4 *)d_dst, bytes / 16, mode);
