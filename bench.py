@@ -123,7 +123,9 @@ def main():
                                    "64-bin angle FFT -> complex64 [64,256,128] (BASELINE configs[1])",
                        "frames_per_gpu": F, "cube": [V, S, C], "angle_bins": A,
                        "sharding": f"frame-sharded x{world}, no collective",
-                       "chunk_frames": int(os.environ.get("MMW_CHAIN_CHUNK", "1024")),
+                       "schedule": "overlapped: fused range-Doppler kernel on 5/8 of the CUs beside the angle kernel on "
+                                   "3/8, 40-frame chunks, RD->angle intermediate resident in Infinity Cache "
+                                   "(override: MMW_CHAIN_PIPELINE / MMW_CHAIN_CHUNK / MMW_RD_CUS)",
                        "device": info["name"], "arch": info["arch"]},
             "hip_event_ms_per_step_rank0": ev_ms / args.steps,
             "chain_hbm_frac_of_8TBs": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),
@@ -138,7 +140,8 @@ def main():
                 traffic = None
                 if os.path.exists(args.traffic_json):
                     with open(args.traffic_json) as fh:
-                        traffic = json.load(fh).get("angle_bytes_per_launch")
+                        per_frame = json.load(fh).get("angle_bytes_per_frame")
+                    traffic = per_frame * frames_per_launch if per_frame else None
                 out["roofline"] = {"bound": "hbm", "kernel": "k_angle64 (angle FFT, reads V planes / writes 64)",
                                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

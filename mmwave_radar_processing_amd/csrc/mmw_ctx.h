@@ -66,6 +66,10 @@ struct mmw_ctx {
     int device = 0;
     int num_cu = 0;
     hipStream_t stream = nullptr;
+    // overlapped chain (DESIGN.md "chain schedule"): two CU-masked queues + ordering events, created lazily
+    hipStream_t q_rd = nullptr, q_ang = nullptr;
+    int q_rd_cus = 0;
+    hipEvent_t pipe_rd[2] = {nullptr, nullptr}, pipe_ang[2] = {nullptr, nullptr}, pipe_begin = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;      // mmw_timer_*
     bool profiling = false;                     // per-family kernel timing (mmw_profile_*)
     std::map<std::string, mmw::ProfileSlot> prof;

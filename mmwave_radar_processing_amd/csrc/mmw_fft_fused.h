@@ -81,7 +81,7 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)F);
-    const bool nt = tune_int("MMW_ANGLE_NT", 0) != 0;
+    const bool nt = tune_int("MMW_ANGLE_NT", 1) != 0;
 #define MMW_ANGLE_LAUNCH(MAGV, NTV) \
     hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w)
     if (mag && nt) MMW_ANGLE_LAUNCH(true, true);
@@ -108,6 +108,7 @@ constexpr int RD_S = 256, RD_C = 128, RD_PITCH = 152;
 constexpr int RD_LDS_MAIN = 128 * RD_PITCH;                       // complex elements (>= 8*16*128 for X1)
 constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8;           // + W128 table
 
+template <bool NTIN>
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int n = 16 * n1 + w;
-            const f32x4 v = src[n * (RD_C / 2) + l];
+            const f32x4 v = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l) : src[n * (RD_C / 2) + l];
             const float hs = hann_s[n];
             y0[n1] = cplx<float>{v.x, v.y} * (hs * hc0);
             y1[n1] = cplx<float>{v.z, v.w} * (hs * hc1);
@@ -206,14 +207,21 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 128, &t128));
     static bool attr_set = false;
     if (!attr_set) {
-        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_fused_256x128),
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_fused_256x128<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_fused_256x128<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
         attr_set = true;
     }
     const int blocks = planes;   // one plane per workgroup: a persistent plane loop made hipcc hoist and spill
-    hipLaunchKernelGGL(k_rd_fused_256x128, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
-                       (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                       (const cplx<float> *)t256, (const cplx<float> *)t128);
+    if (tune_int("MMW_RD_NT", 1))
+        hipLaunchKernelGGL(k_rd_fused_256x128<true>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
+                           (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                           (const cplx<float> *)t256, (const cplx<float> *)t128);
+    else
+        hipLaunchKernelGGL(k_rd_fused_256x128<false>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
+                           (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                           (const cplx<float> *)t256, (const cplx<float> *)t128);
     return check_launch("rd_fused");
 }
 

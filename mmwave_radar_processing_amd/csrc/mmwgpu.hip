@@ -138,6 +138,15 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
     (void)hipEventDestroy(ctx->t1);
     drain_profile(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->q_rd) {
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(ctx->pipe_rd[i]);
+            (void)hipEventDestroy(ctx->pipe_ang[i]);
+        }
+        (void)hipEventDestroy(ctx->pipe_begin);
+        (void)hipStreamDestroy(ctx->q_rd);
+        (void)hipStreamDestroy(ctx->q_ang);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MMW_OK;
@@ -341,29 +350,105 @@ int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int
     return launch_fft_axis<float, float>(ctx, a, A, false);
 }
 
+// Lazily create the two CU-masked queues of the overlapped chain: the RD queue owns the first rd_cus
+// CU-mask bits, the angle queue the rest, so workgroups of the two kernels are co-resident on the chip.
+static int ensure_pipe_queues(mmw_ctx *ctx, int rd_cus) {
+    if (ctx->q_rd && ctx->q_rd_cus == rd_cus) return MMW_OK;
+    if (ctx->q_rd) {
+        MMW_HIP(hipStreamSynchronize(ctx->q_rd));
+        MMW_HIP(hipStreamSynchronize(ctx->q_ang));
+        MMW_HIP(hipStreamDestroy(ctx->q_rd));
+        MMW_HIP(hipStreamDestroy(ctx->q_ang));
+        ctx->q_rd = ctx->q_ang = nullptr;
+    } else {
+        for (int i = 0; i < 2; ++i) {
+            MMW_HIP(hipEventCreateWithFlags(&ctx->pipe_rd[i], hipEventDisableTiming));
+            MMW_HIP(hipEventCreateWithFlags(&ctx->pipe_ang[i], hipEventDisableTiming));
+        }
+        MMW_HIP(hipEventCreateWithFlags(&ctx->pipe_begin, hipEventDisableTiming));
+    }
+    const int words = (ctx->num_cu + 31) / 32;
+    std::vector<uint32_t> m_rd(words, 0u), m_ang(words, 0u);
+    for (int i = 0; i < ctx->num_cu; ++i) ((i < rd_cus) ? m_rd : m_ang)[i / 32] |= 1u << (i % 32);
+    MMW_HIP(hipExtStreamCreateWithCUMask(&ctx->q_rd, (uint32_t)words, m_rd.data()));
+    MMW_HIP(hipExtStreamCreateWithCUMask(&ctx->q_ang, (uint32_t)words, m_ang.data()));
+    ctx->q_rd_cus = rd_cus;
+    return MMW_OK;
+}
+
 int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames, int V, int S, int C,
                 int A, int magnitude) {
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
-    int chunk = env_int("MMW_CHAIN_CHUNK", 1024);
+    if (n_frames == 0) return MMW_OK;
+    const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
+    const size_t out_frame_bytes = (size_t)A * S * C * (magnitude ? sizeof(float) : sizeof(cplx<float>));
+    // Two schedules (DESIGN.md "chain schedule").
+    //  serial    : RD then angle over chunks of frames on the context stream.
+    //  overlapped: RD(k+1) on a queue masked to rd_cus CUs runs beside angle(k) on the remaining CUs.  RD is
+    //              LDS/ALU/latency bound, angle is HBM-write bound and saturates HBM from ~3/8 of the CUs, and
+    //              the double-buffered RD scratch (2 chunks ~ 250 MB) stays resident in the 256 MB Infinity
+    //              Cache, so the RD->angle intermediate never goes to HBM.  Default for batches of the fused
+    //              shape; MMW_CHAIN_PIPELINE=0/1 forces a schedule.
+    int rd_cus = env_int("MMW_RD_CUS", ctx->num_cu * 5 / 8);
+    if (rd_cus < 1 || rd_cus >= ctx->num_cu) rd_cus = ctx->num_cu / 2;
+    // chunk: whole RD waves (rd_cus planes each) and two chunks of RD output within ~250 MB of cache
+    int chunk_auto = (int)((250u << 20) / (2 * cube_bytes));
+    if (V > 0 && rd_cus % 1 == 0) {
+        const int per_wave_num = rd_cus, per_wave_den = V;     // frames per RD wave = rd_cus / V
+        int waves = (int)((long)chunk_auto * per_wave_den / per_wave_num);
+        if (waves >= 1) chunk_auto = (int)((long)waves * per_wave_num / per_wave_den);
+    }
+    if (chunk_auto < 1) chunk_auto = 1;
+    const bool fused_shape = fused_rd_ok(S, C) && A == 64 && (V == 4 || V == 8 || V == 12 || V == 16);
+    const int want_pipe = env_int("MMW_CHAIN_PIPELINE", -1);
+    const bool pipelined = !d_rd && (want_pipe == 1 || (want_pipe == -1 && fused_shape && n_frames >= 2 * chunk_auto));
+    int chunk = env_int("MMW_CHAIN_CHUNK", pipelined ? chunk_auto : 1024);
     if (chunk < 1) chunk = 1;
-    const size_t cube_elems = (size_t)V * S * C;
-    const size_t out_elem_bytes = magnitude ? sizeof(float) : sizeof(cplx<float>);
+    if (chunk > n_frames) chunk = n_frames;
     void *rd_scratch = nullptr;
     if (!d_rd) {
-        // the FFT kernels may use ctx->scratch themselves only on the float64 path, not here
-        MMW_TRY(ensure_scratch(ctx, (size_t)chunk * cube_elems * sizeof(cplx<float>)));
+        MMW_TRY(ensure_scratch(ctx, (size_t)(pipelined ? 2 : 1) * chunk * cube_bytes));
         rd_scratch = ctx->scratch;
     }
-    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
-        const int nf = std::min(chunk, n_frames - f0);
-        const char *in = (const char *)d_cubes + (size_t)f0 * cube_elems * sizeof(cplx<float>);
-        char *rd = d_rd ? (char *)d_rd + (size_t)f0 * cube_elems * sizeof(cplx<float>) : (char *)rd_scratch;
-        char *out = (char *)d_out + (size_t)f0 * A * S * C * out_elem_bytes;
-        MMW_TRY(mmw_range_doppler(ctx, in, rd, nullptr, nf, V, S, C));
-        MMW_TRY(mmw_angle_fft(ctx, rd, out, nf, V, S, C, A, magnitude));
+    if (!pipelined) {
+        for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+            const int nf = std::min(chunk, n_frames - f0);
+            const char *in = (const char *)d_cubes + (size_t)f0 * cube_bytes;
+            char *rd = d_rd ? (char *)d_rd + (size_t)f0 * cube_bytes : (char *)rd_scratch;
+            MMW_TRY(mmw_range_doppler(ctx, in, rd, nullptr, nf, V, S, C));
+            MMW_TRY(mmw_angle_fft(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, magnitude));
+        }
+        return MMW_OK;
     }
-    return MMW_OK;
+    MMW_TRY(ensure_pipe_queues(ctx, rd_cus));
+    hipStream_t main_stream = ctx->stream;
+    // both queues start after whatever the caller enqueued on the context stream
+    MMW_HIP(hipEventRecord(ctx->pipe_begin, main_stream));
+    MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_begin, 0));
+    MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_begin, 0));
+    int k = 0, rc = MMW_OK;
+    for (int f0 = 0; f0 < n_frames && rc == MMW_OK; f0 += chunk, ++k) {
+        const int nf = std::min(chunk, n_frames - f0), buf = k & 1;
+        char *rd = (char *)rd_scratch + (size_t)buf * chunk * cube_bytes;
+        // RD(k) may overwrite its buffer only after angle(k-2) has read it
+        if (k >= 2) MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[buf], 0));
+        ctx->stream = ctx->q_rd;
+        rc = mmw_range_doppler(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C);
+        ctx->stream = main_stream;
+        if (rc != MMW_OK) break;
+        MMW_HIP(hipEventRecord(ctx->pipe_rd[buf], ctx->q_rd));
+        MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_rd[buf], 0));
+        ctx->stream = ctx->q_ang;
+        rc = mmw_angle_fft(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, magnitude);
+        ctx->stream = main_stream;
+        if (rc != MMW_OK) break;
+        MMW_HIP(hipEventRecord(ctx->pipe_ang[buf], ctx->q_ang));
+    }
+    // everything enqueued later on the context stream is ordered after the chain
+    if (k >= 1) MMW_HIP(hipStreamWaitEvent(main_stream, ctx->pipe_ang[(k - 1) & 1], 0));
+    if (k >= 2) MMW_HIP(hipStreamWaitEvent(main_stream, ctx->pipe_ang[k & 1], 0));
+    return rc;
 }
 
 int mmw_range_profile(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C,
