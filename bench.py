@@ -48,6 +48,19 @@ def cpu_baseline(seconds: float = 12.0):
                       f"(float64 NumPy, single thread) in {dt:.1f} s"}
 
 
+def chunk_frames(n_frames: int) -> int:
+    """Frames per kernel launch of mmw_chain3d's default overlapped schedule (csrc/mmwgpu.hip)."""
+    env = os.environ.get("MMW_CHAIN_CHUNK")
+    if env:
+        return max(1, min(int(env), n_frames))
+    rd_cus = int(os.environ.get("MMW_RD_CUS", 256 * 5 // 8))
+    auto = (250 << 20) // (2 * CUBE_BYTES)
+    waves = auto * V // rd_cus
+    if waves >= 1:
+        auto = waves * rd_cus // V
+    return max(1, min(auto, n_frames))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +69,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1250, help="frames resident per GPU (10k-frame batch / 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--profile-every", type=int, default=8,
+                    help="record a HIP event pair around every n-th launch of each kernel inside the timed region")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     args = ap.parse_args()
 
@@ -94,7 +109,7 @@ def main():
     barrier()
     if not args.no_profile:
         ctx.profile_reset()
-        ctx.profile_enable(True)
+        ctx.profile_enable(max(1, args.profile_every))
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
@@ -134,7 +149,8 @@ def main():
             ang_ms, ang_n = ctx.profile_get("angle")
             rd_ms, rd_n = ctx.profile_get("rd")
             if ang_n:
-                frames_per_launch = F * args.steps / ang_n
+                # sampled launches: full 40-frame chunks and the tail chunk are hit in proportion
+                frames_per_launch = F / -(-F // chunk_frames(F))
                 avg_s = ang_ms * 1e-3 / ang_n
                 achieved = frames_per_launch * ALGO_BYTES_PER_FRAME / avg_s / 1e9
                 traffic = None
@@ -149,7 +165,7 @@ def main():
                                    "frames_per_launch": frames_per_launch,
                                    "algorithmic_bytes_per_launch": frames_per_launch * ALGO_BYTES_PER_FRAME}
             if rd_n:
-                fpl = F * args.steps / rd_n
+                fpl = F / -(-F // chunk_frames(F))
                 avg_s = rd_ms * 1e-3 / rd_n
                 out["rd_kernel"] = {"avg_launch_us": avg_s * 1e6, "launches": rd_n,
                                     "achieved_GBs": fpl * 2 * CUBE_BYTES / avg_s / 1e9,

@@ -172,7 +172,9 @@ int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, i
 
 /* ---------------------------------------------------------------- per-kernel timing hook for bench.py
  * Average duration (ms) of the most recent launch group of the named kernel family measured
- * with HIP events on the ctx stream: "rd", "angle", "cfar".  Enabled by mmw_profile_enable(1). */
+ * with HIP event pairs on the launching queue (no host sync): "rd", "angle", "cfar", ...
+ * mmw_profile_enable(ctx, n): 0 = off, 1 = time every launch group, n > 1 = every n-th per family
+ * (an event pair costs a few microseconds of queue time, so bench.py samples). */
 int mmw_profile_enable(mmw_ctx *ctx, int on);
 int mmw_profile_get(mmw_ctx *ctx, const char *family, float *total_ms, int *launches);
 int mmw_profile_reset(mmw_ctx *ctx);

@@ -188,7 +188,8 @@ class Context:
         check(self.lib.mmw_timer_stop(self.handle, C.byref(ms)))
         return ms.value
 
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """on: False/0 off, True/1 every launch group, n > 1 every n-th launch group of each family."""
         check(self.lib.mmw_profile_enable(self.handle, int(on)))
 
     def profile_reset(self):

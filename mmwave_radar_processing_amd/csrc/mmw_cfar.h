@@ -83,6 +83,8 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
     double *tile = reinterpret_cast<double *>(smem);
     const int hr = p.tr + p.gr, hd = p.td + p.gd;
     const int TW = CFAR_TC + 2 * hd, TH = CFAR_TR + 2 * hr;
+    double *rs_full = tile + TW * TH;                 // [TH][CFAR_TC] pairwise row sums of the full window row
+    double *rs_mask = rs_full + TH * CFAR_TC;         // same with the guard columns replaced by +0.0
     const long plane = (long)p.R * p.D;
     const double *X = p.X + (long)blockIdx.z * plane;
     const int r0 = blockIdx.y * CFAR_TR, c0 = blockIdx.x * CFAR_TC;
@@ -91,6 +93,19 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
         tile[t] = (rr >= 0 && rr < p.R && cc >= 0 && cc < p.D) ? X[(long)rr * p.D + cc] : 0.0;
     }
     __syncthreads();
+    const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
+    if (p.kind == MMW_CFAR_CA) {
+        // Every CUT of a column shares the per-row sums of its window rows: compute each (tile row, window
+        // start column) pair once, in NumPy's pairwise order, then add Wr of them in row order per CUT.
+        for (int t = threadIdx.x; t < TH * CFAR_TC; t += CFAR_TR * CFAR_TC) {
+            const int row = t / CFAR_TC, col = t % CFAR_TC;
+            const double *src = tile + row * TW + col;
+            rs_full[t] = np_pairwise<2>([&](int wd) { return src[wd]; }, 0, Wd);
+            rs_mask[t] = np_pairwise<2>(
+                [&](int wd) { return (wd >= p.td && wd <= p.td + 2 * p.gd) ? 0.0 : src[wd]; }, 0, Wd);
+        }
+        __syncthreads();
+    }
     const int lr = threadIdx.x / CFAR_TC, lc = threadIdx.x % CFAR_TC;
     const int r = r0 + lr, c = c0 + lc;
     if (r >= p.R || c >= p.D) return;
@@ -98,19 +113,16 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
     double thr = INFINITY, est = 0.0;
     const bool valid = r >= hr && r < p.R - hr && c >= hd && c < p.D - hd;
     if (valid) {
-        const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
         const int ntrain = Wr * Wd - (2 * p.gr + 1) * (2 * p.gd + 1);
-        // window row wr, column wd (both relative to the window's top-left corner)
-        auto cell = [&](int wr, int wd) { return tile[(lr + wr) * TW + lc + wd]; };
-        auto guarded = [&](int wr, int wd) {
-            return wr >= p.tr && wr <= p.tr + 2 * p.gr && wd >= p.td && wd <= p.td + 2 * p.gd;
-        };
         if (p.kind == MMW_CFAR_CA) {
             double sum = 0.0;
-            for (int wr = 0; wr < Wr; ++wr)
-                sum += np_pairwise<2>([&](int wd) { return guarded(wr, wd) ? 0.0 : cell(wr, wd); }, 0, Wd);
+            for (int wr = 0; wr < Wr; ++wr) {
+                const bool guard_row = wr >= p.tr && wr <= p.tr + 2 * p.gr;
+                sum += (guard_row ? rs_mask : rs_full)[(lr + wr) * CFAR_TC + lc];
+            }
             est = sum / (double)ntrain;
         } else {  // OS: k-th smallest of the training cells
+            auto cell = [&](int wr, int wd) { return tile[(lr + wr) * TW + lc + wd]; };
             auto train = [&](int i) {
                 // enumerate training cells in row-major window order, skipping the guard block
                 const int gw = 2 * p.gd + 1, g0 = p.tr * Wd;                 // cells before the guard rows

@@ -70,8 +70,12 @@ struct mmw_ctx {
     hipStream_t q_rd = nullptr, q_ang = nullptr;
     int q_rd_cus = 0;
     hipEvent_t pipe_rd[2] = {nullptr, nullptr}, pipe_ang[2] = {nullptr, nullptr}, pipe_begin = nullptr;
+    bool pipe_ang_used[2] = {false, false};
+    bool pipe_pending = false;   // chain work in flight on q_rd/q_ang that the context stream has not joined yet
     hipEvent_t t0 = nullptr, t1 = nullptr;      // mmw_timer_*
     bool profiling = false;                     // per-family kernel timing (mmw_profile_*)
+    int prof_every = 1;                         // time every n-th launch group of a family (event records cost ~us)
+    std::map<std::string, int> prof_seen;
     std::map<std::string, mmw::ProfileSlot> prof;
     std::vector<hipEvent_t> ev_pool;            // idle events
     std::vector<mmw::PendingSpan> ev_pending;   // recorded, not yet read back
@@ -129,9 +133,25 @@ template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **
     return MMW_OK;
 }
 
+// Order the context stream after any overlapped-chain work still running on the two chain queues.  The
+// chain does not do this itself so that back-to-back mmw_chain3d calls keep the RD || angle pipeline full;
+// every other entry point that touches the context stream calls it first.
+inline int join_pipe(mmw_ctx *ctx) {
+    if (!ctx->pipe_pending) return MMW_OK;
+    for (int i = 0; i < 2; ++i)
+        if (ctx->pipe_ang_used[i]) MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_ang[i], 0));
+    ctx->pipe_pending = false;
+    return MMW_OK;
+}
+#define MMW_JOIN(ctx) MMW_TRY(mmw::join_pipe(ctx))
+
 inline int ensure_scratch(mmw_ctx *ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return MMW_OK;
     if (ctx->scratch) {
+        if (ctx->q_rd) {
+            MMW_HIP(hipStreamSynchronize(ctx->q_rd));
+            MMW_HIP(hipStreamSynchronize(ctx->q_ang));
+        }
         MMW_HIP(hipStreamSynchronize(ctx->stream));
         MMW_HIP(hipFree(ctx->scratch));
         ctx->scratch = nullptr;
@@ -176,6 +196,7 @@ struct ProfScope {
     PendingSpan span;
     bool on;
     ProfScope(mmw_ctx *c, const char *f) : ctx(c), span{f, nullptr, nullptr}, on(c->profiling) {
+        if (on && c->prof_every > 1) on = (c->prof_seen[f]++ % c->prof_every) == 0;
         if (!on) return;
         span.e0 = take_event(ctx);
         span.e1 = take_event(ctx);

@@ -59,6 +59,7 @@ template <typename T>
 int range_profile_impl(mmw_ctx *ctx, const void *d_cubes, T *d_out, int n_frames, int V, int S, int C,
                        int chirp_idx) {
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0, "bad shape");
     MMW_REQUIRE(chirp_idx >= -C && chirp_idx < C, "chirp_idx %d out of range", chirp_idx);
     if (chirp_idx < 0) chirp_idx += C;  // numpy negative indexing
@@ -139,6 +140,8 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
     drain_profile(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->q_rd) {
+        (void)hipStreamSynchronize(ctx->q_rd);
+        (void)hipStreamSynchronize(ctx->q_ang);
         for (int i = 0; i < 2; ++i) {
             (void)hipEventDestroy(ctx->pipe_rd[i]);
             (void)hipEventDestroy(ctx->pipe_ang[i]);
@@ -154,6 +157,7 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
 
 int mmw_sync(mmw_ctx *ctx) {
     MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
     MMW_HIP(hipStreamSynchronize(ctx->stream));
     return MMW_OK;
 }
@@ -171,6 +175,7 @@ int mmw_malloc(mmw_ctx *ctx, void **d_ptr, size_t bytes) {
 
 int mmw_free(mmw_ctx *ctx, void *d_ptr) {
     MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
     if (!d_ptr) return MMW_OK;
     auto it = std::find(ctx->owned.begin(), ctx->owned.end(), d_ptr);
     MMW_REQUIRE(it != ctx->owned.end(), "pointer was not allocated by this context");
@@ -182,6 +187,7 @@ int mmw_free(mmw_ctx *ctx, void *d_ptr) {
 
 int mmw_memcpy_h2d(mmw_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     MMW_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "null argument");
+    MMW_JOIN(ctx);
     if (!bytes) return MMW_OK;
     MMW_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     MMW_HIP(hipStreamSynchronize(ctx->stream));
@@ -190,6 +196,7 @@ int mmw_memcpy_h2d(mmw_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
 
 int mmw_memcpy_d2h(mmw_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     MMW_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "null argument");
+    MMW_JOIN(ctx);
     if (!bytes) return MMW_OK;
     MMW_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MMW_HIP(hipStreamSynchronize(ctx->stream));
@@ -198,6 +205,7 @@ int mmw_memcpy_d2h(mmw_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
 
 int mmw_memset(mmw_ctx *ctx, void *d_dst, int value, size_t bytes) {
     MMW_REQUIRE(ctx && (bytes == 0 || d_dst), "null argument");
+    MMW_JOIN(ctx);
     if (!bytes) return MMW_OK;
     MMW_HIP(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
     return MMW_OK;
@@ -205,12 +213,14 @@ int mmw_memset(mmw_ctx *ctx, void *d_dst, int value, size_t bytes) {
 
 int mmw_timer_start(mmw_ctx *ctx) {
     MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
     MMW_HIP(hipEventRecord(ctx->t0, ctx->stream));
     return MMW_OK;
 }
 
 int mmw_timer_stop(mmw_ctx *ctx, float *elapsed_ms) {
     MMW_REQUIRE(ctx && elapsed_ms, "null argument");
+    MMW_JOIN(ctx);
     MMW_HIP(hipEventRecord(ctx->t1, ctx->stream));
     MMW_HIP(hipEventSynchronize(ctx->t1));
     MMW_HIP(hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
@@ -220,6 +230,8 @@ int mmw_timer_stop(mmw_ctx *ctx, float *elapsed_ms) {
 int mmw_profile_enable(mmw_ctx *ctx, int on) {
     MMW_REQUIRE(ctx, "ctx is null");
     ctx->profiling = on != 0;
+    ctx->prof_every = on > 1 ? on : 1;      // on = n > 1: sample every n-th launch group per family
+    ctx->prof_seen.clear();
     return MMW_OK;
 }
 
@@ -243,6 +255,7 @@ int mmw_profile_get(mmw_ctx *ctx, const char *family, float *total_ms, int *laun
 int mmw_synth_cubes(mmw_ctx *ctx, void *d_cubes, int n_frames, int V, int S, int C, uint64_t seed0,
                     int num_targets, float noise_sigma) {
     MMW_REQUIRE(ctx && d_cubes, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0, "bad shape");
     MMW_REQUIRE(num_targets >= 0 && num_targets <= SYNTH_MAX_TARGETS, "num_targets must be 0..%d", SYNTH_MAX_TARGETS);
     const long total = (long)n_frames * V * S * C;
@@ -255,6 +268,7 @@ int mmw_synth_cubes(mmw_ctx *ctx, void *d_cubes, int n_frames, int V, int S, int
 int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, int n_frames, int num_rx,
                                int num_tx, int S, int loops) {
     MMW_REQUIRE(ctx && d_raw && d_virt, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && num_rx > 0 && num_tx > 0 && S > 0 && loops > 0, "bad shape");
     const long total = (long)n_frames * num_rx * num_tx * S * loops;
     if (!total) return MMW_OK;
@@ -264,8 +278,8 @@ int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, in
 }
 
 // ------------------------------------------------------------------ FFT chain
-int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_mag_f32, int n_frames, int V,
-                      int S, int C) {
+static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_mag_f32, int n_frames, int V,
+                             int S, int C) {
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0, "bad shape");
     if (n_frames == 0) return MMW_OK;
@@ -280,9 +294,17 @@ int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_ma
     return MMW_OK;
 }
 
+int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_mag_f32, int n_frames, int V,
+                      int S, int C) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
+    return range_doppler_impl(ctx, d_cubes, d_out, d_mag_f32, n_frames, V, S, C);
+}
+
 int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S,
                             int C, int rx_idx) {
     MMW_REQUIRE(ctx && d_cubes && d_mag, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && rx_idx >= 0 && rx_idx < V, "bad shape / rx_idx");
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "rd64");
@@ -315,8 +337,8 @@ int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, in
     return launch_fft_axis<double, double>(ctx, b, C, true);
 }
 
-int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
-                  int magnitude) {
+static int angle_fft_impl(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
+                         int magnitude) {
     MMW_REQUIRE(ctx && d_rd && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
     if (n_frames == 0) return MMW_OK;
@@ -348,6 +370,13 @@ int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int
     a.shift = 1;
     a.magnitude = magnitude != 0;
     return launch_fft_axis<float, float>(ctx, a, A, false);
+}
+
+int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
+                  int magnitude) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
+    return angle_fft_impl(ctx, d_rd, d_out, n_frames, V, S, C, A, magnitude);
 }
 
 // Lazily create the two CU-masked queues of the overlapped chain: the RD queue owns the first rd_cus
@@ -412,12 +441,13 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         rd_scratch = ctx->scratch;
     }
     if (!pipelined) {
+        MMW_JOIN(ctx);
         for (int f0 = 0; f0 < n_frames; f0 += chunk) {
             const int nf = std::min(chunk, n_frames - f0);
             const char *in = (const char *)d_cubes + (size_t)f0 * cube_bytes;
             char *rd = d_rd ? (char *)d_rd + (size_t)f0 * cube_bytes : (char *)rd_scratch;
-            MMW_TRY(mmw_range_doppler(ctx, in, rd, nullptr, nf, V, S, C));
-            MMW_TRY(mmw_angle_fft(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, magnitude));
+            MMW_TRY(range_doppler_impl(ctx, in, rd, nullptr, nf, V, S, C));
+            MMW_TRY(angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, magnitude));
         }
         return MMW_OK;
     }
@@ -432,22 +462,23 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         const int nf = std::min(chunk, n_frames - f0), buf = k & 1;
         char *rd = (char *)rd_scratch + (size_t)buf * chunk * cube_bytes;
         // RD(k) may overwrite its buffer only after angle(k-2) has read it
-        if (k >= 2) MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[buf], 0));
+        // (also across calls: the events persist, so a back-to-back chain keeps the pipeline full)
+        if (ctx->pipe_ang_used[buf]) MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[buf], 0));
         ctx->stream = ctx->q_rd;
-        rc = mmw_range_doppler(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C);
+        rc = range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C);
         ctx->stream = main_stream;
         if (rc != MMW_OK) break;
         MMW_HIP(hipEventRecord(ctx->pipe_rd[buf], ctx->q_rd));
         MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_rd[buf], 0));
         ctx->stream = ctx->q_ang;
-        rc = mmw_angle_fft(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, magnitude);
+        rc = angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, magnitude);
         ctx->stream = main_stream;
         if (rc != MMW_OK) break;
         MMW_HIP(hipEventRecord(ctx->pipe_ang[buf], ctx->q_ang));
+        ctx->pipe_ang_used[buf] = true;
     }
-    // everything enqueued later on the context stream is ordered after the chain
-    if (k >= 1) MMW_HIP(hipStreamWaitEvent(main_stream, ctx->pipe_ang[(k - 1) & 1], 0));
-    if (k >= 2) MMW_HIP(hipStreamWaitEvent(main_stream, ctx->pipe_ang[k & 1], 0));
+    // The context stream joins lazily (join_pipe) at the next entry point that uses it.
+    ctx->pipe_pending = true;
     return rc;
 }
 
@@ -464,6 +495,7 @@ int mmw_range_profile_f64(mmw_ctx *ctx, const void *d_cubes, double *d_out, int 
 int mmw_range_angle(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int A,
                     int chirp_idx, const int *h_rx, int n_rx, int perform_windowing) {
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A > 0, "bad shape");
     MMW_REQUIRE(chirp_idx >= -C && chirp_idx < C, "chirp_idx %d out of range", chirp_idx);
     MMW_REQUIRE(n_rx >= 0 && (n_rx == 0 || h_rx), "bad rx list");
@@ -525,6 +557,7 @@ int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, 
                int R, int D, int kind, int train_r, int train_d, int guard_r, int guard_d, double scale,
                int k_rank) {
     MMW_REQUIRE(ctx && d_X, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && R > 0 && D > 0, "bad shape");
     MMW_REQUIRE(train_r >= 0 && train_d >= 0 && guard_r >= 0 && guard_d >= 0, "negative window size");
     MMW_REQUIRE(kind == MMW_CFAR_CA || kind == MMW_CFAR_OS, "2-D CFAR kind must be CA or OS");
@@ -533,7 +566,7 @@ int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, 
     const long ntrain = (long)(2 * hr + 1) * (2 * hd + 1) - (long)(2 * guard_r + 1) * (2 * guard_d + 1);
     if (kind == MMW_CFAR_OS) MMW_REQUIRE(k_rank >= 1 && k_rank <= ntrain, "k_rank must be between 1 and %ld, got %d", ntrain, k_rank);
     MMW_REQUIRE(2 * hd + 1 <= 512, "Doppler window too wide for the exact summation order");
-    const size_t lds = (size_t)(CFAR_TR + 2 * hr) * (CFAR_TC + 2 * hd) * sizeof(double);
+    const size_t lds = ((size_t)(CFAR_TR + 2 * hr) * (CFAR_TC + 2 * hd) + 2 * (size_t)(CFAR_TR + 2 * hr) * CFAR_TC) * sizeof(double);
     if (lds > 64 * 1024) return set_error(MMW_ERR_UNSUPPORTED, "CFAR window %dx%d too large for the LDS tile", 2 * hr + 1, 2 * hd + 1);
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "cfar");
@@ -546,6 +579,7 @@ int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, 
 int mmw_cfar1d(mmw_ctx *ctx, const double *d_x, double *d_thr, double *d_noise, uint8_t *d_mask, int n_rows,
                int L, int kind, int num_train, int num_guard, double scale, int k_rank) {
     MMW_REQUIRE(ctx && d_x, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_rows >= 0 && L > 0 && num_train >= 0 && num_guard >= 0, "bad shape");
     MMW_REQUIRE(kind >= MMW_CFAR_CA && kind <= MMW_CFAR_SO, "unknown CFAR kind %d", kind);
     MMW_REQUIRE(num_train <= 512, "num_train too large for the exact summation order");
@@ -561,6 +595,7 @@ int mmw_cfar1d(mmw_ctx *ctx, const double *d_x, double *d_thr, double *d_noise, 
 int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t *d_counts, int n_frames,
                   int R, int D, int cap) {
     MMW_REQUIRE(ctx && d_mask && d_dets && d_counts, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && R > 0 && D > 0 && cap >= 0, "bad shape");
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "compact");
@@ -573,6 +608,7 @@ int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, cons
                      int32_t *d_idx, int n_frames, int V, int S, int C, int cap, const int *h_ant, int n_ant,
                      int A, int shift) {
     MMW_REQUIRE(ctx && d_rd && d_dets && d_counts && d_idx, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && n_frames <= 65535 && V > 0 && S > 0 && C > 0 && cap >= 0 && A > 0, "bad shape");
     MMW_REQUIRE(n_ant >= 1 && n_ant <= MAX_ANT && n_ant <= A && h_ant, "antenna list must have 1..%d entries (<= A)", MAX_ANT);
     AntList ants{};
@@ -595,11 +631,13 @@ int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, cons
 
 int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
     MMW_REQUIRE(ctx && (n == 0 || (d_in && d_out)), "null argument");
+    MMW_JOIN(ctx);
     return abs_c64(ctx, d_in, d_out, n);
 }
 
 int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks) {
     MMW_REQUIRE(ctx && d_src && d_dst && bytes % 16 == 0 && mode >= 0 && mode <= 5, "bad argument");
+    MMW_JOIN(ctx);
     if (blocks <= 0) blocks = ctx->num_cu * 8;
     hipLaunchKernelGGL(k_diag_membw, dim3(blocks), dim3(256), 0, ctx->stream, (const diag_f4 *)d_src,
                        (diag_f4 *)d_dst, bytes / 16, mode);
@@ -610,6 +648,7 @@ int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, i
 int mmw_bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int S,
                  int E, int T, double lambda_m) {
     MMW_REQUIRE(ctx && d_X && d_P && d_dirs && d_out, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(S > 0 && E > 0 && T > 0 && lambda_m > 0, "bad shape");
     return bartlett(ctx, d_X, d_P, d_dirs, d_out, S, E, T, lambda_m);
 }
@@ -617,6 +656,7 @@ int mmw_bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double 
 int mmw_capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out, int V, int R, int K, int T,
               double delta) {
     MMW_REQUIRE(ctx && d_X && h_thetas && d_out, "null argument");
+    MMW_JOIN(ctx);
     MMW_REQUIRE(V > 0 && V <= 16 && R > 0 && K > 0 && T > 0, "bad shape (V <= 16)");
     return capon(ctx, d_X, h_thetas, d_out, V, R, K, T, delta);
 }
