@@ -61,6 +61,20 @@ def chunk_frames(n_frames: int) -> int:
     return max(1, min(auto, n_frames))
 
 
+class stdout_to_stderr:
+    """Route C-level stdout to stderr (gloo prints connection chatter there; stdout carries only the JSON line)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +97,9 @@ def main():
     if world > 1:
         import torch.distributed as dist   # control plane only: barrier + max of the elapsed time
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        with stdout_to_stderr():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
 
     from mmwave_radar_processing_amd import _lib
     ndev = _lib.device_count()
@@ -180,8 +196,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        with stdout_to_stderr():
+            dist.barrier()
+            dist.destroy_process_group()
     ctx.close()
 
 

@@ -457,3 +457,79 @@ def test_frame_pipeline_matches_per_frame_processors_and_oracle():
         small = FramePipeline(cm, max_frames=2, shape=(12, 256, 128), det_capacity=4)
         small.load(cubes[:1])
         small.detect()
+
+
+def test_overlapped_chain_schedule_full_batch():
+    """The default schedule for large batches (RD and angle kernels on CU-masked queues, 40-frame chunks,
+    lazy join with the context stream): every chunk boundary, the tail chunk and back-to-back calls are
+    checked against the oracle, with unrelated work interleaved on the context stream."""
+    ctx = _lib.default_context()
+    F, V, S, C, A = 330, 12, 256, 128, 64
+    n = V * S * C
+    d_in, d_out, d_rd = ctx.alloc(F * n * 8), ctx.alloc(F * A * S * C * 8), ctx.alloc(4 * n * 8)
+    L, h = ctx.lib, ctx.handle
+    check_frames = (0, 39, 40, 41, 79, 80, 159, 160, 319, 320, 329)
+
+    def verify(cubes):
+        for f in check_frames:
+            got = d_out.download((A, S, C), np.complex64, f * A * S * C * 8)
+            assert rel_err(got, O.fft3d_windowed(cubes[f], A)) <= SPEC_TOL, f
+
+    for rnd, seed in enumerate((555, 777)):
+        _lib.check(L.mmw_synth_cubes(h, d_in.ptr, F, V, S, C, seed, 8, 30.0))
+        d_out.zero()
+        _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+        if rnd == 1:    # a second chain right behind the first (pipeline kept full), then other work
+            _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+            _lib.check(L.mmw_range_doppler(h, d_in.ptr, d_rd.ptr, None, 4, V, S, C))
+        cubes = d_in.download((F, V, S, C), np.complex64)
+        verify(cubes)
+        if rnd == 1:
+            rd = d_rd.download((4, V, S, C), np.complex64)
+            assert rel_err(rd[3], O.range_doppler(cubes[3])) <= SPEC_TOL
+    # magnitude output through the same schedule
+    _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 1))
+    for f in (0, 200, 329):
+        got = d_out.download((A, S, C), np.float32, f * A * S * C * 4)
+        assert rel_err(got, np.abs(O.fft3d_windowed(cubes[f], A))) <= SPEC_TOL
+    for b in (d_in, d_out, d_rd):
+        b.free()
+
+
+def test_degenerate_shapes_and_arguments():
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    buf = ctx.alloc(1 << 20)
+    # zero frames: accepted, nothing launched
+    assert L.mmw_range_doppler(h, buf.ptr, buf.ptr, None, 0, 12, 256, 128) == 0
+    assert L.mmw_chain3d(h, buf.ptr, None, buf.ptr, 0, 12, 256, 128, 64, 0) == 0
+    assert L.mmw_cfar2d(h, buf.ptr, None, None, buf.ptr, 0, 8, 8, 0, 1, 1, 0, 0, 1.0, 0) == 0
+    # bad arguments -> MMW_ERR_INVALID (-1) with a message, surfaced as ValueError
+    assert L.mmw_range_doppler(h, None, buf.ptr, None, 1, 12, 256, 128) == -1
+    assert L.mmw_angle_fft(h, buf.ptr, buf.ptr, 1, 12, 8, 8, 8, 0) == -1          # A < V
+    assert b"A >= V" in L.mmw_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(L.mmw_cfar2d(h, buf.ptr, None, None, buf.ptr, 1, 8, 8, 1, 1, 1, 0, 0, 1.0, 99))   # k_rank > N
+    with pytest.raises(ValueError):
+        _lib.check(L.mmw_free(h, 12345))
+    buf.free()
+    # single antenna, single chirp-ish shapes through the Python API
+    for shape in ((1, 8, 8), (2, 16, 2), (12, 4, 4), (3, 2, 5)):
+        V, S, C = shape
+        cm = make_cm(synth.synth_cfg_text(num_samples=S, num_loops=C))
+        cube = synth.synth_cube(3, shape, num_targets=2)
+        rd_got = RangeDopplerProcessor(cm).process(cube, rx_idx=-1, return_magnitude=False)
+        rd_ref = O.range_doppler(cube)
+        if np.max(np.abs(rd_ref)) > 0:  # hann(2) = [0, 0] zeroes the whole map in the reference too
+            assert rel_err(rd_got, rd_ref) <= SPEC_TOL
+        else:
+            assert np.max(np.abs(rd_got)) == 0
+        A = max(V, 4)
+        got = RangeAngleProcessorDBSEnhanced(cm, num_angle_bins_range_angle_response=A).compute_3d_windowed_fft(cube)
+        ref = O.fft3d_windowed(cube, A)
+        if np.max(np.abs(ref)) > 0:     # hann(1) = 1, hann(2) = [0, 0]: the reference's own degenerate cases
+            assert rel_err(got, ref) <= SPEC_TOL
+        else:
+            assert np.max(np.abs(got)) == 0
+    with pytest.raises(ValueError):
+        RangeDopplerProcessor(make_cm(synth.synth_cfg_text(8, 8))).process(np.zeros((8, 8), dtype=complex))
