@@ -91,7 +91,7 @@ int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, in
  *   end-to-end in float64 so detection indices are bit-exact against the float64 reference.
  * mmw_angle_fft: d_out[F][A][S][C] c64 = fftshift_A FFT_A( zero-pad_{V->A}( hann(V) rd ) )
  *   last stage of RangeAngleProcessorDBSEnhanced.compute_3d_windowed_fft
- *   (processors/range_angle_resp_dbs_enhanced.py:175-196).  If magnitude != 0 the output is
+ *   (processors/range_angle_resp_dbs_enhanced.py:175-196).  With MMW_ANGLE_MAGNITUDE the output is
  *   float32 |.| [F][A][S][C] instead (perform/process_dbs_enhanced :293).
  * mmw_chain3d: mmw_range_doppler followed by mmw_angle_fft, chunked so the RD intermediate
  *   stays cache-resident; d_rd may be NULL (internal scratch) or [F][V][S][C] to keep it.
@@ -100,10 +100,20 @@ int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_ma
                       int n_frames, int V, int S, int C);
 int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag,
                             int n_frames, int V, int S, int C, int rx_idx);
+/* flags of mmw_angle_fft / mmw_chain3d (0 = complex64 output, Hann(V) window, fftshift over angle) */
+#define MMW_ANGLE_MAGNITUDE 1   /* float32 |.| output                                                    */
+#define MMW_ANGLE_NO_WINDOW 2   /* no antenna window (DopplerAzimuthProcessor on "ods" geometry)         */
+#define MMW_ANGLE_NO_SHIFT  4   /* no fftshift over the angle axis (shift_angle=False)                   */
 int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames,
-                  int V, int S, int C, int A, int magnitude);
+                  int V, int S, int C, int A, int flags);
 int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames,
-                int V, int S, int C, int A, int magnitude);
+                int V, int S, int C, int A, int flags);
+/* mmw_mean_over_range: d_out[F][C][A] float32 = mean over range rows [s_lo, s_hi) of d_mag[F][A][S][C];
+ *   with mmw_chain3d(flags | MAGNITUDE) this is DopplerAzimuthProcessor.process, coarse path
+ *   (processors/doppler_azimuth_resp.py:84-128,296-334,419-491): range FFT -> range-window mask ->
+ *   2-D FFT over (chirp, antenna) -> |.| -> mean over the kept range bins. */
+int mmw_mean_over_range(mmw_ctx *ctx, const float *d_mag, float *d_out, int n_frames,
+                        int A, int S, int C, int s_lo, int s_hi);
 
 /* mmw_range_profile: d_out[F][S] float32 = mean_rx | FFT_S( hann(S) x[:, :, chirp] ) |
  *   replaces RangeProcessor.coarse_fft (processors/range_resp.py:32-57).

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmmwgpu.so")
 MMW_OK = 0
 MMW_ERR_TRUNCATED = -4
 CFAR_CA, CFAR_OS, CFAR_GO, CFAR_SO = 0, 1, 2, 3
+ANGLE_MAGNITUDE, ANGLE_NO_WINDOW, ANGLE_NO_SHIFT = 1, 2, 4
 
 
 class MmwGpuError(RuntimeError):
@@ -50,6 +51,7 @@ _SIGNATURES = {
     "mmw_range_doppler_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_angle_fft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_chain3d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "mmw_mean_over_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_range_profile": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_profile_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_angle": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _i, _i],

@@ -24,7 +24,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // NT: streaming (non-temporal) stores for the write-once output cube
 template <int VIN, bool MAG, bool NT>
 __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, void *__restrict__ out,
-                                                  long pairs_per_frame, AngleWin win) {
+                                                  long pairs_per_frame, AngleWin win, int shift_off) {
     // grid.x covers pairs of adjacent bins of one frame; grid.y = frame
     const long pair = (long)blockIdx.x * 256 + threadIdx.x;
     if (pair >= pairs_per_frame) return;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, v
         RegFFT<8, float>::run(zb);
         static_for<8>([&](auto K2) {
             constexpr int k2 = decltype(K2)::value;
-            constexpr int a = (k1 + 8 * k2 + 32) % 64;   // fftshift over the angle axis
+            const int a = (k1 + 8 * k2 + shift_off) & 63;   // fftshift over the angle axis (shift_off = 32)
             const cplx<float> va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
             const long o = (f * 64 + a) * pairs_per_frame + pair;
             if constexpr (MAG) {
@@ -76,14 +76,15 @@ __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, v
 }
 
 template <int VIN>
-int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bool mag, const float *h) {
+int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bool mag, const float *h, bool shift) {
     AngleWin w;
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)F);
     const bool nt = tune_int("MMW_ANGLE_NT", 1) != 0;
 #define MMW_ANGLE_LAUNCH(MAGV, NTV) \
-    hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w)
+    hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, \
+                       shift ? 32 : 0)
     if (mag && nt) MMW_ANGLE_LAUNCH(true, true);
     else if (mag) MMW_ANGLE_LAUNCH(true, false);
     else if (nt) MMW_ANGLE_LAUNCH(false, true);

@@ -125,6 +125,21 @@ __global__ __launch_bounds__(256) void k_diag_membw(const diag_f4 *src, diag_f4 
     if (mode == 2 && acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[0] = acc;
 }
 
+// out[f][c][a] = mean over range rows s in [s_lo, s_hi) of mag[f][a][s][c]
+// (DopplerAzimuthProcessor.process: np.mean(resp, axis=0), processors/doppler_azimuth_resp.py:489)
+__global__ __launch_bounds__(256) void k_mean_over_range(const float *mag, float *out, int F, int A, int S, int C,
+                                                          int s_lo, int s_hi) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)F * A * C) return;
+    const int c = (int)(gid % C);
+    const int a = (int)((gid / C) % A);
+    const long f = gid / ((long)C * A);
+    const float *src = mag + ((f * A + a) * S) * (long)C + c;
+    float acc = 0.f;
+    for (int s = s_lo; s < s_hi; ++s) acc += src[(long)s * C];
+    out[(f * C + c) * A + a] = acc / (float)(s_hi - s_lo);
+}
+
 constexpr int MAX_ANT = 32;
 struct AntList {
     int n;

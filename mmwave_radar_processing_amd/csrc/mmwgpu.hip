@@ -338,21 +338,24 @@ int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, in
 }
 
 static int angle_fft_impl(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
-                         int magnitude) {
+                         int flags) {
     MMW_REQUIRE(ctx && d_rd && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
+    MMW_REQUIRE((flags & ~7) == 0, "unknown flag bits %d", flags);
     if (n_frames == 0) return MMW_OK;
+    const bool magnitude = flags & MMW_ANGLE_MAGNITUDE, window = !(flags & MMW_ANGLE_NO_WINDOW),
+               shift = !(flags & MMW_ANGLE_NO_SHIFT);
     ProfScope ps(ctx, "angle");
     const long bins = (long)S * C;
     if (A == 64 && bins % 2 == 0 && n_frames <= 65535 && !env_int("MMW_NO_FUSED_ANGLE", 0) &&
         (V == 4 || V == 8 || V == 12 || V == 16)) {
         float h[16];
-        for (int i = 0; i < V; ++i) h[i] = (float)np_window(TAB_HANN, i, V);
+        for (int i = 0; i < V; ++i) h[i] = window ? (float)np_window(TAB_HANN, i, V) : 1.f;
         switch (V) {
-            case 4: return launch_angle64<4>(ctx, d_rd, d_out, n_frames, bins, magnitude != 0, h);
-            case 8: return launch_angle64<8>(ctx, d_rd, d_out, n_frames, bins, magnitude != 0, h);
-            case 12: return launch_angle64<12>(ctx, d_rd, d_out, n_frames, bins, magnitude != 0, h);
-            default: return launch_angle64<16>(ctx, d_rd, d_out, n_frames, bins, magnitude != 0, h);
+            case 4: return launch_angle64<4>(ctx, d_rd, d_out, n_frames, bins, magnitude, h, shift);
+            case 8: return launch_angle64<8>(ctx, d_rd, d_out, n_frames, bins, magnitude, h, shift);
+            case 12: return launch_angle64<12>(ctx, d_rd, d_out, n_frames, bins, magnitude, h, shift);
+            default: return launch_angle64<16>(ctx, d_rd, d_out, n_frames, bins, magnitude, h, shift);
         }
     }
     FftArgs a{};
@@ -365,18 +368,31 @@ static int angle_fft_impl(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_fra
     a.out_outer_stride = (long)A * bins;
     a.in_axis_stride = a.out_axis_stride = bins;
     a.in_inner_stride = a.out_inner_stride = 1;
-    MMW_TRY(get_table<float>(ctx, TAB_HANN, V, &a.win_axis));
+    if (window) MMW_TRY(get_table<float>(ctx, TAB_HANN, V, &a.win_axis));
     a.scale = 1.0;
-    a.shift = 1;
-    a.magnitude = magnitude != 0;
+    a.shift = shift;
+    a.magnitude = magnitude;
     return launch_fft_axis<float, float>(ctx, a, A, false);
 }
 
 int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
-                  int magnitude) {
+                  int flags) {
     MMW_REQUIRE(ctx, "ctx is null");
     MMW_JOIN(ctx);
-    return angle_fft_impl(ctx, d_rd, d_out, n_frames, V, S, C, A, magnitude);
+    return angle_fft_impl(ctx, d_rd, d_out, n_frames, V, S, C, A, flags);
+}
+
+int mmw_mean_over_range(mmw_ctx *ctx, const float *d_mag, float *d_out, int n_frames, int A, int S, int C,
+                        int s_lo, int s_hi) {
+    MMW_REQUIRE(ctx && d_mag && d_out, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && A > 0 && S > 0 && C > 0, "bad shape");
+    MMW_REQUIRE(0 <= s_lo && s_lo < s_hi && s_hi <= S, "empty or out-of-range row interval [%d, %d)", s_lo, s_hi);
+    const long total = (long)n_frames * A * C;
+    if (!total) return MMW_OK;
+    hipLaunchKernelGGL(k_mean_over_range, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_mag, d_out,
+                       n_frames, A, S, C, s_lo, s_hi);
+    return check_launch("mean_over_range");
 }
 
 // Lazily create the two CU-masked queues of the overlapped chain: the RD queue owns the first rd_cus
@@ -406,7 +422,8 @@ static int ensure_pipe_queues(mmw_ctx *ctx, int rd_cus) {
 }
 
 int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames, int V, int S, int C,
-                int A, int magnitude) {
+                int A, int flags) {
+    const int magnitude = flags & MMW_ANGLE_MAGNITUDE;
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
     if (n_frames == 0) return MMW_OK;
@@ -447,7 +464,7 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
             const char *in = (const char *)d_cubes + (size_t)f0 * cube_bytes;
             char *rd = d_rd ? (char *)d_rd + (size_t)f0 * cube_bytes : (char *)rd_scratch;
             MMW_TRY(range_doppler_impl(ctx, in, rd, nullptr, nf, V, S, C));
-            MMW_TRY(angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, magnitude));
+            MMW_TRY(angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, flags));
         }
         return MMW_OK;
     }
@@ -471,7 +488,7 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         MMW_HIP(hipEventRecord(ctx->pipe_rd[buf], ctx->q_rd));
         MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_rd[buf], 0));
         ctx->stream = ctx->q_ang;
-        rc = angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, magnitude);
+        rc = angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, flags);
         ctx->stream = main_stream;
         if (rc != MMW_OK) break;
         MMW_HIP(hipEventRecord(ctx->pipe_ang[buf], ctx->q_ang));

@@ -5,6 +5,7 @@ from .range_doppler_resp import RangeDopplerProcessor
 from .range_angle_resp import RangeAngleProcessor
 from .range_angle_resp_dbs_enhanced import RangeAngleProcessorDBSEnhanced
 from .point_cloud_generator import PointCloudGenerator
+from .doppler_azimuth_resp import DopplerAzimuthProcessor
 
 __all__ = ["_Processor", "VirtualArrayReformatter", "RangeProcessor", "RangeDopplerProcessor",
-           "RangeAngleProcessor", "RangeAngleProcessorDBSEnhanced", "PointCloudGenerator"]
+           "RangeAngleProcessor", "RangeAngleProcessorDBSEnhanced", "PointCloudGenerator", "DopplerAzimuthProcessor"]

@@ -172,6 +172,31 @@ def dbs_sharpen(mag_asc, velocity_ned, angle_bins_no_dbs, angle_bins_dbs, vel_bi
 
 
 # --------------------------------------------------------------------------
+# f-2  DopplerAzimuthProcessor.process, coarse path -- processors/doppler_azimuth_resp.py:84-128,296-334,419-491
+# --------------------------------------------------------------------------
+def doppler_azimuth(cube, sc, num_angle_bins=64, rx_antennas=(), range_window=(), shift_angle=True,
+                    valid_angle_range=(np.deg2rad(-60), np.deg2rad(60)), standard_geometry=True):
+    rx = np.asarray(rx_antennas)
+    x = cube[rx] if rx.size > 0 else cube                                   # :462-466
+    V, S, C = x.shape
+    xw = x * np.hanning(S)[None, :, None]
+    xw = xw * np.hanning(C)[None, None, :]
+    if standard_geometry and sc["virtual_antennas_enabled"]:                # :97-100
+        xw = xw * np.hanning(V)[:, None, None]
+    rng_bins, _ = rd_bins(sc)
+    rw = np.asarray(range_window, dtype=float)
+    if rw.size == 0:
+        rw = np.array([0, sc["range_max_m"]])
+    r = np.fft.fft(xw, axis=1)[:, (rng_bins >= rw[0]) & (rng_bins <= rw[1]), :]   # :119-126
+    data = np.zeros((r.shape[1], C, num_angle_bins), dtype=complex)
+    data[:, :, :V] = np.transpose(r, (1, 2, 0))
+    resp = np.abs(np.fft.fftshift(np.fft.fft2(data, axes=(1, 2)), axes=(1, 2) if shift_angle else (1)))   # :320-332
+    _, abins = angle_tables(num_angle_bins)
+    valid = (abins >= valid_angle_range[0]) & (abins <= valid_angle_range[1])
+    return np.mean(resp[:, :, valid], axis=0)                               # :486-489
+
+
+# --------------------------------------------------------------------------
 # a13/a14  CFAR family -- detectors/base.py, ca_cfar.py, os_cfar.py, go_so_cfar.py
 # --------------------------------------------------------------------------
 def alpha_ca(n_train_cells, pfa):

@@ -33,6 +33,7 @@ from mmwave_radar_processing.processors.range_angle_resp_dbs_enhanced import Ran
 from mmwave_radar_processing.processors.range_doppler_detection.range_doppler_detector_2d import RangeDopplerDetector2D  # noqa: E402
 from mmwave_radar_processing.processors.point_cloud_generator import PointCloudGenerator  # noqa: E402
 from mmwave_radar_processing.processors.simple_synthetic_array_beamformer_processor_multiFrame import SyntheticArrayBeamformerProcessor  # noqa: E402
+from mmwave_radar_processing.processors.doppler_azimuth_resp import DopplerAzimuthProcessor      # noqa: E402
 from mmwave_radar_processing.detectors import CaCFAR1D, CaCFAR2D, GoCFAR1D, SoCFAR1D, OsCFAR1D, OsCFAR2D  # noqa: E402
 
 from mmwave_radar_processing_amd import synth                                          # noqa: E402
@@ -235,9 +236,37 @@ def gen_bartlett():
     print("bartlett_small.npz:", out.shape)
 
 
+def gen_doppler_azimuth():
+    """DopplerAzimuthProcessor coarse path on a small cube (standard geometry) and the sample cfg shape (ods)."""
+    d = {}
+    cm = load_cm(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    p = DopplerAzimuthProcessor(cm, num_angle_bins=64)
+    d["std_all"] = p.process(cube)
+    d["std_sub_win"] = p.process(cube, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], shift_angle=False)
+    d["valid_angle_bins"] = p.valid_angle_bins
+    with open(os.path.join(REF, "configs", "6843_RadVel_ods_20Hz.cfg")) as f:
+        text = f.read()
+    with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as f:
+        f.write(text)
+        path = f.name
+    cm2 = ConfigManager()
+    cm2.load_cfg(path, array_geometry="ods", array_direction="down")
+    os.unlink(path)
+    virt = synth.synth_cube(202, (12, 63, 70))
+    p2 = DopplerAzimuthProcessor(cm2, num_angle_bins=64, valid_angle_range=np.array([-1.04719755, 1.04719755]))
+    d["ods_sub"] = p2.process(virt, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], shift_angle=False)
+    np.savez_compressed(os.path.join(HERE, "doppler_azimuth.npz"), **d)
+    print("doppler_azimuth.npz:", {k: v.shape for k, v in d.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "doppler_azimuth":
+        gen_doppler_azimuth()
+        sys.exit(0)
     gen_cfgs()
     gen_small_chain()
     gen_frames_256()
     gen_cfar_known()
     gen_bartlett()
+    gen_doppler_azimuth()

@@ -163,3 +163,17 @@ def test_capon_single_source_peak():
     th = np.linspace(-1.2, 1.2, 241)
     P = O.capon_spectrum(X, th)
     assert np.all(np.abs(th[np.argmax(P, axis=1)] - th0) <= 0.011)
+
+
+def test_doppler_azimuth_coarse_path(golden):
+    g = golden("doppler_azimuth.npz")
+    sc = O.cfg_scalars(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    close(O.doppler_azimuth(cube, sc), g["std_all"])
+    close(O.doppler_azimuth(cube, sc, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], shift_angle=False),
+          g["std_sub_win"])
+    with open(os.path.join(GOLDEN, "cfg_scalars.json")) as f:
+        sc2 = O.cfg_scalars("\n".join(json.load(f)["6843_RadVel_ods_20Hz.cfg"]["lines"]))
+    virt = synth.synth_cube(202, (12, 63, 70))
+    close(O.doppler_azimuth(virt, sc2, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], shift_angle=False,
+                            valid_angle_range=(-1.04719755, 1.04719755), standard_geometry=False), g["ods_sub"])
