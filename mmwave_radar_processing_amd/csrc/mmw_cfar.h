@@ -106,6 +106,39 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
         }
         __syncthreads();
     }
+    // OS: rank every tile element once per workgroup (bitonic sort of (ordered key, position) pairs in LDS)
+    unsigned long long *os_key = reinterpret_cast<unsigned long long *>(rs_full);
+    int os_bits = 0;
+    while ((1 << os_bits) < TW * TH) ++os_bits;
+    const int npad = 1 << os_bits;
+    unsigned short *os_pos = reinterpret_cast<unsigned short *>(os_key + npad);
+    unsigned short *os_rank = os_pos + npad;
+    if (p.kind == MMW_CFAR_OS) {
+        const int NT = CFAR_TR * CFAR_TC;
+        for (int t = threadIdx.x; t < npad; t += NT) {
+            os_key[t] = t < TW * TH ? f64_key(tile[t]) : ~0ull;
+            os_pos[t] = (unsigned short)t;
+        }
+        __syncthreads();
+        for (int k = 2; k <= npad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < npad / 2; t += NT) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j;
+                    const unsigned long long ka = os_key[i], kb = os_key[q];
+                    const unsigned short pa = os_pos[i], pb = os_pos[q];
+                    const bool a_gt_b = ka > kb || (ka == kb && pa > pb);
+                    if (a_gt_b == ((i & k) == 0)) {
+                        os_key[i] = kb; os_key[q] = ka;
+                        os_pos[i] = pb; os_pos[q] = pa;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int t = threadIdx.x; t < npad; t += NT)
+            if (os_pos[t] < TW * TH) os_rank[os_pos[t]] = (unsigned short)t;
+        __syncthreads();
+    }
     const int lr = threadIdx.x / CFAR_TC, lc = threadIdx.x % CFAR_TC;
     const int r = r0 + lr, c = c0 + lc;
     if (r >= p.R || c >= p.D) return;
@@ -121,27 +154,26 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
                 sum += (guard_row ? rs_mask : rs_full)[(lr + wr) * CFAR_TC + lc];
             }
             est = sum / (double)ntrain;
-        } else {  // OS: k-th smallest of the training cells
-            auto cell = [&](int wr, int wd) { return tile[(lr + wr) * TW + lc + wd]; };
-            auto train = [&](int i) {
-                // enumerate training cells in row-major window order, skipping the guard block
-                const int gw = 2 * p.gd + 1, g0 = p.tr * Wd;                 // cells before the guard rows
-                const int per_guard_row = Wd - gw, gspan = (2 * p.gr + 1) * per_guard_row;
-                int wr, wd;
-                if (i < g0) { wr = i / Wd; wd = i % Wd; }
-                else if (i < g0 + gspan) {
-                    const int q = i - g0;
-                    wr = p.tr + q / per_guard_row;
-                    wd = q % per_guard_row;
-                    if (wd >= p.td) wd += gw;
-                } else {
-                    const int q = i - g0 - gspan;
-                    wr = p.tr + 2 * p.gr + 1 + q / Wd;
-                    wd = q % Wd;
+        } else {
+            // OS: the k-th smallest training cell == the training cell with the k-th smallest tile rank.
+            // Bisection over the log2(npad) rank bits instead of 64 key bits, on 2-byte LDS reads.
+            int prefix = 0;
+            for (int bit = os_bits - 1; bit >= 0; --bit) {
+                const int cand = prefix | (1 << bit);
+                int below = 0;
+                for (int wr = 0; wr < Wr; ++wr) {
+                    const unsigned short *rrow = os_rank + (lr + wr) * TW + lc;
+                    const bool guard_row = wr >= p.tr && wr <= p.tr + 2 * p.gr;
+                    if (!guard_row) {
+                        for (int wd = 0; wd < Wd; ++wd) below += rrow[wd] < cand ? 1 : 0;
+                    } else {
+                        for (int wd = 0; wd < p.td; ++wd) below += rrow[wd] < cand ? 1 : 0;
+                        for (int wd = p.td + 2 * p.gd + 1; wd < Wd; ++wd) below += rrow[wd] < cand ? 1 : 0;
+                    }
                 }
-                return cell(wr, wd);
-            };
-            est = kth_smallest(train, ntrain, p.k_rank);
+                if (below < p.k_rank) prefix = cand;
+            }
+            est = f64_unkey(os_key[prefix]);
         }
         thr = p.scale * est;
     }

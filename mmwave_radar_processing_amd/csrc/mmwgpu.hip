@@ -583,7 +583,13 @@ int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, 
     const long ntrain = (long)(2 * hr + 1) * (2 * hd + 1) - (long)(2 * guard_r + 1) * (2 * guard_d + 1);
     if (kind == MMW_CFAR_OS) MMW_REQUIRE(k_rank >= 1 && k_rank <= ntrain, "k_rank must be between 1 and %ld, got %d", ntrain, k_rank);
     MMW_REQUIRE(2 * hd + 1 <= 512, "Doppler window too wide for the exact summation order");
-    const size_t lds = ((size_t)(CFAR_TR + 2 * hr) * (CFAR_TC + 2 * hd) + 2 * (size_t)(CFAR_TR + 2 * hr) * CFAR_TC) * sizeof(double);
+    const size_t n_tile = (size_t)(CFAR_TR + 2 * hr) * (CFAR_TC + 2 * hd);
+    size_t npad = 1;
+    while (npad < n_tile) npad <<= 1;
+    const size_t aux_ca = 2 * (size_t)(CFAR_TR + 2 * hr) * CFAR_TC * sizeof(double);     // row-sum tables
+    const size_t aux_os = npad * 8 + npad * 2 + n_tile * 2 + 16;                          // keys, positions, ranks
+    const size_t lds = n_tile * sizeof(double) + (kind == MMW_CFAR_OS ? aux_os : aux_ca);
+    MMW_REQUIRE(kind != MMW_CFAR_OS || npad <= 32768, "OS-CFAR window too large");
     if (lds > 64 * 1024) return set_error(MMW_ERR_UNSUPPORTED, "CFAR window %dx%d too large for the LDS tile", 2 * hr + 1, 2 * hd + 1);
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "cfar");

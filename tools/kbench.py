@@ -73,6 +73,25 @@ def main():
     d_dets, d_cnt = ctx.alloc(F * cap * 8), ctx.alloc(F * 4)
     run("compact2d", lambda: _lib.check(L.mmw_compact2d(ctx.handle, d_mask.ptr, d_dets.ptr, d_cnt.ptr, F, S, C, cap)),
         F * S * C)
+    k_os = max(1, min(int(0.7 * 200), 200))
+    run("cfar2d_os_5x5_g3x2", lambda: _lib.check(L.mmw_cfar2d(ctx.handle, d_mag.ptr, None, None, d_mask.ptr, F, S, C,
+                                                               1, 5, 5, 3, 2, 2.0, 122)), F * S * C * (8 + 1))
+    _lib.check(L.mmw_cfar2d(ctx.handle, d_mag.ptr, None, None, d_mask.ptr, F, S, C, 0, 4, 4, 2, 2, alpha, 0))
+    _lib.check(L.mmw_compact2d(ctx.handle, d_mask.ptr, d_dets.ptr, d_cnt.ptr, F, S, C, cap))
+    d_idx = ctx.alloc(F * cap * 4)
+    ants, n_ant = _lib.int_array(range(8))
+    run("angle_argmax_az8", lambda: _lib.check(L.mmw_angle_argmax(ctx.handle, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr,
+                                                                   min(F, 65535), V, S, C, cap, ants, n_ant, A, 1)), F * 8 * 80 * 8)
+
+    def detect_all():
+        _lib.check(L.mmw_range_doppler(ctx.handle, d_in.ptr, d_rd.ptr, None, F, V, S, C))
+        _lib.check(L.mmw_range_doppler_mag64(ctx.handle, d_in.ptr, d_mag.ptr, F, V, S, C, 0))
+        _lib.check(L.mmw_cfar2d(ctx.handle, d_mag.ptr, None, None, d_mask.ptr, F, S, C, 0, 4, 4, 2, 2, alpha, 0))
+        _lib.check(L.mmw_compact2d(ctx.handle, d_mask.ptr, d_dets.ptr, d_cnt.ptr, F, S, C, cap))
+        _lib.check(L.mmw_angle_argmax(ctx.handle, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, min(F, 65535), V, S, C, cap,
+                                      ants, n_ant, A, 1))
+    run("detect_pipeline_config3", detect_all, F * (2 * cube_b + S * C * 4))
+    res["mean_detections_per_frame"] = float(d_cnt.download((F,), np.int32).mean())
     print(json.dumps(res))
 
 
