@@ -109,7 +109,7 @@ constexpr int RD_S = 256, RD_C = 128, RD_PITCH = 152;
 constexpr int RD_LDS_MAIN = 128 * RD_PITCH;                       // complex elements (>= 8*16*128 for X1)
 constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8;           // + W128 table
 
-template <bool NTIN>
+template <bool NTIN, int ABL = 0>   // ABL: timing-only ablations (1 no stores, 2 no loads, 3 neither)
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
@@ -133,7 +133,9 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int n = 16 * n1 + w;
-            const f32x4 v = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l) : src[n * (RD_C / 2) + l];
+            f32x4 v;
+            if constexpr (ABL & 2) v = f32x4{(float)(n + l), (float)(n - l), (float)(n ^ l), 1.0f};
+            else v = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l) : src[n * (RD_C / 2) + l];
             const float hs = hann_s[n];
             y0[n1] = cplx<float>{v.x, v.y} * (hs * hc0);
             y1[n1] = cplx<float>{v.z, v.w} * (hs * hc1);
@@ -189,7 +191,13 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
                 static_for<8>([&](auto K) {
                     constexpr int k2d = decltype(K)::value;
                     const int kk = (k1d + 16 * k2d) ^ 64;       // fftshift over the 128 Doppler bins
-                    dst[kr * RD_C + kk] = e[bitrev<8>(k2d)];
+                    const cplx<float> val = e[bitrev<8>(k2d)];
+                    if constexpr (ABL & 1) {
+                        const float vx = val.x, vy = val.y;
+                        asm volatile("" ::"v"(vx), "v"(vy));
+                    } else {
+                        dst[kr * RD_C + kk] = val;
+                    }
                 });
             }
             __syncthreads();
@@ -215,6 +223,19 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
         attr_set = true;
     }
     const int blocks = planes;   // one plane per workgroup: a persistent plane loop made hipcc hoist and spill
+    const int abl = tune_int("MMW_RD_ABLATE", 0);
+    if (abl) {
+        auto launch = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
+                               (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                               (const cplx<float> *)t256, (const cplx<float> *)t128);
+        };
+        if (abl == 1) launch(k_rd_fused_256x128<true, 1>);
+        else if (abl == 2) launch(k_rd_fused_256x128<true, 2>);
+        else launch(k_rd_fused_256x128<true, 3>);
+        return check_launch("rd_fused_ablate");
+    }
     if (tune_int("MMW_RD_NT", 1))
         hipLaunchKernelGGL(k_rd_fused_256x128<true>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
                            (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,

@@ -468,7 +468,18 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         }
         return MMW_OK;
     }
-    MMW_TRY(ensure_pipe_queues(ctx, rd_cus));
+    if (ensure_pipe_queues(ctx, rd_cus) != MMW_OK) {
+        // CU-masked queues unavailable on this runtime: fall back to the serial schedule (same results)
+        MMW_JOIN(ctx);
+        const int big = std::min(n_frames, 1024);
+        MMW_TRY(ensure_scratch(ctx, (size_t)big * cube_bytes));
+        for (int f0 = 0; f0 < n_frames; f0 += big) {
+            const int nf = std::min(big, n_frames - f0);
+            MMW_TRY(range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, ctx->scratch, nullptr, nf, V, S, C));
+            MMW_TRY(angle_fft_impl(ctx, ctx->scratch, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, flags));
+        }
+        return MMW_OK;
+    }
     hipStream_t main_stream = ctx->stream;
     // both queues start after whatever the caller enqueued on the context stream
     MMW_HIP(hipEventRecord(ctx->pipe_begin, main_stream));
