@@ -65,6 +65,7 @@ struct PendingSpan {
 struct mmw_ctx {
     int device = 0;
     int num_cu = 0;
+    int active_cus = 0;                         // CUs of the queue being launched on (0 = all), set by the chain
     hipStream_t stream = nullptr;
     // overlapped chain (DESIGN.md "chain schedule"): two CU-masked queues + ordering events, created lazily
     hipStream_t q_rd = nullptr, q_ang = nullptr;

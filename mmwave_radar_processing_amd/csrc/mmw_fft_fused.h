@@ -205,6 +205,120 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
     }
 }
 
+// Persistent variant: each workgroup walks planes blockIdx.x, +gridDim.x, ... and issues the NEXT plane's 16 row
+// loads as soon as the y registers die (after the second X1 write), so the load latency hides under the rest of
+// the current plane.  PF = rows prefetched that early (16 = all, 8 = half; the rest load at the loop top).
+template <bool NTIN, int PF, int POS = 0>   // POS 0: prefetch after the 2nd X1 write, 1: after the 2nd X3 write
+__global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
+                                                            int planes, const float *__restrict__ hann_s,
+                                                            const float *__restrict__ hann_c,
+                                                            const cplx<float> *__restrict__ tw256,
+                                                            const cplx<float> *__restrict__ tw128) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
+    cplx<float> *tw128_l = lds + RD_LDS_MAIN;
+    if (threadIdx.x < 128) tw128_l[threadIdx.x] = tw128[threadIdx.x];
+    const int t0 = threadIdx.x;
+    const int l0 = t0 & 63;
+    const int w0 = __builtin_amdgcn_readfirstlane(t0 >> 6);
+
+    f32x4 nx[16];
+    auto issue_loads = [&](int plane, auto FIRST, auto LAST) {
+        const f32x4 *src = in + (long)plane * (RD_S * RD_C / 2);
+#pragma unroll
+        for (int n1 = decltype(FIRST)::value; n1 < decltype(LAST)::value; ++n1) {
+            const int n = 16 * n1 + w0;
+            nx[n1] = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l0) : src[n * (RD_C / 2) + l0];
+        }
+    };
+    if ((int)blockIdx.x < planes) issue_loads(blockIdx.x, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
+    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        cplx<float> *dst = out + (long)plane * (RD_S * RD_C);
+        // Re-derive the thread indices behind an opaque asm every plane: otherwise hipcc hoists every
+        // lane-constant LDS / global address out of the plane loop and spills them around it.
+        int t = t0;
+        asm volatile("" : "+v"(t));
+        const int l = t & 63;
+        const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+        const float hc0 = hann_c[2 * l], hc1 = hann_c[2 * l + 1];
+        if constexpr (PF < 16) issue_loads(plane, std::integral_constant<int, PF>{}, std::integral_constant<int, 16>{});
+        // ---- step 0: window, range pass 1 (n = 16*n1 + w)
+        cplx<float> y0[16], y1[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int n = 16 * n1 + w;
+            const f32x4 v = nx[n1];
+            const float hs = hann_s[n];
+            y0[n1] = cplx<float>{v.x, v.y} * (hs * hc0);
+            y1[n1] = cplx<float>{v.z, v.w} * (hs * hc1);
+        }
+        RegFFT<16, float>::run(y0);
+        RegFFT<16, float>::run(y1);
+        static_for<2>([&](auto H) {
+            constexpr int h = decltype(H)::value;
+            // ---- X1: [k1l][j = w][c], twiddle applied on the way out
+            static_for<8>([&](auto K) {
+                constexpr int k1l = decltype(K)::value;
+                constexpr int k1 = 8 * h + k1l;
+                const cplx<float> tw = tw256[w * k1];
+                constexpr int br = bitrev<16>(k1);
+                const cplx<float> a = cmul(y0[br], tw), b = cmul(y1[br], tw);
+                *reinterpret_cast<f32x4 *>(&lds[(k1l * 16 + w) * 128 + 2 * l]) = f32x4{a.x, a.y, b.x, b.y};
+            });
+            if constexpr (h == 1 && POS == 0) {     // y0 / y1 are dead from here on: their registers take the next plane
+                const int next = plane + gridDim.x;
+                if (next < planes) issue_loads(next, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
+            }
+            __syncthreads();
+            const int k1l = w & 7, c = 64 * (w >> 3) + l;
+            cplx<float> b[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) b[j] = lds[(k1l * 16 + j) * 128 + c];
+            RegFFT<16, float>::run(b);
+            __syncthreads();
+            // ---- X2: row-major [rl = k1l + 8*k2][c], pitch 152
+            static_for<16>([&](auto K) {
+                constexpr int k2 = decltype(K)::value;
+                lds[(k1l + 8 * k2) * RD_PITCH + c] = b[bitrev<16>(k2)];
+            });
+            __syncthreads();
+            // ---- Doppler pass 1: thread (rl, j8), chirps 8*n1 + j8
+            const int rl = t >> 3, j8 = t & 7;
+            cplx<float> d[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) d[n1] = lds[rl * RD_PITCH + 8 * n1 + j8];
+            RegFFT<16, float>::run(d);
+            // X3 in place: only this wave reads/writes rows 8w .. 8w+7 from here on
+            static_for<16>([&](auto K) {
+                constexpr int k1d = decltype(K)::value;
+                lds[rl * RD_PITCH + k1d * 9 + j8] = cmul(d[bitrev<16>(k1d)], tw128_l[j8 * k1d]);
+            });
+            if constexpr (h == 1 && POS == 1) {     // only e[8] is live below: room for all 16 rows of the next plane
+                const int next = plane + gridDim.x;
+                if (next < planes) issue_loads(next, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
+            }
+            __syncthreads();
+            // ---- Doppler pass 2 + store (two (row, k1d) units per lane)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = l + 64 * u;
+                const int k1d = idx & 15, row = 8 * w + (idx >> 4);
+                cplx<float> e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) e[q] = lds[row * RD_PITCH + k1d * 9 + q];
+                RegFFT<8, float>::run(e);
+                const int kr = 8 * h + (row & 7) + 16 * (row >> 3);
+                static_for<8>([&](auto K) {
+                    constexpr int k2d = decltype(K)::value;
+                    const int kk = (k1d + 16 * k2d) ^ 64;       // fftshift over the 128 Doppler bins
+                    dst[kr * RD_C + kk] = e[bitrev<8>(k2d)];
+                });
+            }
+            __syncthreads();
+        });
+    }
+}
+
 inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
 
 inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C) {
@@ -223,6 +337,25 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
         attr_set = true;
     }
     const int blocks = planes;   // one plane per workgroup: a persistent plane loop made hipcc hoist and spill
+    // Standalone launches use the persistent variant with 8 rows prefetched (+12 %); inside the overlapped
+    // chain the one-plane-per-workgroup kernel is faster (measured), so the chain sets active_cus and gets it.
+    const int pf = tune_int("MMW_RD_PERSIST", -1) >= 0 ? tune_int("MMW_RD_PERSIST", -1) : (ctx->active_cus > 0 ? 0 : 8);
+    if (pf == 8 || pf == 16) {
+        int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu) * tune_int("MMW_RD_PERSIST_WGS_PER_CU", 1);
+        if (grid > planes) grid = planes;
+        auto launch = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
+                               (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                               (const cplx<float> *)t256, (const cplx<float> *)t128);
+        };
+        const int pos = tune_int("MMW_RD_PERSIST_POS", 0);
+        if (pf == 16 && pos == 1) launch(k_rd_fused_256x128_persist<true, 16, 1>);
+        else if (pf == 16) launch(k_rd_fused_256x128_persist<true, 16, 0>);
+        else if (pos == 1) launch(k_rd_fused_256x128_persist<true, 8, 1>);
+        else launch(k_rd_fused_256x128_persist<true, 8, 0>);
+        return check_launch("rd_fused_persist");
+    }
     const int abl = tune_int("MMW_RD_ABLATE", 0);
     if (abl) {
         auto launch = [&](auto kern) {

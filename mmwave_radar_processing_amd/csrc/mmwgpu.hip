@@ -493,8 +493,10 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         // (also across calls: the events persist, so a back-to-back chain keeps the pipeline full)
         if (ctx->pipe_ang_used[buf]) MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[buf], 0));
         ctx->stream = ctx->q_rd;
+        ctx->active_cus = rd_cus;
         rc = range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C);
         ctx->stream = main_stream;
+        ctx->active_cus = 0;
         if (rc != MMW_OK) break;
         MMW_HIP(hipEventRecord(ctx->pipe_rd[buf], ctx->q_rd));
         MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_rd[buf], 0));
