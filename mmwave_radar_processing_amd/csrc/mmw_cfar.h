@@ -88,21 +88,64 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
     const long plane = (long)p.R * p.D;
     const double *X = p.X + (long)blockIdx.z * plane;
     const int r0 = blockIdx.y * CFAR_TR, c0 = blockIdx.x * CFAR_TC;
-    for (int t = threadIdx.x; t < TW * TH; t += CFAR_TR * CFAR_TC) {
-        const int rr = r0 - hr + t / TW, cc = c0 - hd + t % TW;
-        tile[t] = (rr >= 0 && rr < p.R && cc >= 0 && cc < p.D) ? X[(long)rr * p.D + cc] : 0.0;
+    {   // tile + halo, 2-D thread mapping (no per-element division)
+        const int ty = threadIdx.x / CFAR_TC, tx = threadIdx.x % CFAR_TC;
+        for (int y = ty; y < TH; y += CFAR_TR) {
+            const int rr = r0 - hr + y;
+            const bool row_ok = rr >= 0 && rr < p.R;
+            for (int x = tx; x < TW; x += CFAR_TC) {
+                const int cc = c0 - hd + x;
+                tile[y * TW + x] = (row_ok && cc >= 0 && cc < p.D) ? X[(long)rr * p.D + cc] : 0.0;
+            }
+        }
     }
     __syncthreads();
     const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
     if (p.kind == MMW_CFAR_CA) {
         // Every CUT of a column shares the per-row sums of its window rows: compute each (tile row, window
         // start column) pair once, in NumPy's pairwise order, then add Wr of them in row order per CUT.
-        for (int t = threadIdx.x; t < TH * CFAR_TC; t += CFAR_TR * CFAR_TC) {
-            const int row = t / CFAR_TC, col = t % CFAR_TC;
+        const int z0 = p.td, z1 = p.td + 2 * p.gd;        // guard columns of the window
+        for (int row = threadIdx.x / CFAR_TC; row < TH; row += CFAR_TR) {
+            const int col = threadIdx.x % CFAR_TC, t = row * CFAR_TC + col;
             const double *src = tile + row * TW + col;
-            rs_full[t] = np_pairwise<2>([&](int wd) { return src[wd]; }, 0, Wd);
-            rs_mask[t] = np_pairwise<2>(
-                [&](int wd) { return (wd >= p.td && wd <= p.td + 2 * p.gd) ? 0.0 : src[wd]; }, 0, Wd);
+            double sf, sm;
+            if (Wd > 128) {                               // rare: generic pairwise recursion
+                sf = np_pairwise<2>([&](int wd) { return src[wd]; }, 0, Wd);
+                sm = np_pairwise<2>([&](int wd) { return (wd >= z0 && wd <= z1) ? 0.0 : src[wd]; }, 0, Wd);
+            } else if (Wd < 8) {
+                sf = sm = 0.0;
+                for (int i = 0; i < Wd; ++i) {
+                    const double v = src[i];
+                    sf += v;
+                    sm += (i >= z0 && i <= z1) ? 0.0 : v;
+                }
+            } else {                                      // NumPy's 8-accumulator block, both sums in one sweep
+                double f[8], m[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double v = src[j];
+                    f[j] = v;
+                    m[j] = (j >= z0 && j <= z1) ? 0.0 : v;
+                }
+                int i = 8;
+                for (; i < Wd - (Wd % 8); i += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const double v = src[i + j];
+                        f[j] += v;
+                        m[j] += (i + j >= z0 && i + j <= z1) ? 0.0 : v;
+                    }
+                }
+                sf = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                sm = ((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]));
+                for (; i < Wd; ++i) {
+                    const double v = src[i];
+                    sf += v;
+                    sm += (i >= z0 && i <= z1) ? 0.0 : v;
+                }
+            }
+            rs_full[t] = sf;
+            rs_mask[t] = sm;
         }
         __syncthreads();
     }
