@@ -47,54 +47,64 @@ constexpr int bitrev_bits(int k, int bits) {
 }
 template <int N> constexpr int bitrev(int k) { return bitrev_bits(k, ilog2(N)); }
 
-// a * W_N^K with W_N = exp(-j 2 pi / N), K compile-time, N | 64.
-template <int N, int K, typename T> MMW_HD cplx<T> mul_w(cplx<T> a) {
+// Scalar-pair complex type: components live in independent registers, so compile-time twiddles become 32-bit
+// literals of v_fmaak/v_fmamk instead of register pairs.  Used where a kernel multiplies by MANY distinct
+// constants (k_angle64: the packed form needed 172 VGPRs for its 60-odd twiddle pairs, this form ~100).
+template <typename T> struct cpair {
+    T x, y;
+    MMW_HD cpair operator+(cpair b) const { return cpair{x + b.x, y + b.y}; }
+    MMW_HD cpair operator-(cpair b) const { return cpair{x - b.x, y - b.y}; }
+    MMW_HD cpair operator*(T s) const { return cpair{x * s, y * s}; }
+};
+
+// a * W_N^K with W_N = exp(-j 2 pi / N), K compile-time, N | 64.  CT = complex type (cplx<T> or cpair<T>).
+template <int N, int K, typename T, typename CT = cplx<T>> MMW_HD CT mul_w(CT a) {
     constexpr int k = ((K % N) + N) % N;
     static_assert(64 % N == 0 || N % 64 == 0, "compile-time twiddles cover N | 64");
     if constexpr (k == 0) {
         return a;
     } else if constexpr (4 * k == N) {
-        return cplx<T>{a.y, -a.x};
+        return CT{a.y, -a.x};
     } else if constexpr (2 * k == N) {
-        return cplx<T>{-a.x, -a.y};
+        return CT{-a.x, -a.y};
     } else if constexpr (4 * k == 3 * N) {
-        return cplx<T>{-a.y, a.x};
+        return CT{-a.y, a.x};
     } else if constexpr (8 * k == N) {
         constexpr T r = (T)0.70710678118654752440;
-        return cplx<T>{(a.x + a.y) * r, (a.y - a.x) * r};
+        return CT{(a.x + a.y) * r, (a.y - a.x) * r};
     } else if constexpr (8 * k == 3 * N) {
         constexpr T r = (T)0.70710678118654752440;
-        return cplx<T>{(a.y - a.x) * r, -(a.x + a.y) * r};
+        return CT{(a.y - a.x) * r, -(a.x + a.y) * r};
     } else {
         constexpr T c = (T)twc::C64[k * (64 / N)];
         constexpr T s = (T)twc::S64[k * (64 / N)];
-        return cplx<T>{a.x * c + a.y * s, a.y * c - a.x * s};
+        return CT{a.x * c + a.y * s, a.y * c - a.x * s};
     }
 }
 
-template <int N, int OFF, int TOT, typename T> struct DifStage {
+template <int N, int OFF, int TOT, typename T, typename CT> struct DifStage {
     template <int... K>
-    static MMW_HD void butterflies(cplx<T> (&a)[TOT], std::integer_sequence<int, K...>) {
+    static MMW_HD void butterflies(CT (&a)[TOT], std::integer_sequence<int, K...>) {
         constexpr int H = N / 2;
         ((void)([&] {
-            cplx<T> u = a[OFF + K], v = a[OFF + K + H];
+            CT u = a[OFF + K], v = a[OFF + K + H];
             a[OFF + K] = u + v;
-            a[OFF + K + H] = mul_w<N, K, T>(u - v);
+            a[OFF + K + H] = mul_w<N, K, T, CT>(u - v);
         }()), ...);
     }
-    static MMW_HD void run(cplx<T> (&a)[TOT]) {
+    static MMW_HD void run(CT (&a)[TOT]) {
         if constexpr (N >= 2) {
             butterflies(a, std::make_integer_sequence<int, N / 2>{});
-            DifStage<N / 2, OFF, TOT, T>::run(a);
-            DifStage<N / 2, OFF + N / 2, TOT, T>::run(a);
+            DifStage<N / 2, OFF, TOT, T, CT>::run(a);
+            DifStage<N / 2, OFF + N / 2, TOT, T, CT>::run(a);
         }
     }
 };
 
 // In-place N-point forward DFT of a[OFF..OFF+N) inside an array of TOT registers.
-template <int N, typename T, int TOT = N, int OFF = 0> struct RegFFT {
+template <int N, typename T, int TOT = N, int OFF = 0, typename CT = cplx<T>> struct RegFFT {
     static_assert(is_pow2(N) && N <= 64, "register FFT sizes are powers of two up to 64");
-    static MMW_HD void run(cplx<T> (&a)[TOT]) { DifStage<N, OFF, TOT, T>::run(a); }
+    static MMW_HD void run(CT (&a)[TOT]) { DifStage<N, OFF, TOT, T, CT>::run(a); }
 };
 
 // compile-time loop helper: f(std::integral_constant<int, I>) for I in [0, N)

@@ -18,49 +18,70 @@ struct AngleWin {
     float h[16];
 };
 
+__device__ __forceinline__ void opaque2(cpair<float> &a, cpair<float> &b) {
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y));
+}
+__device__ __forceinline__ void opaque2(cplx<float> &a, cplx<float> &b) {
+    asm volatile("" : "+v"(a), "+v"(b));
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// NT: streaming (non-temporal) stores for the write-once output cube
-template <int VIN, bool MAG, bool NT>
+#ifndef ANGLE_CT
+#define ANGLE_CT cplx<float>     // cpair<float> (scalar re/im) is selectable for experiments; packed is faster
+#endif
+// NT: streaming (non-temporal) stores for the write-once output cube.
+// ZE:  the window's end points are exactly zero (np.hanning): antennas 0 and V-1 contribute nothing, so their
+//      planes are neither loaded nor multiplied (identical results for finite input; -17 % loads, ~-10 % VALU).
+// The kernel is VALU-bound per CU (~44 GB/s/CU; it needs >= 128 CUs to saturate HBM).  hipcc CSEs the
+// x[n] +- rot(x[n+8]) terms across the eight unrolled k1 passes (172 VGPRs, 2 waves/SIMD); forcing the passes
+// apart (90 VGPRs, 5 waves/SIMD) or scalar re/im math (95 VGPRs) was 10-20 % SLOWER per CU -- measured.
+template <int VIN, bool MAG, bool NT, bool ZE>
 __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, void *__restrict__ out,
                                                   long pairs_per_frame, AngleWin win, int shift_off) {
+    typedef ANGLE_CT C;
     // grid.x covers pairs of adjacent bins of one frame; grid.y = frame
     const long pair = (long)blockIdx.x * 256 + threadIdx.x;
     if (pair >= pairs_per_frame) return;
     const long f = blockIdx.y;
     const f32x4 *src = rd + f * VIN * pairs_per_frame + pair;
-    cplx<float> xa[VIN], xb[VIN];
+    C xa[VIN], xb[VIN];
 #pragma unroll
     for (int v = 0; v < VIN; ++v) {
+        if (ZE && (v == 0 || v == VIN - 1)) {
+            xa[v] = C{0.f, 0.f};
+            xb[v] = C{0.f, 0.f};
+            continue;
+        }
         const f32x4 t = src[(long)v * pairs_per_frame];
         const float h = win.h[v];
-        xa[v] = cplx<float>{t.x, t.y} * h;
-        xb[v] = cplx<float>{t.z, t.w} * h;
+        xa[v] = C{t.x * h, t.y * h};
+        xb[v] = C{t.z * h, t.w * h};
     }
     static_for<8>([&](auto K1) {
         constexpr int k1 = decltype(K1)::value;
-        cplx<float> za[8], zb[8];
+        C za[8], zb[8];
         static_for<8>([&](auto N2) {
             constexpr int n2 = decltype(N2)::value;
-            cplx<float> ya = cplx<float>{0.f, 0.f}, yb = cplx<float>{0.f, 0.f};
+            C ya = C{0.f, 0.f}, yb = C{0.f, 0.f};
             if constexpr (n2 < VIN) {
                 ya = xa[n2];
                 yb = xb[n2];
             }
             if constexpr (n2 + 8 < VIN) {
-                ya = ya + mul_w<8, k1, float>(xa[n2 + 8]);
-                yb = yb + mul_w<8, k1, float>(xb[n2 + 8]);
+                ya = ya + mul_w<8, k1, float, C>(xa[n2 + 8]);
+                yb = yb + mul_w<8, k1, float, C>(xb[n2 + 8]);
             }
-            za[n2] = mul_w<64, n2 * k1, float>(ya);
-            zb[n2] = mul_w<64, n2 * k1, float>(yb);
+            za[n2] = mul_w<64, n2 * k1, float, C>(ya);
+            zb[n2] = mul_w<64, n2 * k1, float, C>(yb);
         });
-        RegFFT<8, float>::run(za);
-        RegFFT<8, float>::run(zb);
+        RegFFT<8, float, 8, 0, C>::run(za);
+        RegFFT<8, float, 8, 0, C>::run(zb);
         static_for<8>([&](auto K2) {
             constexpr int k2 = decltype(K2)::value;
             const int a = (k1 + 8 * k2 + shift_off) & 63;   // fftshift over the angle axis (shift_off = 32)
-            const cplx<float> va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
+            const C va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
             const long o = (f * 64 + a) * pairs_per_frame + pair;
             if constexpr (MAG) {
                 const f32x2 m = {hypotf(va.x, va.y), hypotf(vb.x, vb.y)};
@@ -82,13 +103,21 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     const long pairs = bins / 2;
     dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)F);
     const bool nt = tune_int("MMW_ANGLE_NT", 1) != 0;
-#define MMW_ANGLE_LAUNCH(MAGV, NTV) \
-    hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, \
+    const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f && tune_int("MMW_ANGLE_ZE", 1) != 0;
+#define MMW_ANGLE_LAUNCH(MAGV, NTV, ZEV) \
+    hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV, ZEV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, \
                        shift ? 32 : 0)
-    if (mag && nt) MMW_ANGLE_LAUNCH(true, true);
-    else if (mag) MMW_ANGLE_LAUNCH(true, false);
-    else if (nt) MMW_ANGLE_LAUNCH(false, true);
-    else MMW_ANGLE_LAUNCH(false, false);
+    if (ze) {
+        if (mag && nt) MMW_ANGLE_LAUNCH(true, true, true);
+        else if (mag) MMW_ANGLE_LAUNCH(true, false, true);
+        else if (nt) MMW_ANGLE_LAUNCH(false, true, true);
+        else MMW_ANGLE_LAUNCH(false, false, true);
+    } else {
+        if (mag && nt) MMW_ANGLE_LAUNCH(true, true, false);
+        else if (mag) MMW_ANGLE_LAUNCH(true, false, false);
+        else if (nt) MMW_ANGLE_LAUNCH(false, true, false);
+        else MMW_ANGLE_LAUNCH(false, false, false);
+    }
 #undef MMW_ANGLE_LAUNCH
     return check_launch("angle64");
 }

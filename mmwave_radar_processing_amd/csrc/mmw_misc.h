@@ -105,6 +105,19 @@ __global__ __launch_bounds__(256) void k_diag_membw(const diag_f4 *src, diag_f4 
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     diag_f4 acc = {0.f, 0.f, 0.f, 0.f};
     const diag_f4 k = {1.f, 2.f, 3.f, 4.f};
+    if (mode == 6 || mode == 7) {
+        // the angle kernel's store pattern without its arithmetic: every thread owns 16 B of a 256-KiB "plane"
+        // and writes the same offset of 64 consecutive planes (mode 7: 4 planes per pass, 16 passes)
+        const size_t plane_vec = 16384, frame_vec = 64 * plane_vec;
+        const size_t frames = n_vec / frame_vec;
+        for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < frames * plane_vec; w += stride) {
+            const size_t f = w / plane_vec, o = w % plane_vec;
+            diag_f4 *base = dst + f * frame_vec + o;
+#pragma unroll 8
+            for (int a = 0; a < 64; ++a) __builtin_nontemporal_store(k, base + (size_t)a * plane_vec);
+        }
+        return;
+    }
     if (mode == 4 || mode == 5) {
         for (size_t i = i0; i + 3 * stride < n_vec; i += 4 * stride) {
             if (mode == 4) {

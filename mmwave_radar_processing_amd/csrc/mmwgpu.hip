@@ -121,7 +121,14 @@ int mmw_ctx_create(mmw_ctx **out, int device) {
     hipDeviceProp_t prop;
     MMW_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
-    MMW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const int ctx_cus = env_int("MMW_CTX_CUS", 0);   // experiment: restrict the context stream to the first n CUs
+    if (ctx_cus > 0 && ctx_cus < c->num_cu) {
+        std::vector<uint32_t> m((c->num_cu + 31) / 32, 0u);
+        for (int i = 0; i < ctx_cus; ++i) m[i / 32] |= 1u << (i % 32);
+        MMW_HIP(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m.size(), m.data()));
+    } else {
+        MMW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     MMW_HIP(hipEventCreate(&c->t0));
     MMW_HIP(hipEventCreate(&c->t1));
     *out = c;
@@ -672,7 +679,7 @@ int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
 }
 
 int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks) {
-    MMW_REQUIRE(ctx && d_src && d_dst && bytes % 16 == 0 && mode >= 0 && mode <= 5, "bad argument");
+    MMW_REQUIRE(ctx && d_src && d_dst && bytes % 16 == 0 && mode >= 0 && mode <= 7, "bad argument");
     MMW_JOIN(ctx);
     if (blocks <= 0) blocks = ctx->num_cu * 8;
     hipLaunchKernelGGL(k_diag_membw, dim3(blocks), dim3(256), 0, ctx->stream, (const diag_f4 *)d_src,

@@ -53,6 +53,7 @@ def main():
     half = (nbytes // 32) * 16
     run("diag_copy", lambda: _lib.check(L.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr + half, half, 0, 0)), 2 * half)
     run("diag_write", lambda: _lib.check(L.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr, nbytes, 1, 0)), nbytes)
+    run("diag_write_angle_pattern", lambda: _lib.check(L.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr, nbytes, 6, 0)), nbytes)
     run("diag_read", lambda: _lib.check(L.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr, nbytes, 2, 0)), nbytes)
     run("rd", lambda: _lib.check(L.mmw_range_doppler(ctx.handle, d_in.ptr, d_rd.ptr, None, F, V, S, C)), F * 2 * cube_b)
     run("angle", lambda: _lib.check(L.mmw_angle_fft(ctx.handle, d_rd.ptr, d_out.ptr, F, V, S, C, A, 0)), F * (cube_b + out_b))
