@@ -561,3 +561,39 @@ def test_doppler_azimuth_processor(golden):
         assert rel_err(p3.process(c3, rx_antennas=[0, 3, 4, 7], range_window=[2.0, 9.0], shift_angle=shift), ref) <= SPEC_TOL
     with pytest.raises(NotImplementedError):
         p3.process(c3, use_precise_fft=True)
+
+
+def test_processor_protocol_state_and_registries():
+    """Plugin-host contract (reference: processors/_processor.py:6-64, view_controller.py:56-111)."""
+    cm = make_cm(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(2, (12, 32, 16))
+    params = {"cfar_type": "os_cfar_2d", "cfar_params": {"num_train": [2, 2], "num_guard": [1, 1], "rho": 0.7, "alpha": 3}}
+    det = RangeDopplerDetector2D(cm, **params)
+    dets = det.process(adc_cube=cube, **params)                 # ctor params re-passed to process()
+    mag = np.abs(O.range_doppler(cube)[0])
+    ref = O.os_cfar_2d(mag, (2, 2), (1, 1), 0.7, 3)[2]
+    np.testing.assert_array_equal(dets, np.array(ref, dtype=np.int64).reshape(-1, 2))
+    for key in ("range_bins", "vel_bins", "dets", "rng_dop_resp", "rng_dop_resp_raw"):
+        assert isinstance(getattr(det, key), np.ndarray)
+    assert det.detector.thresholds.shape == (32, 16) and det.detector.detections.dtype == bool
+    det.update_history(estimated=np.array([1.0, 2.0]), ground_truth=np.array([1.5]))
+    assert len(det.history_estimated) == 1 and len(det.history_gt) == 1
+    det.reset()
+    assert det.dets is None and det.rng_dop_resp is None and det.history_estimated == []
+    r, v, ri, vi = det._map_detections_to_bins(np.empty((0, 2), dtype=int))
+    assert r.size == 0 and vi.size == 0
+    r, v, ri, vi = det._map_detections_to_bins(np.array([[3, 5], [7, 1]]))
+    np.testing.assert_array_equal(r, det.range_bins[[3, 7]])
+    np.testing.assert_array_equal(v, det.vel_bins[[5, 1]])
+    reg = get_range_doppler_detector_registry()
+    assert set(reg) == {"range_doppler_detector_2d", "range_doppler_detector_sequential"}
+    # a foreign magnitude map goes through the detector's own host path
+    foreign = np.abs(np.random.default_rng(0).standard_normal((32, 16))) * 10
+    out = det._detect(cube, foreign)
+    np.testing.assert_array_equal(out, np.array(O.os_cfar_2d(foreign, (2, 2), (1, 1), 0.7, 3)[2], dtype=np.int64).reshape(-1, 2))
+    # PointCloudGenerator with an empty frame
+    pcg = PointCloudGenerator(cm, az_antenna_idxs=[0, 1, 2, 3], el_antenna_idxs=[],
+                              detector_params={"cfar_type": "ca_cfar_2d", "cfar_params": CFAR})
+    pc = pcg.process(np.zeros((12, 32, 16), dtype=complex))
+    assert pc.shape == (0, 4)
+    pcg.reset()
