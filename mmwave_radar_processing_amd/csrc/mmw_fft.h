@@ -47,17 +47,7 @@ constexpr int bitrev_bits(int k, int bits) {
 }
 template <int N> constexpr int bitrev(int k) { return bitrev_bits(k, ilog2(N)); }
 
-// Scalar-pair complex type: components live in independent registers, so compile-time twiddles become 32-bit
-// literals of v_fmaak/v_fmamk instead of register pairs.  Used where a kernel multiplies by MANY distinct
-// constants (k_angle64: the packed form needed 172 VGPRs for its 60-odd twiddle pairs, this form ~100).
-template <typename T> struct cpair {
-    T x, y;
-    MMW_HD cpair operator+(cpair b) const { return cpair{x + b.x, y + b.y}; }
-    MMW_HD cpair operator-(cpair b) const { return cpair{x - b.x, y - b.y}; }
-    MMW_HD cpair operator*(T s) const { return cpair{x * s, y * s}; }
-};
-
-// a * W_N^K with W_N = exp(-j 2 pi / N), K compile-time, N | 64.  CT = complex type (cplx<T> or cpair<T>).
+// a * W_N^K with W_N = exp(-j 2 pi / N), K compile-time, N | 64.  CT = complex type (any {x, y} type with + and -).
 template <int N, int K, typename T, typename CT = cplx<T>> MMW_HD CT mul_w(CT a) {
     constexpr int k = ((K % N) + N) % N;
     static_assert(64 % N == 0 || N % 64 == 0, "compile-time twiddles cover N | 64");

@@ -18,19 +18,10 @@ struct AngleWin {
     float h[16];
 };
 
-__device__ __forceinline__ void opaque2(cpair<float> &a, cpair<float> &b) {
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y));
-}
-__device__ __forceinline__ void opaque2(cplx<float> &a, cplx<float> &b) {
-    asm volatile("" : "+v"(a), "+v"(b));
-}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef ANGLE_CT
-#define ANGLE_CT cplx<float>     // cpair<float> (scalar re/im) is selectable for experiments; packed is faster
-#endif
 // NT: streaming (non-temporal) stores for the write-once output cube.
 // ZE:  the window's end points are exactly zero (np.hanning): antennas 0 and V-1 contribute nothing, so their
 //      planes are neither loaded nor multiplied (identical results for finite input; -17 % loads, ~-10 % VALU).
@@ -40,7 +31,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int VIN, bool MAG, bool NT, bool ZE>
 __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, void *__restrict__ out,
                                                   long pairs_per_frame, AngleWin win, int shift_off) {
-    typedef ANGLE_CT C;
+    typedef cplx<float> C;
     // grid.x covers pairs of adjacent bins of one frame; grid.y = frame
     const long pair = (long)blockIdx.x * 256 + threadIdx.x;
     if (pair >= pairs_per_frame) return;
@@ -236,8 +227,9 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
 
 // Persistent variant: each workgroup walks planes blockIdx.x, +gridDim.x, ... and issues the NEXT plane's 16 row
 // loads as soon as the y registers die (after the second X1 write), so the load latency hides under the rest of
-// the current plane.  PF = rows prefetched that early (16 = all, 8 = half; the rest load at the loop top).
-template <bool NTIN, int PF, int POS = 0>   // POS 0: prefetch after the 2nd X1 write, 1: after the 2nd X3 write
+// the current plane.  PF = rows prefetched that early; the rest load at the loop top.  PF = 8 fits the register
+// budget (126 VGPRs, no scratch) and is 12 % faster than one plane per workgroup; PF = 16 spilled and was slower.
+template <bool NTIN, int PF>
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
@@ -294,7 +286,7 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
                 const cplx<float> a = cmul(y0[br], tw), b = cmul(y1[br], tw);
                 *reinterpret_cast<f32x4 *>(&lds[(k1l * 16 + w) * 128 + 2 * l]) = f32x4{a.x, a.y, b.x, b.y};
             });
-            if constexpr (h == 1 && POS == 0) {     // y0 / y1 are dead from here on: their registers take the next plane
+            if constexpr (h == 1) {     // y0 / y1 are dead from here on: their registers take the next plane
                 const int next = plane + gridDim.x;
                 if (next < planes) issue_loads(next, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
             }
@@ -322,10 +314,6 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
                 constexpr int k1d = decltype(K)::value;
                 lds[rl * RD_PITCH + k1d * 9 + j8] = cmul(d[bitrev<16>(k1d)], tw128_l[j8 * k1d]);
             });
-            if constexpr (h == 1 && POS == 1) {     // only e[8] is live below: room for all 16 rows of the next plane
-                const int next = plane + gridDim.x;
-                if (next < planes) issue_loads(next, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
-            }
             __syncthreads();
             // ---- Doppler pass 2 + store (two (row, k1d) units per lane)
 #pragma unroll
@@ -369,7 +357,7 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
     // Standalone launches use the persistent variant with 8 rows prefetched (+12 %); inside the overlapped
     // chain the one-plane-per-workgroup kernel is faster (measured), so the chain sets active_cus and gets it.
     const int pf = tune_int("MMW_RD_PERSIST", -1) >= 0 ? tune_int("MMW_RD_PERSIST", -1) : (ctx->active_cus > 0 ? 0 : 8);
-    if (pf == 8 || pf == 16) {
+    if (pf == 8) {
         int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu) * tune_int("MMW_RD_PERSIST_WGS_PER_CU", 1);
         if (grid > planes) grid = planes;
         auto launch = [&](auto kern) {
@@ -378,11 +366,7 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
                                (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
                                (const cplx<float> *)t256, (const cplx<float> *)t128);
         };
-        const int pos = tune_int("MMW_RD_PERSIST_POS", 0);
-        if (pf == 16 && pos == 1) launch(k_rd_fused_256x128_persist<true, 16, 1>);
-        else if (pf == 16) launch(k_rd_fused_256x128_persist<true, 16, 0>);
-        else if (pos == 1) launch(k_rd_fused_256x128_persist<true, 8, 1>);
-        else launch(k_rd_fused_256x128_persist<true, 8, 0>);
+        launch(k_rd_fused_256x128_persist<true, 8>);
         return check_launch("rd_fused_persist");
     }
     const int abl = tune_int("MMW_RD_ABLATE", 0);

@@ -93,6 +93,26 @@ def main():
                                       ants, n_ant, A, 1))
     run("detect_pipeline_config3", detect_all, F * (2 * cube_b + S * C * 4))
     res["mean_detections_per_frame"] = float(d_cnt.download((F,), np.int32).mean())
+    # ---- beamformers (BASELINE config 4 shapes): complex GEMM on f32 MFMA, MVDR on f64 MFMA
+    Sb, Eb, Tb = 256, 256, 64
+    rng = np.random.default_rng(1)
+    d_X = ctx.alloc(Sb * Eb * 8); d_X.upload((rng.standard_normal((Sb, Eb)) + 1j * rng.standard_normal((Sb, Eb))).astype(np.complex64))
+    d_P = ctx.alloc(3 * Eb * 8); d_P.upload(rng.uniform(-0.05, 0.05, (3, Eb)))
+    az = np.linspace(-1.2, 1.2, Tb)
+    dirs = np.ascontiguousarray(np.stack([np.cos(az), np.sin(az), np.zeros(Tb)]))
+    d_D = ctx.alloc(dirs.nbytes); d_D.upload(dirs)
+    d_Y = ctx.alloc(Sb * Tb * 8)
+    run("bartlett_256x256x64", lambda: _lib.check(L.mmw_bartlett(ctx.handle, d_X.ptr, d_P.ptr, d_D.ptr, d_Y.ptr, Sb, Eb, Tb,
+                                                                 299792458.0 / 77e9)), 8.0 * Sb * Eb * Tb)   # "GBs" = GFLOP/s here
+    Vc, Rc, Kc, Tc = 12, 512, 128, 181
+    d_Xc = ctx.alloc(Vc * Rc * Kc * 8)
+    d_Xc.upload((rng.standard_normal((Vc, Rc, Kc)) + 1j * rng.standard_normal((Vc, Rc, Kc))).astype(np.complex64))
+    th = np.linspace(-1.3, 1.3, Tc)
+    import ctypes as ct
+    d_Pc = ctx.alloc(Rc * Tc * 4)
+    run("capon_12x512x128_T181", lambda: _lib.check(L.mmw_capon(ctx.handle, d_Xc.ptr, th.ctypes.data_as(ct.POINTER(ct.c_double)),
+                                                                d_Pc.ptr, Vc, Rc, Kc, Tc, 1e-3)),
+        8.0 * Vc * Vc * Kc * Rc + 8.0 * Tc * Vc * Vc * Rc)     # covariance + R^-1 A flops -> GFLOP/s
     print(json.dumps(res))
 
 
