@@ -72,6 +72,7 @@ struct mmw_ctx {
     int q_rd_cus = 0;
     hipEvent_t pipe_rd[2] = {nullptr, nullptr}, pipe_ang[2] = {nullptr, nullptr}, pipe_begin = nullptr;
     bool pipe_ang_used[2] = {false, false};
+    bool rd_attr_set = false;    // hipFuncSetAttribute(max dynamic LDS) done for this context's device
     bool pipe_pending = false;   // chain work in flight on q_rd/q_ang that the context stream has not joined yet
     hipEvent_t t0 = nullptr, t1 = nullptr;      // mmw_timer_*
     bool profiling = false;                     // per-family kernel timing (mmw_profile_*)
@@ -138,6 +139,7 @@ template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **
 // chain does not do this itself so that back-to-back mmw_chain3d calls keep the RD || angle pipeline full;
 // every other entry point that touches the context stream calls it first.
 inline int join_pipe(mmw_ctx *ctx) {
+    MMW_HIP(hipSetDevice(ctx->device));     // several contexts (devices) may live in one process
     if (!ctx->pipe_pending) return MMW_OK;
     for (int i = 0; i < 2; ++i)
         if (ctx->pipe_ang_used[i]) MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_ang[i], 0));

@@ -345,13 +345,12 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
     MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_C, &hc));
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 256, &t256));
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 128, &t128));
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->rd_attr_set) {
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_fused_256x128<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_fused_256x128<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
-        attr_set = true;
+        ctx->rd_attr_set = true;
     }
     const int blocks = planes;   // one plane per workgroup: a persistent plane loop made hipcc hoist and spill
     // Standalone launches use the persistent variant with 8 rows prefetched (+12 %); inside the overlapped

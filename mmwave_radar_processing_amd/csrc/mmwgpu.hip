@@ -434,6 +434,7 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
     if (n_frames == 0) return MMW_OK;
+    MMW_HIP(hipSetDevice(ctx->device));
     const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
     const size_t out_frame_bytes = (size_t)A * S * C * (magnitude ? sizeof(float) : sizeof(cplx<float>));
     // Two schedules (DESIGN.md "chain schedule").
