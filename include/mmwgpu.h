@@ -108,6 +108,11 @@ int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames,
                   int V, int S, int C, int A, int flags);
 int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames,
                 int V, int S, int C, int A, int flags);
+/* mmw_dbs_gather: d_out[F][S][n_out] float32 = d_mag[F][h_ang_idx[i]][s][h_vel_idx[i]] -- the Doppler-beam-
+ *   sharpening column pick of perform_dbs_sharpen (processors/range_angle_resp_dbs_enhanced.py:216-263); the
+ *   nearest-bin index tables are computed by the host from its angle / velocity bin tables. */
+int mmw_dbs_gather(mmw_ctx *ctx, const float *d_mag, const int *h_ang_idx, const int *h_vel_idx, float *d_out,
+                   int n_frames, int A, int S, int C, int n_out);
 /* mmw_mean_over_range: d_out[F][C][A] float32 = mean over range rows [s_lo, s_hi) of d_mag[F][A][S][C];
  *   with mmw_chain3d(flags | MAGNITUDE) this is DopplerAzimuthProcessor.process, coarse path
  *   (processors/doppler_azimuth_resp.py:84-128,296-334,419-491): range FFT -> range-window mask ->

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "mmw_range_doppler_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_angle_fft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_chain3d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "mmw_dbs_gather": [_vp, _vp, _ip, _ip, _vp, _i, _i, _i, _i, _i],
     "mmw_mean_over_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_range_profile": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_profile_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],

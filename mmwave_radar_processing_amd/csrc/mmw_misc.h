@@ -153,6 +153,18 @@ __global__ __launch_bounds__(256) void k_mean_over_range(const float *mag, float
     out[(f * C + c) * A + a] = acc / (float)(s_hi - s_lo);
 }
 
+// out[f][s][i] = mag[f][ang_idx[i]][s][vel_idx[i]]   (perform_dbs_sharpen,
+// processors/range_angle_resp_dbs_enhanced.py:216-263: one [angle bin, :, Doppler bin] column per output angle)
+__global__ __launch_bounds__(256) void k_dbs_gather(const float *mag, const int *ang_idx, const int *vel_idx, float *out,
+                                                     int F, int A, int S, int C, int n_out) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)F * S * n_out) return;
+    const int i = (int)(gid % n_out);
+    const int s = (int)((gid / n_out) % S);
+    const long f = gid / ((long)n_out * S);
+    out[gid] = mag[((f * A + ang_idx[i]) * S + s) * (long)C + vel_idx[i]];
+}
+
 constexpr int MAX_ANT = 32;
 struct AntList {
     int n;

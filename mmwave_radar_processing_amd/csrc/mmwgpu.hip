@@ -389,6 +389,26 @@ int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int
     return angle_fft_impl(ctx, d_rd, d_out, n_frames, V, S, C, A, flags);
 }
 
+int mmw_dbs_gather(mmw_ctx *ctx, const float *d_mag, const int *h_ang_idx, const int *h_vel_idx, float *d_out,
+                   int n_frames, int A, int S, int C, int n_out) {
+    MMW_REQUIRE(ctx && d_mag && h_ang_idx && h_vel_idx && d_out, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && A > 0 && S > 0 && C > 0 && n_out > 0, "bad shape");
+    for (int i = 0; i < n_out; ++i)
+        MMW_REQUIRE(h_ang_idx[i] >= 0 && h_ang_idx[i] < A && h_vel_idx[i] >= 0 && h_vel_idx[i] < C,
+                    "gather index %d out of range", i);
+    if (n_frames == 0) return MMW_OK;
+    MMW_TRY(ensure_scratch(ctx, (size_t)2 * n_out * sizeof(int)));
+    int *d_idx = (int *)ctx->scratch;
+    MMW_HIP(hipMemcpyAsync(d_idx, h_ang_idx, (size_t)n_out * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MMW_HIP(hipMemcpyAsync(d_idx + n_out, h_vel_idx, (size_t)n_out * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MMW_HIP(hipStreamSynchronize(ctx->stream));     // the index arrays are caller-owned host memory
+    const long total = (long)n_frames * S * n_out;
+    hipLaunchKernelGGL(k_dbs_gather, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_mag, d_idx,
+                       d_idx + n_out, d_out, n_frames, A, S, C, n_out);
+    return check_launch("dbs_gather");
+}
+
 int mmw_mean_over_range(mmw_ctx *ctx, const float *d_mag, float *d_out, int n_frames, int A, int S, int C,
                         int s_lo, int s_hi) {
     MMW_REQUIRE(ctx && d_mag && d_out, "null argument");

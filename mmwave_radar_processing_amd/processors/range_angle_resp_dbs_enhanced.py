@@ -67,14 +67,18 @@ class RangeAngleProcessorDBSEnhanced(RangeAngleProcessor):
         r = np.array([np.cos(angle), np.sin(angle), 0])
         return -1 * np.dot((r / np.linalg.norm(r)), ego_vel)
 
-    def perform_dbs_sharpen(self, velocity_ned: np.ndarray, angle_rng_dop_resp_mag: np.ndarray) -> np.ndarray:
-        """Pick, per output angle, the [nearest angle bin, :, nearest Doppler bin] column (reference :216-263).
-
-        Host-side gather over argmin tables: ``num_angle_bins_dbs`` columns of length S."""
+    def _dbs_indices(self, velocity_ned):
+        """Nearest (angle bin, Doppler bin) per sharpened output angle -- host argmin over the bin tables (:240-257)."""
         ang = self.angle_bins_dbs_enhanced
         dop = np.array([self.get_dop_vel(a, velocity_ned) for a in ang])
         vel_bin = np.argmin(np.abs(self.vel_bins[None, :] - dop[:, None]), axis=1)
         ang_bin = np.argmin(np.abs(self.angle_bins_no_dbs_enhancement[None, :] - ang[:, None]), axis=1)
+        return ang_bin, vel_bin
+
+    def perform_dbs_sharpen(self, velocity_ned: np.ndarray, angle_rng_dop_resp_mag: np.ndarray) -> np.ndarray:
+        """Pick, per output angle, the [nearest angle bin, :, nearest Doppler bin] column of a HOST magnitude cube
+        (reference :216-263); ``process_dbs_enhanced`` does the same pick on the device-resident cube."""
+        ang_bin, vel_bin = self._dbs_indices(velocity_ned)
         picked = np.asarray(angle_rng_dop_resp_mag)[ang_bin, :, vel_bin]        # (A', S)
         return np.ascontiguousarray(picked.T)
 
@@ -84,9 +88,15 @@ class RangeAngleProcessorDBSEnhanced(RangeAngleProcessor):
         cube = np.asarray(adc_cube)
         if rx.size > 0:
             cube = cube[rx, :, :]
-        d_out, shape = self._chain3d_device(cube, magnitude=True)       # |.| on the GPU (:293)
-        mag = d_out.download(shape, np.float32).astype(np.float64)
-        return self.perform_dbs_sharpen(velocity_ned=velocity_ned, angle_rng_dop_resp_mag=mag)
+        d_mag, (A, S, C) = self._chain3d_device(cube, magnitude=True)       # |.| on the GPU (:293)
+        ang_bin, vel_bin = self._dbs_indices(velocity_ned)
+        ctx, bufs = self._device()
+        n_out = len(ang_bin)
+        d_out = bufs.get("dbs_out", S * n_out * 4)
+        a_arr, _ = _lib.int_array(ang_bin)
+        v_arr, _ = _lib.int_array(vel_bin)
+        _lib.check(ctx.lib.mmw_dbs_gather(ctx.handle, d_mag.ptr, a_arr, v_arr, d_out.ptr, 1, A, S, C, n_out))
+        return d_out.download((S, n_out), np.float32).astype(np.float64)
 
     def process(self, adc_cube, velocity_ned, rx_antennas=np.array([]), chirp_idx: int = 0, **kwargs) -> np.ndarray:
         if np.linalg.norm(np.asarray(velocity_ned)[0:2]) < self.min_vel_dbs:
