@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Range-Doppler and 3-D chain timings for cube shapes other than the headline one (generic kernels)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmwave_radar_processing_amd import _lib  # noqa: E402
+
+ctx = _lib.Context(0)
+L = ctx.lib
+out = {}
+for (V, S, C) in ((12, 64, 64), (12, 128, 128), (12, 256, 128), (12, 512, 64), (12, 256, 256), (12, 512, 128),
+                  (12, 63, 70), (12, 100, 100), (8, 128, 64)):
+    A = 64
+    frames = max(8, min(2048, (1 << 30) // (V * S * C * 8 * 8)))
+    n = V * S * C * 8
+    d_in, d_rd, d_out = ctx.alloc(frames * n), ctx.alloc(frames * n), ctx.alloc(frames * A * S * C * 8)
+    _lib.check(L.mmw_synth_cubes(ctx.handle, d_in.ptr, frames, V, S, C, 5, 8, 30.0))
+    res = {}
+    for name, fn, moved in (
+            ("rd", lambda: _lib.check(L.mmw_range_doppler(ctx.handle, d_in.ptr, d_rd.ptr, None, frames, V, S, C)), 2 * n),
+            ("chain3d", lambda: _lib.check(L.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, frames, V, S, C, A, 0)),
+             n + A * S * C * 8)):
+        fn(); ctx.sync(); ctx.timer_start()
+        for _ in range(5):
+            fn()
+        ms = ctx.timer_stop() / 5
+        res[name] = {"us_per_frame": round(1e3 * ms / frames, 3), "GBs": round(frames * moved / ms / 1e6)}
+    out[f"{V}x{S}x{C}"] = dict(frames=frames, **res)
+    for b in (d_in, d_rd, d_out):
+        b.free()
+print(json.dumps(out, indent=1))
