@@ -74,9 +74,11 @@ struct Cfar2dArgs {
     int tr, td, gr, gd;
     double scale;
     int k_rank;
+    int os_fast;   // OS only: LDS holds the 15 coarse integral images (tile <= 1024 cells)
 };
 
 constexpr int CFAR_TR = 16, CFAR_TC = 16;
+constexpr int OS_COARSE = 16;   // coarse rank buckets; the bucket width npad/16 <= 64 fits one 64-bit mask
 
 __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
     const int npad = 1 << os_bits;
     unsigned short *os_pos = reinterpret_cast<unsigned short *>(os_key + npad);
     unsigned short *os_rank = os_pos + npad;
+    unsigned short *os_integ = os_rank + ((TW * TH + 1) & ~1);
     if (p.kind == MMW_CFAR_OS) {
         const int NT = CFAR_TR * CFAR_TC;
         for (int t = threadIdx.x; t < npad; t += NT) {
@@ -181,6 +184,31 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
         for (int t = threadIdx.x; t < npad; t += NT)
             if (os_pos[t] < TW * TH) os_rank[os_pos[t]] = (unsigned short)t;
         __syncthreads();
+        if (p.os_fast) {
+            // integral images of [rank < j * npad/16], j = 1..15, with a zero border row / column
+            const int IW = TW + 1, IH = TH + 1, isz = IW * IH, bucket = npad / OS_COARSE;
+            for (int t = threadIdx.x; t < (OS_COARSE - 1) * IH; t += NT) {        // row prefix sums
+                const int j = t / IH + 1, y = t % IH;
+                unsigned short *row = os_integ + (j - 1) * isz + y * IW;
+                row[0] = 0;
+                unsigned short run = 0;
+                for (int x = 1; x < IW; ++x) {
+                    if (y > 0) run += os_rank[(y - 1) * TW + (x - 1)] < j * bucket ? 1 : 0;
+                    row[x] = run;
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < (OS_COARSE - 1) * TW; t += NT) {        // column prefix sums
+                const int j = t / TW + 1, x = t % TW + 1;
+                unsigned short *col = os_integ + (j - 1) * isz + x;
+                unsigned short run = 0;
+                for (int y = 1; y < IH; ++y) {
+                    run += col[y * IW];
+                    col[y * IW] = run;
+                }
+            }
+            __syncthreads();
+        }
     }
     const int lr = threadIdx.x / CFAR_TC, lc = threadIdx.x % CFAR_TC;
     const int r = r0 + lr, c = c0 + lc;
@@ -199,8 +227,54 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
             est = sum / (double)ntrain;
         } else {
             // OS: the k-th smallest training cell == the training cell with the k-th smallest tile rank.
-            // Bisection over the log2(npad) rank bits instead of 64 key bits, on 2-byte LDS reads.
             int prefix = 0;
+            if (p.os_fast) {
+                // (1) coarse bucket from the integral images: 8 two-byte reads per probe, 4 probes
+                const int IW = TW + 1, isz = IW * (TH + 1), bucket = npad / OS_COARSE;
+                const int wy0 = lr, wx0 = lc, wy1 = lr + Wr, wx1 = lc + Wd;                       // window, exclusive end
+                const int gy0 = lr + p.tr, gx0 = lc + p.td, gy1 = gy0 + 2 * p.gr + 1, gx1 = gx0 + 2 * p.gd + 1;
+                auto count_below = [&](int j) {
+                    const unsigned short *I = os_integ + (j - 1) * isz;
+                    const int win = I[wy1 * IW + wx1] - I[wy0 * IW + wx1] - I[wy1 * IW + wx0] + I[wy0 * IW + wx0];
+                    const int grd = I[gy1 * IW + gx1] - I[gy0 * IW + gx1] - I[gy1 * IW + gx0] + I[gy0 * IW + gx0];
+                    return win - grd;
+                };
+                int j = 0, below = 0;
+                for (int step = OS_COARSE / 2; step >= 1; step >>= 1) {
+                    const int c = count_below(j + step);
+                    if (c < p.k_rank) {
+                        j += step;
+                        below = c;
+                    }
+                }
+                // (2) the answer is the (k - below)-th smallest rank inside [j*bucket, (j+1)*bucket): one sweep of
+                //     the window sets a bit per training cell of that bucket, then select the q-th set bit
+                const int base = j * bucket;
+                unsigned long long bits = 0;
+                for (int wr = 0; wr < Wr; ++wr) {
+                    const unsigned short *rrow = os_rank + (lr + wr) * TW + lc;
+                    const bool guard_row = wr >= p.tr && wr <= p.tr + 2 * p.gr;
+                    for (int wd = 0; wd < Wd; ++wd) {
+                        if (guard_row && wd >= p.td && wd <= p.td + 2 * p.gd) continue;
+                        const unsigned d = (unsigned)rrow[wd] - (unsigned)base;
+                        if (d < (unsigned)bucket) bits |= 1ull << d;
+                    }
+                }
+                int q = p.k_rank - below, pos = 0;
+                for (int half = 32; half >= 1; half >>= 1) {
+                    const unsigned long long lowmask = (1ull << half) - 1;
+                    const int c = __popcll(bits & lowmask);
+                    if (q > c) {
+                        q -= c;
+                        bits >>= half;
+                        pos += half;
+                    } else {
+                        bits &= lowmask;
+                    }
+                }
+                prefix = base + pos;
+            } else {
+            // Bisection over the log2(npad) rank bits instead of 64 key bits, on 2-byte LDS reads.
             for (int bit = os_bits - 1; bit >= 0; --bit) {
                 const int cand = prefix | (1 << bit);
                 int below = 0;
@@ -215,6 +289,7 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
                     }
                 }
                 if (below < p.k_rank) prefix = cand;
+            }
             }
             est = f64_unkey(os_key[prefix]);
         }

@@ -628,13 +628,17 @@ int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, 
     size_t npad = 1;
     while (npad < n_tile) npad <<= 1;
     const size_t aux_ca = 2 * (size_t)(CFAR_TR + 2 * hr) * CFAR_TC * sizeof(double);     // row-sum tables
-    const size_t aux_os = npad * 8 + npad * 2 + n_tile * 2 + 16;                          // keys, positions, ranks
+    size_t aux_os = npad * 8 + npad * 2 + ((n_tile + 1) & ~(size_t)1) * 2 + 16;         // keys, positions, ranks
+    const size_t integ = (size_t)(OS_COARSE - 1) * (CFAR_TR + 2 * hr + 1) * (CFAR_TC + 2 * hd + 1) * 2;
+    const bool os_fast = kind == MMW_CFAR_OS && npad <= 1024 && n_tile * sizeof(double) + aux_os + integ <= 64 * 1024 &&
+                         !env_int("MMW_OS_SLOW", 0);
+    if (os_fast) aux_os += integ;
     const size_t lds = n_tile * sizeof(double) + (kind == MMW_CFAR_OS ? aux_os : aux_ca);
     MMW_REQUIRE(kind != MMW_CFAR_OS || npad <= 32768, "OS-CFAR window too large");
     if (lds > 64 * 1024) return set_error(MMW_ERR_UNSUPPORTED, "CFAR window %dx%d too large for the LDS tile", 2 * hr + 1, 2 * hd + 1);
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "cfar");
-    Cfar2dArgs a{d_X, d_thr, d_noise, d_mask, R, D, kind, train_r, train_d, guard_r, guard_d, scale, k_rank};
+    Cfar2dArgs a{d_X, d_thr, d_noise, d_mask, R, D, kind, train_r, train_d, guard_r, guard_d, scale, k_rank, os_fast ? 1 : 0};
     dim3 grid((D + CFAR_TC - 1) / CFAR_TC, (R + CFAR_TR - 1) / CFAR_TR, n_frames);
     hipLaunchKernelGGL(k_cfar2d, grid, dim3(CFAR_TR * CFAR_TC), lds, ctx->stream, a);
     return check_launch("cfar2d");

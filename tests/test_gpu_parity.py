@@ -241,7 +241,7 @@ def test_cfar_known_answers_bit_exact(golden):
 
 
 @pytest.mark.parametrize("params", [((4, 4), (2, 2)), ((5, 5), (3, 2)), ((8, 4), (2, 1)), ((1, 1), (0, 0)),
-                                    ((2, 9), (1, 3))])
+                                    ((2, 9), (1, 3)), ((8, 8), (2, 2)), ((0, 3), (0, 1))])   # (8,8): tile > 1024 cells
 def test_cfar2d_random_maps_bit_exact(params):
     rng = np.random.default_rng(hash(params) % 1000)
     X = rng.exponential(1.0, (70, 45)) * 1e3
