@@ -131,6 +131,11 @@ int mmw_range_profile(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_fra
  * (processors/range_doppler_detection/range_doppler_detector_sequential.py:84-91). */
 int mmw_range_profile_f64(mmw_ctx *ctx, const void *d_cubes, double *d_out, int n_frames,
                           int V, int S, int C, int chirp_idx);
+/* mmw_range_zoom: d_out[F][m] float32 = mean_rx | sum_n hann(S)[n] x[rx][n][chirp] exp(-j 2 pi n (f0 + k df)) |,
+ *   k = 0..m-1, frequencies in cycles per sample: the zoomed range profile of RangeProcessor.zoom_fft
+ *   (processors/range_resp.py:59-102), which the reference evaluates with scipy.signal.ZoomFFT. */
+int mmw_range_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C,
+                   int chirp_idx, int m, double f0_cycles_per_sample, double df_cycles_per_sample);
 int mmw_range_angle(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames,
                     int V, int S, int C, int A, int chirp_idx, const int *h_rx, int n_rx,
                     int perform_windowing);

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "mmw_mean_over_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_range_profile": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_profile_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_range_zoom": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _d],
     "mmw_range_angle": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ip, _i, _i],
     "mmw_cfar2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i],
     "mmw_cfar1d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i],

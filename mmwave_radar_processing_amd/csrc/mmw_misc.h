@@ -165,6 +165,36 @@ __global__ __launch_bounds__(256) void k_dbs_gather(const float *mag, const int 
     out[gid] = mag[((f * A + ang_idx[i]) * S + s) * (long)C + vel_idx[i]];
 }
 
+// Zoom DFT: out[row][k] = sum_n win[n] x[row][n] exp(-j 2 pi n (f0 + k df)), frequencies in cycles/sample.
+// This is what scipy.signal.ZoomFFT evaluates (by Bluestein) for RangeProcessor.zoom_fft
+// (processors/range_resp.py:59-102); n and m are a few hundred, so the direct sum in float64 phase is enough.
+// One workgroup per row, the windowed row staged in LDS, thread k owns output bins k, k+256, ...
+__global__ __launch_bounds__(256) void k_zoom_dft(const float2 *x, long row_stride, long elem_stride, const float *win,
+                                                   float2 *out, int n, int m, double f0, double df) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *xs = reinterpret_cast<float2 *>(smem);
+    const float2 *src = x + (long)blockIdx.x * row_stride;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float2 v = src[(long)i * elem_stride];
+        const float w = win ? win[i] : 1.f;
+        xs[i] = make_float2(v.x * w, v.y * w);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < m; k += 256) {
+        const double f = f0 + (double)k * df;
+        double re = 0.0, im = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double turns = f * (double)i;
+            turns -= rint(turns);
+            double sn, cs;
+            sincospi(-2.0 * turns, &sn, &cs);
+            re += (double)xs[i].x * cs - (double)xs[i].y * sn;
+            im += (double)xs[i].x * sn + (double)xs[i].y * cs;
+        }
+        out[(long)blockIdx.x * m + k] = make_float2((float)re, (float)im);
+    }
+}
+
 constexpr int MAX_ANT = 32;
 struct AntList {
     int n;

@@ -550,6 +550,29 @@ int mmw_range_profile_f64(mmw_ctx *ctx, const void *d_cubes, double *d_out, int 
     return range_profile_impl<double>(ctx, d_cubes, d_out, n_frames, V, S, C, chirp_idx);
 }
 
+int mmw_range_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int chirp_idx,
+                   int m, double f0_cycles_per_sample, double df_cycles_per_sample) {
+    MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && m > 0, "bad shape");
+    MMW_REQUIRE(chirp_idx >= -C && chirp_idx < C, "chirp_idx %d out of range", chirp_idx);
+    MMW_REQUIRE((size_t)S * sizeof(float2) <= 64 * 1024, "too many samples for the zoom DFT row buffer");
+    if (chirp_idx < 0) chirp_idx += C;
+    if (n_frames == 0) return MMW_OK;
+    const void *hann;
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &hann));
+    MMW_TRY(ensure_scratch(ctx, (size_t)n_frames * V * m * sizeof(float2)));
+    // rows = (frame, antenna): x[row][i] = cube[frame][v][i][chirp]
+    hipLaunchKernelGGL(k_zoom_dft, dim3(n_frames * V), dim3(256), (size_t)S * sizeof(float2), ctx->stream,
+                       (const float2 *)d_cubes + chirp_idx, (long)S * C, (long)C, (const float *)hann,
+                       (float2 *)ctx->scratch, S, m, f0_cycles_per_sample, df_cycles_per_sample);
+    MMW_TRY(check_launch("zoom_dft"));
+    const long n = (long)n_frames * m;
+    hipLaunchKernelGGL((k_mean_abs_over_v<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const cplx<float> *)ctx->scratch, d_out, n_frames, V, m);
+    return check_launch("mean_abs_over_v");
+}
+
 int mmw_range_angle(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int A,
                     int chirp_idx, const int *h_rx, int n_rx, int perform_windowing) {
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");

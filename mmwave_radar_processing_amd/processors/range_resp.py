@@ -29,5 +29,21 @@ class RangeProcessor(_Processor):
         _lib.check(ctx.lib.mmw_range_profile(ctx.handle, d_cube.ptr, d_out.ptr, 1, V, S, C, int(chirp_idx)))
         return d_out.download((S,), np.float32).astype(np.float64)
 
+    def zoom_fft(self, adc_cube: np.ndarray, range_start_m: float, range_stop_m: float, chirp_idx: int = 0):
+        """(zoom_fft_magnitude, zoom_range_bins): S bins between the two ranges, mean |.| over antennas (:59-102)."""
+        cm = self.config_manager
+        ctx, bufs, d_cube, (V, S, C) = self._upload_cube(adc_cube)
+        fs = 1 / cm.range_res_m
+        freq_start = range_start_m * fs / cm.range_max_m
+        freq_stop = range_stop_m * fs / cm.range_max_m
+        m = S                                              # ZoomFFT(n, fn, m=None) -> m = n, endpoint=False
+        f0 = freq_start / fs
+        df = (freq_stop - freq_start) / m / fs
+        d_out = bufs.get("zoom", m * 4)
+        _lib.check(ctx.lib.mmw_range_zoom(ctx.handle, d_cube.ptr, d_out.ptr, 1, V, S, C, int(chirp_idx), m,
+                                          float(f0), float(df)))
+        zoom_avg = d_out.download((m,), np.float32).astype(np.float64)
+        return zoom_avg, np.linspace(range_start_m, range_stop_m, m)
+
     def process(self, adc_cube: np.ndarray, chirp_idx: int = 0, **kwargs) -> np.ndarray:
         return self.coarse_fft(adc_cube, chirp_idx)

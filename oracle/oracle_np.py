@@ -110,6 +110,19 @@ def range_profile(cube: np.ndarray, chirp_idx: int = 0) -> np.ndarray:
     return np.mean(np.abs(np.fft.fft(x, axis=1)), axis=0)
 
 
+def range_zoom(cube, sc, range_start_m, range_stop_m, chirp_idx=0):
+    """RangeProcessor.zoom_fft -- processors/range_resp.py:59-102.  scipy's ZoomFFT(n, [f1, f2], fs) is the DFT on
+    the arc f_k = f1 + k (f2 - f1)/n, k < n (endpoint=False); restated as that direct sum (float64)."""
+    x = cube[:, :, chirp_idx] * np.hanning(cube.shape[1])
+    S = x.shape[1]
+    fs = 1 / sc["range_res_m"]
+    f1 = range_start_m * fs / sc["range_max_m"]
+    f2 = range_stop_m * fs / sc["range_max_m"]
+    fk = f1 + np.arange(S) * (f2 - f1) / S
+    kern = np.exp(-2j * np.pi * np.outer(fk / fs, np.arange(S)))        # [m, n]
+    return np.mean(np.abs(x @ kern.T), axis=0), np.linspace(range_start_m, range_stop_m, S)
+
+
 # --------------------------------------------------------------------------
 # a5/a6  RangeDopplerProcessor -- processors/range_doppler_resp.py:49-110
 # --------------------------------------------------------------------------

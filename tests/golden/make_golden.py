@@ -256,6 +256,10 @@ def gen_doppler_azimuth():
     virt = synth.synth_cube(202, (12, 63, 70))
     p2 = DopplerAzimuthProcessor(cm2, num_angle_bins=64, valid_angle_range=np.array([-1.04719755, 1.04719755]))
     d["ods_sub"] = p2.process(virt, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], shift_angle=False)
+    # RangeProcessor.zoom_fft (scipy ZoomFFT inside the reference)
+    rp = RangeProcessor(cm)
+    z, zb = rp.zoom_fft(cube, range_start_m=0.6, range_stop_m=1.9, chirp_idx=3)
+    d["zoom_mag"], d["zoom_bins"] = z, zb
     np.savez_compressed(os.path.join(HERE, "doppler_azimuth.npz"), **d)
     print("doppler_azimuth.npz:", {k: v.shape for k, v in d.items()})
 

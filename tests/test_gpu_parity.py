@@ -632,3 +632,17 @@ def test_generic_kernels_cover_the_headline_shape(monkeypatch):
     assert rel_err(d_b.download((V, S, C), np.complex64, 5 * n * 8), ref_rd) <= SPEC_TOL
     for b in (d_in, d_a, d_b):
         b.free()
+
+
+def test_range_zoom_fft(golden):
+    g = golden("doppler_azimuth.npz")
+    cm = make_cm(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    z, zb = RangeProcessor(cm).zoom_fft(cube, range_start_m=0.6, range_stop_m=1.9, chirp_idx=3)
+    assert rel_err(z, g["zoom_mag"]) <= SPEC_TOL
+    np.testing.assert_array_equal(zb, g["zoom_bins"])
+    cm2 = make_cm(synth.SYNTH_CFG_256x128x12)
+    sc2 = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    c2 = synth.synth_cube(6)
+    z2, _ = RangeProcessor(cm2).zoom_fft(c2, 3.0, 7.5, chirp_idx=-1)
+    assert rel_err(z2, O.range_zoom(c2, sc2, 3.0, 7.5, chirp_idx=-1)[0]) <= SPEC_TOL

@@ -177,3 +177,12 @@ def test_doppler_azimuth_coarse_path(golden):
     virt = synth.synth_cube(202, (12, 63, 70))
     close(O.doppler_azimuth(virt, sc2, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], shift_angle=False,
                             valid_angle_range=(-1.04719755, 1.04719755), standard_geometry=False), g["ods_sub"])
+
+
+def test_range_zoom_matches_reference_zoomfft(golden):
+    g = golden("doppler_azimuth.npz")
+    sc = O.cfg_scalars(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    z, zb = O.range_zoom(cube, sc, 0.6, 1.9, chirp_idx=3)
+    close(z, g["zoom_mag"], 1e-11)
+    np.testing.assert_array_equal(zb, g["zoom_bins"])
