@@ -646,3 +646,68 @@ def test_range_zoom_fft(golden):
     c2 = synth.synth_cube(6)
     z2, _ = RangeProcessor(cm2).zoom_fft(c2, 3.0, 7.5, chirp_idx=-1)
     assert rel_err(z2, O.range_zoom(c2, sc2, 3.0, 7.5, chirp_idx=-1)[0]) <= SPEC_TOL
+
+
+def test_full_batch_size_independent_properties():
+    """BASELINE full size (1250 resident frames per GPU, the configs[4] shard): properties that need no oracle.
+    Parseval for the range-Doppler stage, linearity of the whole chain, a pure tone landing in its bin, and a
+    checksum-of-checksums comparing the overlapped schedule against the serial one on every frame."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, V, S, C, A = 1250, 12, 256, 128, 64
+    n = V * S * C
+    d_in, d_rd, d_out = ctx.alloc(F * n * 8), ctx.alloc(F * n * 8), ctx.alloc(F * A * S * C * 8)
+    _lib.check(L.mmw_synth_cubes(h, d_in.ptr, F, V, S, C, 20260, 8, 30.0))
+    # ---- Parseval: sum |RD|^2 = S*C * sum |hann(S) hann(C) x|^2 per antenna plane
+    _lib.check(L.mmw_range_doppler(h, d_in.ptr, d_rd.ptr, None, F, V, S, C))
+    win = np.hanning(S)[:, None] * np.hanning(C)[None, :]
+    for f in (0, 417, 1249):
+        x = d_in.download((V, S, C), np.complex64, f * n * 8).astype(np.complex128)
+        rd = d_rd.download((V, S, C), np.complex64, f * n * 8).astype(np.complex128)
+        lhs = np.sum(np.abs(rd) ** 2, axis=(1, 2))
+        rhs = S * C * np.sum(np.abs(x * win) ** 2, axis=(1, 2))
+        np.testing.assert_allclose(lhs, rhs, rtol=2e-6)
+    # ---- linearity of the full chain on frames of the batch: chain(2x - 3j y) = 2 chain(x) - 3j chain(y)
+    _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+    fx, fy = 100, 1100
+    x = d_in.download((V, S, C), np.complex64, fx * n * 8)
+    y = d_in.download((V, S, C), np.complex64, fy * n * 8)
+    cx = d_out.download((A, S, C), np.complex64, fx * A * S * C * 8).astype(np.complex128)
+    cy = d_out.download((A, S, C), np.complex64, fy * A * S * C * 8).astype(np.complex128)
+    mix = (2.0 * x - 3.0j * y).astype(np.complex64)
+    d_mix, d_mix_out = ctx.alloc(n * 8), ctx.alloc(A * S * C * 8)
+    d_mix.upload(mix)
+    _lib.check(L.mmw_chain3d(h, d_mix.ptr, None, d_mix_out.ptr, 1, V, S, C, A, 0))
+    cm_ = d_mix_out.download((A, S, C), np.complex64).astype(np.complex128)
+    expect = 2.0 * cx - 3.0j * cy
+    assert np.max(np.abs(cm_ - expect)) / np.max(np.abs(expect)) <= 1e-6
+    # ---- a pure tone lands in its (angle, range, Doppler) bin: x = exp(j 2 pi (kr s/S + kc c/C + ka v/A))
+    kr, kc, ka = 37, -21, 9
+    v_, s_, c_ = np.meshgrid(np.arange(V), np.arange(S), np.arange(C), indexing="ij")
+    tone = (1000.0 * np.exp(2j * np.pi * (kr * s_ / S + kc * c_ / C + ka * v_ / A))).astype(np.complex64)
+    d_mix.upload(tone)
+    _lib.check(L.mmw_chain3d(h, d_mix.ptr, None, d_mix_out.ptr, 1, V, S, C, A, 0))
+    mag = np.abs(d_mix_out.download((A, S, C), np.complex64))
+    assert np.unravel_index(np.argmax(mag), mag.shape) == ((ka + A // 2) % A, kr, (kc + C // 2) % C)
+    # ---- checksum of checksums: serial schedule vs overlapped schedule, all 1250 frames
+    os.environ["MMW_CHAIN_PIPELINE"] = "0"
+    try:
+        d_out2 = ctx.alloc(F * A * S * C * 4)
+        d_out1 = ctx.alloc(F * A * S * C * 4)
+        _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out2.ptr, F, V, S, C, A, 1))     # serial, |.| output
+    finally:
+        del os.environ["MMW_CHAIN_PIPELINE"]
+    _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out1.ptr, F, V, S, C, A, 1))         # overlapped
+    sums1 = np.empty(F)
+    sums2 = np.empty(F)
+    step = 50
+    for f0 in range(0, F, step):
+        a = d_out1.download((step, A * S * C), np.float32, f0 * A * S * C * 4)
+        b = d_out2.download((step, A * S * C), np.float32, f0 * A * S * C * 4)
+        sums1[f0:f0 + step] = a.sum(axis=1, dtype=np.float64)
+        sums2[f0:f0 + step] = b.sum(axis=1, dtype=np.float64)
+        assert np.array_equal(a[::7], b[::7])           # same kernels, same bits
+    np.testing.assert_array_equal(sums1, sums2)
+    assert np.all(sums1 > 0)
+    for b_ in (d_in, d_rd, d_out, d_mix, d_mix_out, d_out1, d_out2):
+        b_.free()
