@@ -336,6 +336,167 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
     }
 }
 
+// ------------------------------------------------------------------ fused range-Doppler, planes that fit LDS
+// k_rd_lds<S, C>: any power-of-two plane of at most 16384 cells (128 KiB) is transformed inside LDS in one pass over
+// HBM: coalesced row loads + Hann x Hann -> LDS; range FFT down the columns as two register passes (in place, lanes
+// walk the contiguous chirp index, so every LDS access is conflict free); Doppler FFT along the rows, the second
+// pass storing straight to global memory with the fftshift folded into the index.  16 cells per thread.
+constexpr int rdl_r1(int n) { return n >= 512 ? 32 : n >= 128 ? 16 : n >= 32 ? 8 : 4; }
+
+template <int S, int C> struct RdLds {
+    static constexpr int R1S = rdl_r1(S), R2S = S / R1S, R1C = rdl_r1(C), R2C = C / R1C;
+    static constexpr int CELLS = S * C;
+    static constexpr int NT = CELLS / 16 > 1024 ? 1024 : (CELLS / 16 < 64 ? 64 : CELLS / 16);
+    static constexpr int VPT = CELLS / NT;                  // cells per thread (16, or more for 1024-thread planes)
+    static constexpr int P = C + R2C;                       // row pitch: strided row reads of pass 1 stay conflict free
+    static constexpr int LDS_BYTES = (S * P + S + C) * 8;
+    static_assert(R1S >= R2S && R1C >= R2C && R2S >= 2 && R2C >= 2, "radix split");
+    static_assert(CELLS <= 16384 && CELLS % NT == 0 && VPT % R2S == 0 && VPT % R2C == 0, "plane must fit the scheme");
+};
+
+template <int S, int C>
+__global__ __launch_bounds__((RdLds<S, C>::NT)) void k_rd_lds(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
+                                                               const float *__restrict__ hann_s,
+                                                               const float *__restrict__ hann_c,
+                                                               const cplx<float> *__restrict__ tw_s_g,
+                                                               const cplx<float> *__restrict__ tw_c_g) {
+    typedef RdLds<S, C> K;
+    constexpr int NT = K::NT, P = K::P, R1S = K::R1S, R2S = K::R2S, R1C = K::R1C, R2C = K::R2C, VPT = K::VPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
+    cplx<float> *tw_s = lds + S * P, *tw_c = tw_s + S;
+    const int t = threadIdx.x;
+    const f32x4 *src = in + (long)blockIdx.x * (K::CELLS / 2);
+    cplx<float> *dst = out + (long)blockIdx.x * K::CELLS;
+    for (int i = t; i < S; i += NT) tw_s[i] = tw_s_g[i];
+    for (int i = t; i < C; i += NT) tw_c[i] = tw_c_g[i];
+    // ---- load + window
+#pragma unroll
+    for (int q = 0; q < VPT / 2; ++q) {
+        const int idx = t + q * NT;                         // float4 index: two adjacent chirps of one sample row
+        const int row = (2 * idx) / C, col = (2 * idx) % C;
+        const f32x4 v = __builtin_nontemporal_load(src + idx);
+        const float w0 = hann_s[row] * hann_c[col], w1 = hann_s[row] * hann_c[col + 1];
+        *reinterpret_cast<f32x4 *>(&lds[row * P + col]) = f32x4{v.x * w0, v.y * w0, v.z * w1, v.w * w1};
+    }
+    __syncthreads();
+    // ---- range pass 1: items (column c, phase j), samples R2S*n1 + j, in place
+    {
+        constexpr int ITEMS = C * R2S, ROUNDS = (ITEMS + NT - 1) / NT;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int it = t + r * NT;
+            if (ITEMS % NT == 0 || it < ITEMS) {
+                const int c = it % C, j = it / C;
+                cplx<float> a[R1S];
+#pragma unroll
+                for (int n1 = 0; n1 < R1S; ++n1) a[n1] = lds[(R2S * n1 + j) * P + c];
+                RegFFT<R1S, float>::run(a);
+                static_for<R1S>([&](auto K1) {
+                    constexpr int k1 = decltype(K1)::value;
+                    lds[(R2S * k1 + j) * P + c] = cmul(a[bitrev<R1S>(k1)], tw_s[j * k1]);
+                });
+            }
+        }
+    }
+    __syncthreads();
+    // ---- range pass 2: items (c, k1); results move to rows k1 + R1S*k2, so everything is read before it is written
+    {
+        constexpr int ITEMS = C * R1S, ROUNDS = ITEMS / NT;
+        static_assert(ITEMS % NT == 0 && ROUNDS * R2S == VPT, "range pass 2 covers the plane exactly");
+        cplx<float> v[ROUNDS][R2S];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int it = t + r * NT, c = it % C, k1 = it / C;
+#pragma unroll
+            for (int n2 = 0; n2 < R2S; ++n2) v[r][n2] = lds[(R2S * k1 + n2) * P + c];
+            RegFFT<R2S, float>::run(v[r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int it = t + r * NT, c = it % C, k1 = it / C;
+            static_for<R2S>([&](auto K2) {
+                constexpr int k2 = decltype(K2)::value;
+                lds[(k1 + R1S * k2) * P + c] = v[r][bitrev<R2S>(k2)];
+            });
+        }
+    }
+    __syncthreads();
+    // ---- Doppler pass 1: items (row s, phase j), chirps R2C*n1 + j, in place
+    {
+        constexpr int ITEMS = S * R2C, ROUNDS = (ITEMS + NT - 1) / NT;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int it = t + r * NT;
+            if (ITEMS % NT == 0 || it < ITEMS) {
+                const int j = it % R2C, row = it / R2C;
+                cplx<float> a[R1C];
+#pragma unroll
+                for (int n1 = 0; n1 < R1C; ++n1) a[n1] = lds[row * P + R2C * n1 + j];
+                RegFFT<R1C, float>::run(a);
+                static_for<R1C>([&](auto K1) {
+                    constexpr int k1 = decltype(K1)::value;
+                    lds[row * P + R2C * k1 + j] = cmul(a[bitrev<R1C>(k1)], tw_c[j * k1]);
+                });
+            }
+        }
+    }
+    __syncthreads();
+    // ---- Doppler pass 2 + store (fftshift = XOR of the top Doppler bit)
+    {
+        constexpr int ITEMS = S * R1C, ROUNDS = ITEMS / NT;
+        static_assert(ITEMS % NT == 0, "Doppler pass 2 covers the plane exactly");
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int it = t + r * NT, k1 = it % R1C, row = it / R1C;
+            cplx<float> a[R2C];
+#pragma unroll
+            for (int n2 = 0; n2 < R2C; ++n2) a[n2] = lds[row * P + R2C * k1 + n2];
+            RegFFT<R2C, float>::run(a);
+            static_for<R2C>([&](auto K2) {
+                constexpr int k2 = decltype(K2)::value;
+                dst[row * C + ((k1 + R1C * k2) ^ (C / 2))] = a[bitrev<R2C>(k2)];
+            });
+        }
+    }
+}
+
+template <int S, int C> int launch_rd_lds_sc(mmw_ctx *ctx, const void *d_in, void *d_out, int planes) {
+    const void *hs, *hc, *ts, *tc;
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &hs));
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, C, &hc));
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, S, &ts));
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, C, &tc));
+    typedef RdLds<S, C> K;
+    if (K::LDS_BYTES > 64 * 1024)
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_lds<S, C>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+    hipLaunchKernelGGL((k_rd_lds<S, C>), dim3(planes), dim3(K::NT), K::LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
+                       (cplx<float> *)d_out, (const float *)hs, (const float *)hc, (const cplx<float> *)ts,
+                       (const cplx<float> *)tc);
+    return check_launch("rd_lds");
+}
+
+// planes handled by k_rd_lds (S x C, both powers of two, S*C <= 16384)
+#define MMW_RD_LDS_SHAPES(X) \
+    X(32, 32) X(64, 32) X(128, 32) X(256, 32) X(512, 32) X(32, 64) X(64, 64) X(128, 64) X(256, 64) \
+    X(32, 128) X(64, 128) X(128, 128)
+
+inline bool rd_lds_supported(int S, int C) {
+#define X(s, c) if (S == s && C == c) return true;
+    MMW_RD_LDS_SHAPES(X)
+#undef X
+    return false;
+}
+
+inline int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C) {
+#define X(s, c) if (S == s && C == c) return launch_rd_lds_sc<s, c>(ctx, d_in, d_out, planes);
+    MMW_RD_LDS_SHAPES(X)
+#undef X
+    return set_error(MMW_ERR_UNSUPPORTED, "no LDS-resident RD kernel for %dx%d", S, C);
+}
+
 inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
 
 inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C) {

@@ -294,6 +294,8 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
         ProfScope ps(ctx, "rd");
         if (fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
             MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C));
+        else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
+            MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C));
         else
             MMW_TRY(range_doppler_generic(ctx, d_cubes, d_out, n_frames, V, S, C));
     }

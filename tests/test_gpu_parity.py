@@ -43,7 +43,11 @@ def sample_cfg_text():
 
 
 SHAPES = [((12, 32, 16), 101), ((12, 64, 32), 5), ((12, 256, 128), 0), ((12, 63, 70), 202),
-          ((4, 128, 64), 9), ((8, 512, 8), 10), ((3, 100, 30), 12)]
+          ((4, 128, 64), 9), ((8, 512, 8), 10), ((3, 100, 30), 12),
+          # every plane shape of the LDS-resident fused kernel (k_rd_lds)
+          ((2, 32, 32), 30), ((2, 64, 32), 31), ((2, 128, 32), 32), ((2, 256, 32), 33), ((3, 512, 32), 34),
+          ((2, 32, 64), 35), ((2, 64, 64), 36), ((2, 256, 64), 37), ((2, 32, 128), 38), ((2, 64, 128), 39),
+          ((5, 128, 128), 40)]
 
 
 def test_device_is_gfx950():
