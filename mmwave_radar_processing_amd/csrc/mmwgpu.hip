@@ -476,7 +476,8 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         if (waves >= 1) chunk_auto = (int)((long)waves * per_wave_num / per_wave_den);
     }
     if (chunk_auto < 1) chunk_auto = 1;
-    const bool fused_shape = fused_rd_ok(S, C) && A == 64 && (V == 4 || V == 8 || V == 12 || V == 16);
+    const bool fused_shape = (fused_rd_ok(S, C) || rd_lds_supported(S, C)) && A == 64 &&
+                             (V == 4 || V == 8 || V == 12 || V == 16);   // both stages have a single-pass kernel
     const int want_pipe = env_int("MMW_CHAIN_PIPELINE", -1);
     const bool pipelined = !d_rd && (want_pipe == 1 || (want_pipe == -1 && fused_shape && n_frames >= 2 * chunk_auto));
     int chunk = env_int("MMW_CHAIN_CHUNK", pipelined ? chunk_auto : 1024);
