@@ -715,3 +715,21 @@ def test_full_batch_size_independent_properties():
     assert np.all(sums1 > 0)
     for b_ in (d_in, d_rd, d_out, d_mix, d_mix_out, d_out1, d_out2):
         b_.free()
+
+
+def test_overlapped_chain_on_an_lds_resident_shape():
+    """12x64x64 cubes (k_rd_lds + k_angle64): batch large enough for the overlapped schedule (chunk ~ 330 frames)."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, V, S, C, A = 1500, 12, 64, 64, 64
+    n = V * S * C
+    d_in, d_out = ctx.alloc(F * n * 8), ctx.alloc(F * A * S * C * 8)
+    _lib.check(L.mmw_synth_cubes(h, d_in.ptr, F, V, S, C, 99, 6, 30.0))
+    for _ in range(2):
+        _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+    for f in (0, 331, 332, 333, 665, 666, 1000, 1499):
+        cube = d_in.download((V, S, C), np.complex64, f * n * 8)
+        got = d_out.download((A, S, C), np.complex64, f * A * S * C * 8)
+        assert rel_err(got, O.fft3d_windowed(cube, A)) <= SPEC_TOL, f
+    d_in.free()
+    d_out.free()
