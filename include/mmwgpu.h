@@ -160,6 +160,14 @@ int mmw_cfar1d(mmw_ctx *ctx, const double *d_x, double *d_thr, double *d_noise, 
 int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t *d_counts,
                   int n_frames, int R, int D, int cap);
 
+/* mmw_detect_batch: the detection pipeline of RangeDopplerDetector2D for a batch of frames in one call:
+ *   d_rd[F][V][S][C] c64 (mmw_range_doppler) and, for antenna 0, d_mag64[F][S][C] -> 2-D CFAR mask -> ordered
+ *   detections d_dets[F][cap][2] / d_counts[F]
+ *   (range_doppler_detection/range_doppler_detector.py:45-80 + range_doppler_detector_2d.py:49-65 per frame). */
+int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_mag64, uint8_t *d_mask,
+                     int32_t *d_dets, int32_t *d_counts, int n_frames, int V, int S, int C, int cfar_kind,
+                     int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap);
+
 /* ---------------------------------------------------------------- point cloud
  * mmw_angle_argmax: for each detection (r, v) of frame f gather rd[f][ant[i]][r][v], zero-pad to A,
  *   FFT, optional fftshift, |.|, first-max argmax -> d_idx[F][cap] int32.

@@ -133,12 +133,13 @@ class FramePipeline:
         d_mask = self.bufs.get("mask", max(F, 1) * n)
         self.d_dets = self.bufs.get("dets", max(F, 1) * cap * 8)
         self.d_cnt = self.bufs.get("counts", max(F, 1) * 4)
-        _lib.check(L.mmw_range_doppler(h, self.d_in.ptr, self.d_rd.ptr, None, F, V, S, C))
-        _lib.check(L.mmw_range_doppler_mag64(h, self.d_in.ptr, d_mag.ptr, F, V, S, C, 0))
-        for f0 in range(0, F, 65535):       # grid.z limit of the CFAR launch
-            nf = min(65535, F - f0)
-            self.cfar._launch_device(self.ctx, d_mag.at(f0 * n * 8), None, None, d_mask.at(f0 * n), nf, S, C)
-        _lib.check(L.mmw_compact2d(h, d_mask.ptr, self.d_dets.ptr, self.d_cnt.ptr, F, S, C, cap))
+        (tr, td), (gr, gd) = self.cfar.num_train, self.cfar.num_guard
+        for f0 in range(0, F, 32768):       # grid limits of the per-frame launches
+            nf = min(32768, F - f0)
+            _lib.check(L.mmw_detect_batch(h, self.d_in.at(f0 * self.cube_bytes), self.d_rd.at(f0 * self.cube_bytes),
+                                          d_mag.at(f0 * n * 8), d_mask.at(f0 * n), self.d_dets.at(f0 * cap * 8),
+                                          self.d_cnt.at(f0 * 4), nf, V, S, C, self.cfar.kind, int(tr), int(td), int(gr),
+                                          int(gd), float(self.cfar._scale()), int(self.cfar._k_rank()), cap))
         self.counts = self.d_cnt.download((F,), np.int32)
         if np.any(self.counts > cap):
             raise _lib.MmwGpuError(f"detection capacity {cap} exceeded (max count {int(self.counts.max())}): "

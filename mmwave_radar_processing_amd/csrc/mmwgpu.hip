@@ -310,10 +310,9 @@ int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_ma
     return range_doppler_impl(ctx, d_cubes, d_out, d_mag_f32, n_frames, V, S, C);
 }
 
-int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S,
-                            int C, int rx_idx) {
+static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S,
+                                   int C, int rx_idx) {
     MMW_REQUIRE(ctx && d_cubes && d_mag, "null argument");
-    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && rx_idx >= 0 && rx_idx < V, "bad shape / rx_idx");
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "rd64");
@@ -344,6 +343,13 @@ int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, in
     b.shift = 1;
     b.magnitude = 1;
     return launch_fft_axis<double, double>(ctx, b, C, true);
+}
+
+int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S,
+                            int C, int rx_idx) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
+    return range_doppler_mag64_impl(ctx, d_cubes, d_mag, n_frames, V, S, C, rx_idx);
 }
 
 static int angle_fft_impl(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
@@ -637,11 +643,10 @@ int mmw_range_angle(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frame
 }
 
 // ------------------------------------------------------------------ CFAR
-int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, uint8_t *d_mask, int n_frames,
-               int R, int D, int kind, int train_r, int train_d, int guard_r, int guard_d, double scale,
-               int k_rank) {
+static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, uint8_t *d_mask, int n_frames,
+                       int R, int D, int kind, int train_r, int train_d, int guard_r, int guard_d, double scale,
+                       int k_rank) {
     MMW_REQUIRE(ctx && d_X, "null argument");
-    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && R > 0 && D > 0, "bad shape");
     MMW_REQUIRE(train_r >= 0 && train_d >= 0 && guard_r >= 0 && guard_d >= 0, "negative window size");
     MMW_REQUIRE(kind == MMW_CFAR_CA || kind == MMW_CFAR_OS, "2-D CFAR kind must be CA or OS");
@@ -670,6 +675,15 @@ int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, 
     return check_launch("cfar2d");
 }
 
+int mmw_cfar2d(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d_noise, uint8_t *d_mask, int n_frames,
+               int R, int D, int kind, int train_r, int train_d, int guard_r, int guard_d, double scale,
+               int k_rank) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
+    return cfar2d_impl(ctx, d_X, d_thr, d_noise, d_mask, n_frames, R, D, kind, train_r, train_d, guard_r, guard_d, scale,
+                       k_rank);
+}
+
 int mmw_cfar1d(mmw_ctx *ctx, const double *d_x, double *d_thr, double *d_noise, uint8_t *d_mask, int n_rows,
                int L, int kind, int num_train, int num_guard, double scale, int k_rank) {
     MMW_REQUIRE(ctx && d_x, "null argument");
@@ -686,15 +700,39 @@ int mmw_cfar1d(mmw_ctx *ctx, const double *d_x, double *d_thr, double *d_noise, 
     return check_launch("cfar1d");
 }
 
-int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t *d_counts, int n_frames,
-                  int R, int D, int cap) {
+static int compact2d_impl(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t *d_counts, int n_frames,
+                          int R, int D, int cap) {
     MMW_REQUIRE(ctx && d_mask && d_dets && d_counts, "null argument");
-    MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && R > 0 && D > 0 && cap >= 0, "bad shape");
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "compact");
     hipLaunchKernelGGL(k_compact2d, dim3(n_frames), dim3(1024), 0, ctx->stream, d_mask, d_dets, d_counts, R, D, cap);
     return check_launch("compact2d");
+}
+
+int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t *d_counts, int n_frames,
+                  int R, int D, int cap) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
+    return compact2d_impl(ctx, d_mask, d_dets, d_counts, n_frames, R, D, cap);
+}
+
+// One call for the per-frame detection pipeline of RangeDopplerDetector2D over a batch: RD cube (fp32, all
+// antennas), float64 |RD| of antenna 0, 2-D CFAR, ordered compaction.  The stages run back to back on the context
+// stream: running the RD kernel beside the detection kernels on CU-masked queues was measured 2x SLOWER, because the
+// float64 FFT and CFAR kernels are latency/ALU bound and scale with the CUs they get (unlike the angle kernel).
+int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_mag64, uint8_t *d_mask,
+                     int32_t *d_dets, int32_t *d_counts, int n_frames, int V, int S, int C, int cfar_kind,
+                     int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap) {
+    MMW_REQUIRE(ctx && d_cubes && d_rd && d_mag64 && d_mask && d_dets && d_counts, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && n_frames <= 65535 && V > 0 && S > 0 && C > 0 && cap >= 0, "bad shape");
+    if (n_frames == 0) return MMW_OK;
+    MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C));
+    MMW_TRY(range_doppler_mag64_impl(ctx, d_cubes, d_mag64, n_frames, V, S, C, 0));
+    MMW_TRY(cfar2d_impl(ctx, d_mag64, nullptr, nullptr, d_mask, n_frames, S, C, cfar_kind, train_r, train_d, guard_r,
+                        guard_d, scale, k_rank));
+    return compact2d_impl(ctx, d_mask, d_dets, d_counts, n_frames, S, C, cap);
 }
 
 // ------------------------------------------------------------------ point cloud

@@ -92,6 +92,13 @@ def main():
         _lib.check(L.mmw_angle_argmax(ctx.handle, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, min(F, 65535), V, S, C, cap,
                                       ants, n_ant, A, 1))
     run("detect_pipeline_config3", detect_all, F * (2 * cube_b + S * C * 4))
+
+    def detect_batch():
+        _lib.check(L.mmw_detect_batch(ctx.handle, d_in.ptr, d_rd.ptr, d_mag.ptr, d_mask.ptr, d_dets.ptr, d_cnt.ptr,
+                                      min(F, 32768), V, S, C, 0, 4, 4, 2, 2, alpha, 0, cap))
+        _lib.check(L.mmw_angle_argmax(ctx.handle, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, min(F, 65535), V, S, C, cap,
+                                      ants, n_ant, A, 1))
+    run("detect_batch_config3", detect_batch, F * (2 * cube_b + S * C * 4))
     res["mean_detections_per_frame"] = float(d_cnt.download((F,), np.int32).mean())
     # ---- beamformers (BASELINE config 4 shapes): complex GEMM on f32 MFMA, MVDR on f64 MFMA
     Sb, Eb, Tb = 256, 256, 64
