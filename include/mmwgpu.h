@@ -119,6 +119,15 @@ int mmw_dbs_gather(mmw_ctx *ctx, const float *d_mag, const int *h_ang_idx, const
  *   2-D FFT over (chirp, antenna) -> |.| -> mean over the kept range bins. */
 int mmw_mean_over_range(mmw_ctx *ctx, const float *d_mag, float *d_out, int n_frames,
                         int A, int S, int C, int s_lo, int s_hi);
+/* mmw_doppler_azimuth_zoom: d_out[F][M][A] float32 = mean over range rows [s_lo, s_hi) of
+ *   | fftshift_A FFT_A( pad_{V->A}( hann(V)[v] sum_{c < n_used} R[v][s][c] exp(-j 2 pi c h_freq[k]) ) ) |,
+ *   R = FFT_S( hann(S) hann(C) x ), h_freq[M] in cycles per chirp (host array; NaN = a bin the reference fills
+ *   with zeros).  This is DopplerAzimuthProcessor.process(use_precise_fft=True)
+ *   (processors/doppler_azimuth_resp.py:130-163,208-294,477-489), whose two scipy.signal.ZoomFFT calls over the
+ *   chirp axis evaluate exactly these sums; the caller derives h_freq from the velocity range (:148-155,254-283).
+ *   flags: MMW_ANGLE_NO_WINDOW, MMW_ANGLE_NO_SHIFT. */
+int mmw_doppler_azimuth_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int A,
+                             int s_lo, int s_hi, int n_used, const double *h_freq, int M, int flags);
 
 /* mmw_range_profile: d_out[F][S] float32 = mean_rx | FFT_S( hann(S) x[:, :, chirp] ) |
  *   replaces RangeProcessor.coarse_fft (processors/range_resp.py:32-57).

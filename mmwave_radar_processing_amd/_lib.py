@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmmwgpu.so")
 
 MMW_OK = 0
+MMW_ERR_INVALID = -1
 MMW_ERR_TRUNCATED = -4
 CFAR_CA, CFAR_OS, CFAR_GO, CFAR_SO = 0, 1, 2, 3
 ANGLE_MAGNITUDE, ANGLE_NO_WINDOW, ANGLE_NO_SHIFT = 1, 2, 4
@@ -53,6 +54,7 @@ _SIGNATURES = {
     "mmw_chain3d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_dbs_gather": [_vp, _vp, _ip, _ip, _vp, _i, _i, _i, _i, _i],
     "mmw_mean_over_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "mmw_doppler_azimuth_zoom": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_d), _i, _i],
     "mmw_range_profile": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_profile_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_zoom": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _d, _d],

@@ -195,6 +195,64 @@ __global__ __launch_bounds__(256) void k_zoom_dft(const float2 *x, long row_stri
     }
 }
 
+// Doppler zoom transform of DopplerAzimuthProcessor.zoom_fft (processors/doppler_azimuth_resp.py:130-163):
+// k_zoom_table  Z[i][k] = exp(-j 2 pi i f[k]) with the phase reduced in float64 (f in cycles per chirp; NaN marks
+//               a bin the reference fills with zeros, :267/:285);
+// k_zoom_rows   out[row][k] = sum_{i<n} x[row][i] Z[i][k] for the rows (frame*antenna, kept range bin) of the
+//               range-FFT cube: RB rows staged in LDS per workgroup, thread k owns one zoom bin.
+__global__ __launch_bounds__(256) void k_zoom_table(const double *freq, float2 *Z, int n, int m) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)n * m) return;
+    const int k = (int)(gid % m), i = (int)(gid / m);
+    const double f = freq[k];
+    float2 z = make_float2(0.f, 0.f);
+    if (f == f) {
+        double turns = f * (double)i;
+        turns -= rint(turns);
+        double sn, cs;
+        sincospi(-2.0 * turns, &sn, &cs);
+        z = make_float2((float)cs, (float)sn);
+    }
+    Z[gid] = z;
+}
+
+template <int RB>
+__global__ __launch_bounds__(256) void k_zoom_rows(const float2 *x, const float2 *Z, float2 *out, int S, int C, int s_lo,
+                                                    int s_keep, int n, int m, long total_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *xs = reinterpret_cast<float2 *>(smem);           // [RB][n]
+    const long row0 = (long)blockIdx.x * RB;
+    for (int e = threadIdx.x; e < RB * n; e += 256) {
+        const int r = e / n, i = e - r * n;
+        const long row = row0 + r;
+        float2 v = make_float2(0.f, 0.f);
+        if (row < total_rows) {
+            const long fv = row / s_keep;
+            const int s = s_lo + (int)(row - fv * s_keep);
+            v = x[(fv * S + s) * (long)C + i];
+        }
+        xs[e] = v;
+    }
+    __syncthreads();
+    const int k = blockIdx.y * 256 + threadIdx.x;
+    if (k >= m) return;
+    float2 acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = make_float2(0.f, 0.f);
+    for (int i = 0; i < n; ++i) {
+        const float2 z = Z[(long)i * m + k];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float2 v = xs[r * n + i];
+            acc[r].x = fmaf(v.x, z.x, fmaf(-v.y, z.y, acc[r].x));
+            acc[r].y = fmaf(v.x, z.y, fmaf(v.y, z.x, acc[r].y));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+        if (row0 + r < total_rows) out[(row0 + r) * m + k] = acc[r];
+}
+
 constexpr int MAX_ANT = 32;
 struct AntList {
     int n;

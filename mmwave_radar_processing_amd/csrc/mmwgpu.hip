@@ -430,6 +430,71 @@ int mmw_mean_over_range(mmw_ctx *ctx, const float *d_mag, float *d_out, int n_fr
     return check_launch("mean_over_range");
 }
 
+int mmw_doppler_azimuth_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int A,
+                             int s_lo, int s_hi, int n_used, const double *h_freq, int M, int flags) {
+    MMW_REQUIRE(ctx && d_cubes && d_out && h_freq, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V && M > 0, "bad shape (need A >= V, M > 0)");
+    MMW_REQUIRE(0 <= s_lo && s_lo < s_hi && s_hi <= S, "empty or out-of-range row interval [%d, %d)", s_lo, s_hi);
+    MMW_REQUIRE(n_used > 0 && n_used <= C, "zoom transform defined for %d chirps, the cube has %d", n_used, C);
+    MMW_REQUIRE((flags & ~(MMW_ANGLE_NO_WINDOW | MMW_ANGLE_NO_SHIFT)) == 0, "unknown flag bits %d", flags);
+    constexpr int RB = 16;
+    MMW_REQUIRE((size_t)RB * n_used * sizeof(float2) <= 64 * 1024, "too many chirps for the zoom row buffer");
+    if (n_frames == 0) return MMW_OK;
+    ProfScope ps(ctx, "dopaz_zoom");
+    const int Sk = s_hi - s_lo;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_freq = up((size_t)M * sizeof(double)), b_tab = up((size_t)n_used * M * sizeof(float2));
+    const size_t f_rng = (size_t)V * S * C * sizeof(float2), f_zoom = (size_t)V * Sk * M * sizeof(float2),
+                 f_mag = (size_t)A * Sk * M * sizeof(float);
+    const size_t per_frame = up(f_rng) + up(f_zoom) + up(f_mag);
+    long chunk = (long)(((size_t)1 << 30) / per_frame);       // <= 1 GiB of intermediates per pass
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_frames) chunk = n_frames;
+    if (chunk > 65535) chunk = 65535;
+    MMW_TRY(ensure_scratch(ctx, b_freq + b_tab + (size_t)chunk * per_frame));
+    char *base = (char *)ctx->scratch;
+    double *d_freq = (double *)base;
+    float2 *d_tab = (float2 *)(base + b_freq);
+    char *d_rng = base + b_freq + b_tab;
+    char *d_zoom = d_rng + up((size_t)chunk * f_rng);
+    char *d_mag = d_zoom + up((size_t)chunk * f_zoom);
+    MMW_HIP(hipMemcpyAsync(d_freq, h_freq, (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MMW_HIP(hipStreamSynchronize(ctx->stream));     // h_freq is caller-owned host memory
+    const long tab_n = (long)n_used * M;
+    hipLaunchKernelGGL(k_zoom_table, dim3((unsigned)((tab_n + 255) / 256)), dim3(256), 0, ctx->stream, d_freq, d_tab,
+                       n_used, M);
+    MMW_TRY(check_launch("zoom_table"));
+    for (long f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = (int)((n_frames - f0 < chunk) ? n_frames - f0 : chunk);
+        FftArgs a{};                                 // range FFT, Hann(S) x Hann(C) folded into the load
+        a.in = (const char *)d_cubes + (size_t)f0 * f_rng;
+        a.out = d_rng;
+        a.outer = nf * V;
+        a.inner = C;
+        a.n_in = S;
+        a.in_outer_stride = a.out_outer_stride = (long)S * C;
+        a.in_axis_stride = a.out_axis_stride = C;
+        a.in_inner_stride = a.out_inner_stride = 1;
+        MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &a.win_axis));
+        MMW_TRY(get_table<float>(ctx, TAB_HANN, C, &a.win_inner));
+        a.scale = 1.0;
+        MMW_TRY((launch_fft_axis<float, float>(ctx, a, S, false)));
+        const long rows = (long)nf * V * Sk;
+        hipLaunchKernelGGL((k_zoom_rows<RB>), dim3((unsigned)((rows + RB - 1) / RB), (unsigned)((M + 255) / 256)), dim3(256),
+                           (size_t)RB * n_used * sizeof(float2), ctx->stream, (const float2 *)d_rng, d_tab,
+                           (float2 *)d_zoom, S, C, s_lo, Sk, n_used, M, rows);
+        MMW_TRY(check_launch("zoom_rows"));
+        // antenna window + zero-padded angle FFT + |.| on [nf][V][Sk][M], then the mean over the kept range bins
+        MMW_TRY(angle_fft_impl(ctx, d_zoom, d_mag, nf, V, Sk, M, A, flags | MMW_ANGLE_MAGNITUDE));
+        const long total = (long)nf * A * M;
+        hipLaunchKernelGGL(k_mean_over_range, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const float *)d_mag, d_out + (size_t)f0 * M * A, nf, A, Sk, M, 0, Sk);
+        MMW_TRY(check_launch("mean_over_range"));
+    }
+    return MMW_OK;
+}
+
 // Lazily create the two CU-masked queues of the overlapped chain: the RD queue owns the first rd_cus
 // CU-mask bits, the angle queue the rest, so workgroups of the two kernels are co-resident on the chip.
 static int ensure_pipe_queues(mmw_ctx *ctx, int rd_cus) {

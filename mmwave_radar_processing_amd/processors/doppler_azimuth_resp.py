@@ -1,11 +1,16 @@
-"""Doppler-azimuth response, coarse FFT path
-(reference: mmwave_radar_processing/processors/doppler_azimuth_resp.py:8-128,296-334,419-491).
+"""Doppler-azimuth response, coarse FFT and precise (ZoomFFT) modes
+(reference: mmwave_radar_processing/processors/doppler_azimuth_resp.py:8-334,419-491).
 
 antenna subset -> Hann(S) x Hann(C) (x Hann(V) on the "standard" geometry with virtual antennas) -> range FFT ->
 keep the range bins inside ``range_window`` -> 2-D FFT over (chirp, zero-padded antenna) -> fftshift -> |.| ->
 valid angle columns -> mean over the kept range bins.  On the GPU this is the 3-D chain of
 ``mmw_chain3d`` (magnitude output) followed by ``mmw_mean_over_range``.
-The reference's ZoomFFT ("precise") mode and scipy peak pickers are a later-round item.
+
+``use_precise_fft=True`` replaces the Doppler FFT by the reference's two ``scipy.signal.ZoomFFT`` calls (one per
+velocity sign) over ``precise_vel_range``; the host derives the frequency of every zoomed bin exactly as the reference
+does and ``mmw_doppler_azimuth_zoom`` evaluates range FFT -> zoom transform -> angle FFT -> |.| -> range mean on the
+GPU.  The scipy peak pickers (``detect_peaks_rows`` ...) are host-side post-processing and stay out of scope
+(SURVEY.md 8f-4).
 """
 from __future__ import annotations
 
@@ -47,12 +52,51 @@ class DopplerAzimuthProcessor(_Processor):
             (self.angle_bins <= self.valid_angle_range[1])
         self.valid_angle_bins = self.angle_bins[self.valid_angle_mask]
 
+    def set_zoomed_fft_vel_bins(self, vel_range) -> np.ndarray:
+        """Velocity bins of the precise mode: ``num_vel_bins`` below zero and ``num_vel_bins`` above (:165-203)."""
+        n = self.vel_bins.size
+        neg = np.linspace(start=vel_range[0], stop=min(-1e-4, vel_range[1]), num=n if vel_range[0] <= 0 else 0,
+                          endpoint=False)
+        pos = np.linspace(start=max(1e-4, vel_range[0]), stop=vel_range[1], num=n if vel_range[1] > 0 else 0,
+                          endpoint=False)
+        self.zoomed_vel_bins = np.concatenate((neg, pos))
+        return self.zoomed_vel_bins
+
+    def _zoom_plan(self, vel_range) -> np.ndarray:
+        """Clamp / widen the velocity range (:234-246), set ``zoomed_vel_bins`` and return, per zoomed bin, the
+        frequency in cycles per chirp of the reference's ZoomFFT call for its half (:148-155,254-283); NaN where the
+        reference emits zeros because the half spans less than ``min_zoom_fft_vel_span``.
+
+        The caller's array is left untouched (the reference edits ``precise_vel_range`` in place)."""
+        cm = self.config_manager
+        vmax = cm.vel_max_m_s
+        vr = np.array(vel_range, dtype=float).ravel()
+        vr[0] = max(vr[0], -1 * vmax)
+        vr[1] = min(vr[1], vmax)
+        spread = 2 * self.min_zoom_fft_vel_span
+        if (vr[1] - vr[0]) < spread:
+            to_max, to_min = abs(vr[1] - vmax), abs(vr[0] + vmax)
+            if to_max > to_min:
+                vr[1] = vr[0] + spread
+            elif to_min > to_max:
+                vr[0] = vr[1] - spread
+        bins = self.set_zoomed_fft_vel_bins(vr)
+        fs = 1 / cm.vel_res_m_s
+        freq = np.full(bins.size, np.nan)
+        n_neg = int(np.count_nonzero(bins <= 0))
+        for vals, first, alias in ((bins[:n_neg], 0, 2 * vmax), (bins[n_neg:], n_neg, 0.0)):
+            m = vals.size
+            if m > 0 and np.abs(np.max(vals) - np.min(vals)) > self.min_zoom_fft_vel_span:
+                f1 = (np.min(vals) + alias) * fs / vmax
+                f2 = (np.max(vals) + alias) * fs / vmax
+                fz = fs * 2                       # the reference's "factor of 2" (:154-155)
+                freq[first:first + m] = f1 / fz + np.arange(m) * ((f2 - f1) / (m * fz))   # ZoomFFT(m, [f1, f2], fs=fz)
+        return freq
+
     def process(self, adc_cube: np.ndarray, rx_antennas: Union[np.ndarray, list] = [],
                 range_window: Union[np.ndarray, list] = [], shift_angle: bool = True, use_precise_fft: bool = False,
                 precise_vel_range=np.array([-0.25, 0.25]), **kwargs) -> np.ndarray:
         """float64 ``[vel bins, valid angle bins]``, averaged over the range bins inside ``range_window``."""
-        if use_precise_fft:
-            raise NotImplementedError("the ZoomFFT (precise) Doppler-azimuth mode is not accelerated yet")
         rx = np.array([]) if rx_antennas is None else np.asarray(rx_antennas).astype(int).ravel()
         rw = np.array([]) if range_window is None else np.asarray(range_window, dtype=float).ravel()
         cube = np.asarray(adc_cube)
@@ -73,6 +117,22 @@ class DopplerAzimuthProcessor(_Processor):
             flags |= _lib.ANGLE_NO_WINDOW
         if not shift_angle:
             flags |= _lib.ANGLE_NO_SHIFT
+        if use_precise_fft:
+            vr = np.array([-0.25, 0.25]) if precise_vel_range is None else precise_vel_range
+            freq = np.ascontiguousarray(self._zoom_plan(vr), dtype=np.float64)
+            M = int(freq.size)
+            n_used = int(self.vel_bins.size)        # zoom_fft keeps the first num_samples chirps (:159-160)
+            if M == 0:
+                return np.zeros((0, int(self.valid_angle_mask.sum())))
+            if n_used > C:
+                raise ValueError(f"CZT defined for length {n_used}, not {C}")     # scipy's error for the same input
+            d_out = bufs.get("da_out", M * A * 4)
+            _lib.check(ctx.lib.mmw_doppler_azimuth_zoom(
+                ctx.handle, d_cube.ptr, d_out.ptr, 1, V, S, C, A, int(keep[0]), int(keep[-1]) + 1, n_used,
+                freq.ctypes.data_as(_lib.C.POINTER(_lib.C.c_double)), M,
+                flags & (_lib.ANGLE_NO_WINDOW | _lib.ANGLE_NO_SHIFT)))
+            resp = d_out.download((M, A), np.float32).astype(np.float64)
+            return resp[:, self.valid_angle_mask]
         d_mag = bufs.get("da_mag", A * S * C * 4)
         d_out = bufs.get("da_out", C * A * 4)
         _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_cube.ptr, None, d_mag.ptr, 1, V, S, C, A, flags))

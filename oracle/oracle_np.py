@@ -209,6 +209,80 @@ def doppler_azimuth(cube, sc, num_angle_bins=64, rx_antennas=(), range_window=()
     return np.mean(resp[:, :, valid], axis=0)                               # :486-489
 
 
+# f-2b  DopplerAzimuthProcessor.process(use_precise_fft=True) -- processors/doppler_azimuth_resp.py:130-294
+def zoomed_vel_plan(sc, vel_range, min_zoom_fft_vel_span=0.1):
+    """-> (zoomed_vel_bins, freq): the Doppler bins of the precise mode and, for each of them, the frequency in
+    cycles per chirp that the reference's two ZoomFFT calls evaluate (NaN where it emits a zero row instead).
+
+    The input range is NOT modified (the reference clamps/widens the caller's array in place, :234-246)."""
+    vmax, vres = sc["vel_max_m_s"], sc["vel_res_m_s"]
+    _, vel_bins = rd_bins(sc)
+    nvb = vel_bins.size
+    vr = np.array(vel_range, dtype=float)
+    vr[0] = max(vr[0], -vmax)                                               # :234-235
+    vr[1] = min(vr[1], vmax)
+    spread = 2 * min_zoom_fft_vel_span                                      # :238-246
+    if (vr[1] - vr[0]) < spread:
+        d_hi, d_lo = abs(vr[1] - vmax), abs(vr[0] + vmax)
+        if d_hi > d_lo:
+            vr[1] = vr[0] + spread
+        elif d_lo > d_hi:
+            vr[0] = vr[1] - spread
+    neg = np.linspace(vr[0], min(-1e-4, vr[1]), nvb if vr[0] <= 0 else 0, endpoint=False)   # :178-183
+    pos = np.linspace(max(1e-4, vr[0]), vr[1], nvb if vr[1] > 0 else 0, endpoint=False)     # :186-191
+    bins = np.concatenate((neg, pos))                                       # :194-201 (either part may be empty)
+    fs = 1.0 / vres                                                         # :148
+    freq = np.full(bins.size, np.nan)
+
+    def seg(vals, offset, shift):
+        m = vals.size
+        if m > 0 and abs(vals.max() - vals.min()) > min_zoom_fft_vel_span:  # :254-255, :272-273
+            lo, hi = vals.min() + shift, vals.max() + shift                 # :256-259 (negative half aliased up by 2 vmax)
+            f1, f2 = lo * fs / vmax, hi * fs / vmax                         # :151-152
+            fz = fs * 2                                                     # :155
+            # scipy.signal.ZoomFFT(n=m, fn=[f1, f2], fs=fz): a = exp(2j pi f1/fz), w = exp(-2j pi (f2-f1)/(m fz)),
+            # X[k] = sum_i x[i] a^-i w^(i k)
+            freq[offset:offset + m] = f1 / fz + np.arange(m) * ((f2 - f1) / (m * fz))
+
+    seg(bins[bins <= 0], 0, 2 * vmax)
+    seg(bins[bins > 0], int(np.sum(bins <= 0)), 0.0)
+    return bins, freq
+
+
+def doppler_azimuth_precise(cube, sc, num_angle_bins=64, rx_antennas=(), range_window=(), shift_angle=True,
+                            vel_range=(-0.25, 0.25), valid_angle_range=(np.deg2rad(-60), np.deg2rad(60)),
+                            standard_geometry=True, min_zoom_fft_vel_span=0.1):
+    """-> (resp [zoomed vel bins, valid angle bins], zoomed_vel_bins).  The zoom transform is evaluated directly,
+    X[k] = sum_i x[i] exp(-2j pi i f_k), which is what ZoomFFT computes by Bluestein's algorithm."""
+    rx = np.asarray(rx_antennas)
+    x = cube[rx] if rx.size > 0 else cube
+    V, S, C = x.shape
+    xw = x * np.hanning(S)[None, :, None] * np.hanning(C)[None, None, :]
+    if standard_geometry and sc["virtual_antennas_enabled"]:
+        xw = xw * np.hanning(V)[:, None, None]
+    rng_bins, _ = rd_bins(sc)
+    rw = np.asarray(range_window, dtype=float)
+    if rw.size == 0:
+        rw = np.array([0, sc["range_max_m"]])
+    r = np.fft.fft(xw, axis=1)[:, (rng_bins >= rw[0]) & (rng_bins <= rw[1]), :]
+    bins, freq = zoomed_vel_plan(sc, vel_range, min_zoom_fft_vel_span)
+    n_used = int(max(np.sum(bins <= 0), np.sum(bins > 0)))                  # data[:, :num_samples, :]  (:159-160)
+    if n_used > C:
+        raise ValueError("ZoomFFT defined for more chirps than the cube has")
+    data = np.zeros((r.shape[1], n_used, num_angle_bins), dtype=complex)    # [range, chirp, padded antenna]  (:228-229)
+    data[:, :, :V] = np.transpose(r, (1, 2, 0))[:, :n_used, :]
+    f = np.where(np.isnan(freq), 0.0, freq)
+    Z = np.exp(-2j * np.pi * np.outer(f, np.arange(n_used)))                # [bins, chirp]
+    Z[np.isnan(freq)] = 0.0                                                 # zero rows (:267, :285)
+    z = np.einsum("kc,sca->ska", Z, data)
+    resp = np.abs(np.fft.fft(z, axis=2))                                    # :161-162
+    if shift_angle:
+        resp = np.fft.fftshift(resp, axes=2)                                # :290-291
+    _, abins = angle_tables(num_angle_bins)
+    valid = (abins >= valid_angle_range[0]) & (abins <= valid_angle_range[1])
+    return np.mean(resp[:, :, valid], axis=0), bins
+
+
 # --------------------------------------------------------------------------
 # a13/a14  CFAR family -- detectors/base.py, ca_cfar.py, os_cfar.py, go_so_cfar.py
 # --------------------------------------------------------------------------

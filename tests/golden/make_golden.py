@@ -260,6 +260,17 @@ def gen_doppler_azimuth():
     rp = RangeProcessor(cm)
     z, zb = rp.zoom_fft(cube, range_start_m=0.6, range_stop_m=1.9, chirp_idx=3)
     d["zoom_mag"], d["zoom_bins"] = z, zb
+    # precise (ZoomFFT) Doppler mode; the reference edits precise_vel_range in place, so every call gets a fresh array
+    for tag, vr, kw in (("default", [-0.25, 0.25], {}),
+                        ("pos_only", [0.3, 1.2], {}),
+                        ("narrow", [-0.05, 0.02], {}),
+                        ("clamped", [-50.0, 50.0], {"shift_angle": False}),
+                        ("neg_sub", [-1.0, -0.2], {"rx_antennas": [4, 5, 8, 9], "range_window": [0.9, 2.0]})):
+        d["precise_" + tag] = p.process(cube, use_precise_fft=True, precise_vel_range=np.array(vr), **kw)
+        d["precise_" + tag + "_bins"] = np.array(p.zoomed_vel_bins)
+    d["precise_ods"] = p2.process(virt, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], use_precise_fft=True,
+                                  precise_vel_range=np.array([-0.25, 0.25]))
+    d["precise_ods_bins"] = np.array(p2.zoomed_vel_bins)
     np.savez_compressed(os.path.join(HERE, "doppler_azimuth.npz"), **d)
     print("doppler_azimuth.npz:", {k: v.shape for k, v in d.items()})
 

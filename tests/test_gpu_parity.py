@@ -563,8 +563,73 @@ def test_doppler_azimuth_processor(golden):
     for shift in (True, False):
         ref = O.doppler_azimuth(c3, sc3, rx_antennas=[0, 3, 4, 7], range_window=[2.0, 9.0], shift_angle=shift)
         assert rel_err(p3.process(c3, rx_antennas=[0, 3, 4, 7], range_window=[2.0, 9.0], shift_angle=shift), ref) <= SPEC_TOL
-    with pytest.raises(NotImplementedError):
-        p3.process(c3, use_precise_fft=True)
+
+
+def test_doppler_azimuth_precise_mode(golden):
+    """use_precise_fft=True against the imported reference's outputs (scipy ZoomFFT inside) and, at the headline
+    shape, against the oracle (reference: processors/doppler_azimuth_resp.py:130-294)."""
+    from mmwave_radar_processing_amd.processors import DopplerAzimuthProcessor
+    g = golden("doppler_azimuth.npz")
+    cm = make_cm(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    p = DopplerAzimuthProcessor(cm, num_angle_bins=64)
+    for tag, vr, kw in (("default", [-0.25, 0.25], {}), ("pos_only", [0.3, 1.2], {}), ("narrow", [-0.05, 0.02], {}),
+                        ("clamped", [-50.0, 50.0], {"shift_angle": False}),
+                        ("neg_sub", [-1.0, -0.2], {"rx_antennas": [4, 5, 8, 9], "range_window": [0.9, 2.0]})):
+        vr_in = np.array(vr)
+        got = p.process(cube, use_precise_fft=True, precise_vel_range=vr_in, **kw)
+        np.testing.assert_array_equal(vr_in, np.array(vr))               # the caller's array is not edited
+        np.testing.assert_allclose(p.zoomed_vel_bins, g["precise_" + tag + "_bins"], rtol=0, atol=1e-15)
+        assert got.shape == g["precise_" + tag].shape and got.dtype == np.float64
+        assert rel_err(got, g["precise_" + tag]) <= SPEC_TOL, tag
+    assert np.all(p.process(cube, use_precise_fft=True, precise_vel_range=[-0.05, 0.02])[:16] == 0)   # zero half
+    cm2 = ConfigManager()
+    cm2.load_cfg_text(sample_cfg_text(), array_geometry="ods")
+    p2 = DopplerAzimuthProcessor(cm2, num_angle_bins=64, valid_angle_range=[-1.04719755, 1.04719755])
+    virt = synth.synth_cube(202, (12, 63, 70))
+    got2 = p2.process(virt, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], use_precise_fft=True)
+    np.testing.assert_allclose(p2.zoomed_vel_bins, g["precise_ods_bins"], rtol=0, atol=1e-15)
+    assert rel_err(got2, g["precise_ods"]) <= SPEC_TOL
+    cm3 = make_cm(synth.SYNTH_CFG_256x128x12)
+    sc3 = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    c3 = synth.synth_cube(8)
+    p3 = DopplerAzimuthProcessor(cm3)
+    for shift, vr in ((True, [-0.25, 0.25]), (False, [-1.5, 0.6])):
+        ref, bins = O.doppler_azimuth_precise(c3, sc3, range_window=[2.0, 9.0], shift_angle=shift, vel_range=vr)
+        got = p3.process(c3, range_window=[2.0, 9.0], shift_angle=shift, use_precise_fft=True, precise_vel_range=vr)
+        np.testing.assert_allclose(p3.zoomed_vel_bins, bins, rtol=0, atol=1e-15)
+        assert got.shape == (256, ref.shape[1]) and rel_err(got, ref) <= SPEC_TOL
+
+
+def test_doppler_azimuth_zoom_batch_and_errors():
+    """C entry on a batch of frames: frame f of the batch == the single-frame call; argument checks."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, V, S, C, A, M = 3, 8, 64, 32, 64, 40
+    cubes = np.stack([synth.synth_cube(300 + f, (V, S, C)) for f in range(F)]).astype(np.complex64)
+    freq = np.linspace(-0.2, 0.3, M)
+    freq[5] = np.nan
+    bufs = _lib.BufferSet(ctx)
+    d_in = bufs.get("in", cubes.nbytes)
+    d_in.upload(cubes)
+    d_out = bufs.get("out", F * M * A * 4)
+    fp = freq.ctypes.data_as(_lib.C.POINTER(_lib.C.c_double))
+    _lib.check(L.mmw_doppler_azimuth_zoom(h, d_in.ptr, d_out.ptr, F, V, S, C, A, 3, 50, C - 2, fp, M, 0))
+    batch = d_out.download((F, M, A), np.float32)
+    assert np.all(batch[:, 5] == 0) and np.all(batch[:, 6] > 0)
+    Z = np.exp(-2j * np.pi * np.outer(np.where(np.isnan(freq), 0, freq), np.arange(C - 2)))
+    Z[5] = 0
+    for f in range(F):
+        x = cubes[f].astype(complex) * np.hanning(S)[None, :, None] * np.hanning(C)[None, None, :] * np.hanning(V)[:, None, None]
+        r = np.fft.fft(x, axis=1)[:, 3:50, :C - 2]                       # [V, kept range, chirps used]
+        y = np.einsum("kc,vsc->skv", Z, r)
+        ref = np.mean(np.abs(np.fft.fftshift(np.fft.fft(y, n=A, axis=2), axes=2)), axis=0)
+        assert rel_err(batch[f], ref) <= SPEC_TOL
+    assert L.mmw_doppler_azimuth_zoom(h, d_in.ptr, d_out.ptr, F, V, S, C, A, 3, 50, C + 1, fp, M, 0) == _lib.MMW_ERR_INVALID
+    assert L.mmw_doppler_azimuth_zoom(h, d_in.ptr, d_out.ptr, F, V, S, C, A, 10, 10, C, fp, M, 0) == _lib.MMW_ERR_INVALID
+    assert L.mmw_doppler_azimuth_zoom(h, d_in.ptr, d_out.ptr, F, V, S, C, A, 0, S, C, fp, M, 1) == _lib.MMW_ERR_INVALID
+    _lib.check(L.mmw_doppler_azimuth_zoom(h, d_in.ptr, d_out.ptr, 0, V, S, C, A, 0, S, C, fp, M, 0))
+    bufs.free()
 
 
 def test_processor_protocol_state_and_registries():

@@ -179,6 +179,27 @@ def test_doppler_azimuth_coarse_path(golden):
                             valid_angle_range=(-1.04719755, 1.04719755), standard_geometry=False), g["ods_sub"])
 
 
+def test_doppler_azimuth_precise_path(golden):
+    """use_precise_fft=True: two scipy ZoomFFT calls inside the reference (doppler_azimuth_resp.py:130-294)."""
+    g = golden("doppler_azimuth.npz")
+    sc = O.cfg_scalars(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    cube = synth.synth_cube(101, (12, 32, 16))
+    for tag, vr, kw in (("default", [-0.25, 0.25], {}), ("pos_only", [0.3, 1.2], {}), ("narrow", [-0.05, 0.02], {}),
+                        ("clamped", [-50.0, 50.0], {"shift_angle": False}),
+                        ("neg_sub", [-1.0, -0.2], {"rx_antennas": [4, 5, 8, 9], "range_window": [0.9, 2.0]})):
+        resp, bins = O.doppler_azimuth_precise(cube, sc, vel_range=vr, **kw)
+        np.testing.assert_allclose(bins, g["precise_" + tag + "_bins"], rtol=0, atol=1e-15)
+        close(resp, g["precise_" + tag], 1e-10)
+    assert np.all(g["precise_narrow"][:16] == 0) and np.all(g["precise_narrow"][16:] > 0)   # zero rows of the short half
+    with open(os.path.join(GOLDEN, "cfg_scalars.json")) as f:
+        sc2 = O.cfg_scalars("\n".join(json.load(f)["6843_RadVel_ods_20Hz.cfg"]["lines"]))
+    virt = synth.synth_cube(202, (12, 63, 70))
+    resp, bins = O.doppler_azimuth_precise(virt, sc2, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0],
+                                           valid_angle_range=(-1.04719755, 1.04719755), standard_geometry=False)
+    np.testing.assert_allclose(bins, g["precise_ods_bins"], rtol=0, atol=1e-15)
+    close(resp, g["precise_ods"], 1e-10)
+
+
 def test_range_zoom_matches_reference_zoomfft(golden):
     g = golden("doppler_azimuth.npz")
     sc = O.cfg_scalars(synth.synth_cfg_text(num_samples=32, num_loops=16))

@@ -100,6 +100,24 @@ def main():
                                       ants, n_ant, A, 1))
     run("detect_batch_config3", detect_batch, F * (2 * cube_b + S * C * 4))
     res["mean_detections_per_frame"] = float(d_cnt.download((F,), np.int32).mean())
+    # ---- Doppler-azimuth: coarse (3-D chain + range mean) and precise (zoom transform, 2 x 128 bins) modes
+    Fz = min(F, 64)
+    d_mag3 = ctx.alloc(Fz * A * S * C * 4)
+    d_da = ctx.alloc(Fz * 2 * C * A * 4)
+
+    def dopaz_coarse():
+        _lib.check(L.mmw_chain3d(ctx.handle, d_in.ptr, None, d_mag3.ptr, Fz, V, S, C, A, 1))
+        _lib.check(L.mmw_mean_over_range(ctx.handle, d_mag3.ptr, d_da.ptr, Fz, A, S, C, 0, S))
+    run("dopaz_coarse", dopaz_coarse, Fz * (cube_b + out_b // 2))
+    if "dopaz_coarse" in res:
+        res["dopaz_coarse"]["us_per_frame"] = round(1e3 * res["dopaz_coarse"]["ms"] / Fz, 3)
+    import ctypes as ct
+    zf = np.concatenate((np.linspace(0.974, 1.0, C, endpoint=False), np.linspace(0.0, 0.026, C, endpoint=False)))
+    run("dopaz_zoom_256bins", lambda: _lib.check(L.mmw_doppler_azimuth_zoom(
+        ctx.handle, d_in.ptr, d_da.ptr, Fz, V, S, C, A, 0, S, C, zf.ctypes.data_as(ct.POINTER(ct.c_double)), 2 * C, 0)),
+        8.0 * Fz * V * S * C * 2 * C)                          # zoom-transform flops -> GFLOP/s
+    if "dopaz_zoom_256bins" in res:
+        res["dopaz_zoom_256bins"]["us_per_frame"] = round(1e3 * res["dopaz_zoom_256bins"]["ms"] / Fz, 3)
     # ---- beamformers (BASELINE config 4 shapes): complex GEMM on f32 MFMA, MVDR on f64 MFMA
     Sb, Eb, Tb = 256, 256, 64
     rng = np.random.default_rng(1)
@@ -115,7 +133,6 @@ def main():
     d_Xc = ctx.alloc(Vc * Rc * Kc * 8)
     d_Xc.upload((rng.standard_normal((Vc, Rc, Kc)) + 1j * rng.standard_normal((Vc, Rc, Kc))).astype(np.complex64))
     th = np.linspace(-1.3, 1.3, Tc)
-    import ctypes as ct
     d_Pc = ctx.alloc(Rc * Tc * 4)
     run("capon_12x512x128_T181", lambda: _lib.check(L.mmw_capon(ctx.handle, d_Xc.ptr, th.ctypes.data_as(ct.POINTER(ct.c_double)),
                                                                 d_Pc.ptr, Vc, Rc, Kc, Tc, 1e-3)),
