@@ -53,7 +53,7 @@ struct ProfileSlot {
     int launches = 0;
 };
 
-enum TableKind { TAB_TWIDDLE = 0, TAB_HANN = 1, TAB_HAMMING = 2 };
+enum TableKind { TAB_TWIDDLE = 0, TAB_HANN = 1, TAB_HAMMING = 2, TAB_DFTMAT = 3 };   // DFTMAT: W_N^(jk), [N][N]
 
 struct PendingSpan {
     const char *family;
@@ -107,9 +107,10 @@ template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **
         *out = it->second;
         return MMW_OK;
     }
-    const size_t elems = (kind == TAB_TWIDDLE) ? 2 * (size_t)N : (size_t)N;
+    const size_t elems = (kind == TAB_TWIDDLE) ? 2 * (size_t)N : (kind == TAB_DFTMAT ? 2 * (size_t)N * N : (size_t)N);
     std::vector<T> h(elems);
-    if (kind == TAB_TWIDDLE) {
+    if (kind == TAB_TWIDDLE || kind == TAB_DFTMAT) {
+        std::vector<T> w(2 * (size_t)N);
         for (int m = 0; m < N; ++m) {
             // exact octant symmetries keep W^0, W^(N/4), ... exact
             const long double ang = -2.0L * M_PIl * (long double)m / (long double)N;
@@ -119,8 +120,18 @@ template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **
                 c = (q == 0) ? 1.0L : (q == 2 ? -1.0L : 0.0L);
                 s = (q == 1) ? -1.0L : (q == 3 ? 1.0L : 0.0L);
             }
-            h[2 * m] = (T)c;
-            h[2 * m + 1] = (T)s;
+            w[2 * m] = (T)c;
+            w[2 * m + 1] = (T)s;
+        }
+        if (kind == TAB_TWIDDLE) {
+            h = w;
+        } else {
+            for (int k = 0; k < N; ++k)
+                for (int j = 0; j < N; ++j) {
+                    const int m = (int)(((long)j * k) % N);
+                    h[2 * ((size_t)k * N + j)] = w[2 * m];
+                    h[2 * ((size_t)k * N + j) + 1] = w[2 * m + 1];
+                }
         }
     } else {
         for (int i = 0; i < N; ++i) h[i] = (T)np_window(kind, i, N);

@@ -2,6 +2,7 @@
 #include "mmw_ctx.h"
 #include "mmw_fft_generic.h"
 #include "mmw_fft_fused.h"
+#include "mmw_fft_mixed.h"
 #include "mmw_cfar.h"
 #include "mmw_misc.h"
 #include "mmw_beamform.h"
@@ -296,6 +297,8 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
             MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C));
         else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
             MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C));
+        else if (rd_mixed_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0))
+            MMW_TRY((launch_rd_mixed<float, false>(ctx, d_cubes, (long)S * C, d_out, n_frames * V, S, C)));
         else
             MMW_TRY(range_doppler_generic(ctx, d_cubes, d_out, n_frames, V, S, C));
     }
@@ -316,6 +319,11 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && rx_idx >= 0 && rx_idx < V, "bad shape / rx_idx");
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "rd64");
+    RdMixedPlan mp;
+    if (!is_pow2(S) || !is_pow2(C))     // the power-of-two register FFTs of the generic path stay the faster choice
+        if (rd_mixed_plan(S, C, sizeof(cplx<double>), &mp) && !env_int("MMW_NO_MIXED_RD", 0))
+            return launch_rd_mixed<double, true>(ctx, (const cplx<float> *)d_cubes + (long)rx_idx * S * C,
+                                                 (long)V * S * C, d_mag, n_frames, S, C);
     MMW_TRY(ensure_scratch(ctx, (size_t)n_frames * S * C * sizeof(cplx<double>)));
     FftArgs a{};
     a.in = (const cplx<float> *)d_cubes + (long)rx_idx * S * C;
@@ -547,7 +555,7 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         if (waves >= 1) chunk_auto = (int)((long)waves * per_wave_num / per_wave_den);
     }
     if (chunk_auto < 1) chunk_auto = 1;
-    const bool fused_shape = (fused_rd_ok(S, C) || rd_lds_supported(S, C)) && A == 64 &&
+    const bool fused_shape = (fused_rd_ok(S, C) || rd_lds_supported(S, C) || rd_mixed_supported(S, C)) && A == 64 && ((long)S * C) % 2 == 0 &&
                              (V == 4 || V == 8 || V == 12 || V == 16);   // both stages have a single-pass kernel
     const int want_pipe = env_int("MMW_CHAIN_PIPELINE", -1);
     const bool pipelined = !d_rd && (want_pipe == 1 || (want_pipe == -1 && fused_shape && n_frames >= 2 * chunk_auto));

@@ -798,3 +798,46 @@ def test_overlapped_chain_on_an_lds_resident_shape():
         assert rel_err(got, O.fft3d_windowed(cube, A)) <= SPEC_TOL, f
     d_in.free()
     d_out.free()
+
+
+# every (samples, loops) plane of the cfg files the reference ships (tests/golden/cfg_scalars.json), plus a few more
+# factorisations: prime axis, radix-32 class, single-level axes, odd cell count
+MIXED_SHAPES = [(200, 40), (254, 50), (130, 50), (100, 30), (63, 115), (90, 100), (90, 80), (63, 100), (63, 127),
+                (127, 32), (63, 70), (70, 40), (512, 32), (64, 40), (100, 100), (120, 126), (512, 8),
+                (13, 11), (96, 23), (25, 49), (7, 3), (1, 6), (16, 1)]
+
+
+@pytest.mark.parametrize("S,C", MIXED_SHAPES)
+def test_mixed_radix_rd_kernel_all_shipped_shapes(S, C, monkeypatch):
+    """LDS-resident mixed-radix RD kernel (mmw_fft_mixed.h): spectrum against the oracle and against the generic
+    two-kernel path, float64 CFAR plane, and bit-exact CA-CFAR detections from it."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, V = 3, 4
+    n = V * S * C
+    cubes = np.stack([synth.synth_cube(7000 + 13 * S + C + f, (V, S, C)) for f in range(F)]).astype(np.complex64)
+    d_in, d_rd, d_mag = ctx.alloc(F * n * 8), ctx.alloc(F * n * 8), ctx.alloc(F * S * C * 8)
+    d_in.upload(cubes)
+    got = {}
+    for no_mixed in ("0", "1"):
+        monkeypatch.setenv("MMW_NO_MIXED_RD", no_mixed)
+        d_rd.zero()
+        d_mag.zero()
+        _lib.check(L.mmw_range_doppler(h, d_in.ptr, d_rd.ptr, None, F, V, S, C))
+        _lib.check(L.mmw_range_doppler_mag64(h, d_in.ptr, d_mag.ptr, F, V, S, C, 1))
+        got[no_mixed] = (d_rd.download((F, V, S, C), np.complex64), d_mag.download((F, S, C), np.float64))
+    monkeypatch.delenv("MMW_NO_MIXED_RD")
+    for f in range(F):
+        ref = O.range_doppler(cubes[f])
+        for key in ("0", "1"):
+            assert rel_err(got[key][0][f], ref) <= SPEC_TOL, key
+            assert rel_err(got[key][1][f], np.abs(ref[1])) <= 1e-12, key
+    if S >= 13 and C >= 13:
+        det = CaCFAR2D(num_train=(2, 2), num_guard=(1, 1), pfa=1e-3)
+        for f in range(F):
+            ref_mag = np.abs(O.range_doppler(cubes[f])[1])
+            want = O.ca_cfar_2d(ref_mag, (2, 2), (1, 1), 1e-3)[2]
+            have = det.detect(got["0"][1][f])
+            np.testing.assert_array_equal(np.asarray(have).reshape(-1, 2), np.array(want, dtype=np.int64).reshape(-1, 2))
+    for b in (d_in, d_rd, d_mag):
+        b.free()

@@ -10,8 +10,11 @@ from mmwave_radar_processing_amd import _lib  # noqa: E402
 ctx = _lib.Context(0)
 L = ctx.lib
 out = {}
-for (V, S, C) in ((12, 64, 64), (12, 128, 128), (12, 256, 128), (12, 512, 64), (12, 256, 256), (12, 512, 128),
-                  (12, 63, 70), (12, 100, 100), (8, 128, 64)):
+# power-of-two planes, then the (samples, loops) planes of the cfg files the reference ships
+SHAPES = ((12, 64, 64), (12, 128, 128), (12, 256, 128), (12, 512, 64), (12, 256, 256), (12, 512, 128), (8, 128, 64),
+          (12, 63, 70), (12, 63, 100), (12, 100, 100), (12, 90, 100), (12, 200, 40), (12, 254, 50), (12, 63, 127),
+          (4, 127, 32), (12, 130, 50), (12, 63, 115), (12, 70, 40), (12, 120, 126), (12, 512, 32), (12, 512, 8))
+for (V, S, C) in SHAPES:
     A = 64
     frames = max(8, min(2048, (1 << 30) // (V * S * C * 8 * 8)))
     n = V * S * C * 8
@@ -27,7 +30,16 @@ for (V, S, C) in ((12, 64, 64), (12, 128, 128), (12, 256, 128), (12, 512, 64), (
             fn()
         ms = ctx.timer_stop() / 5
         res[name] = {"us_per_frame": round(1e3 * ms / frames, 3), "GBs": round(frames * moved / ms / 1e6)}
+    if (S & (S - 1)) or (C & (C - 1)):       # same call on the generic two-kernel path, for comparison
+        os.environ["MMW_NO_MIXED_RD"] = "1"
+        fn = lambda: _lib.check(L.mmw_range_doppler(ctx.handle, d_in.ptr, d_rd.ptr, None, frames, V, S, C))
+        fn(); ctx.sync(); ctx.timer_start()
+        for _ in range(5):
+            fn()
+        ms = ctx.timer_stop() / 5
+        res["rd_generic_path"] = {"us_per_frame": round(1e3 * ms / frames, 3), "GBs": round(frames * 2 * n / ms / 1e6)}
+        del os.environ["MMW_NO_MIXED_RD"]
     out[f"{V}x{S}x{C}"] = dict(frames=frames, **res)
     for b in (d_in, d_rd, d_out):
         b.free()
-print(json.dumps(out, indent=1))
+print(json.dumps(out))
