@@ -107,8 +107,9 @@ template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **
         *out = it->second;
         return MMW_OK;
     }
-    const size_t elems = (kind == TAB_TWIDDLE) ? 2 * (size_t)N : (kind == TAB_DFTMAT ? 2 * (size_t)N * N : (size_t)N);
-    std::vector<T> h(elems);
+    // DFTMAT rows are read up to 8 entries past the end by dft_level_big: zero padding
+    const size_t elems = (kind == TAB_TWIDDLE) ? 2 * (size_t)N : (kind == TAB_DFTMAT ? 2 * ((size_t)N * N + 8) : (size_t)N);
+    std::vector<T> h(elems, (T)0);
     if (kind == TAB_TWIDDLE || kind == TAB_DFTMAT) {
         std::vector<T> w(2 * (size_t)N);
         for (int m = 0; m < N; ++m) {

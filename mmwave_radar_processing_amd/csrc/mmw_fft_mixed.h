@@ -12,9 +12,13 @@
 // for every lane of the wave (the output loop is uniform), so it arrives through the scalar cache and the inner
 // loop is pure FMA on VGPR x SGPR operands.  Cost per cell: (S1 + S2 + C1 + C2) complex MACs instead of the
 // S + C of a one-level direct DFT: 36 instead of 163 for the 63 x 100 plane.
-// Radix classes keep the register budget tight: class 0 = radices <= 16, class 1 = radices <= 32 (20, 23, 25),
-// class 2 = radices <= 16 plus the prime 127 (63 x 127, 127 x 32, 254 x 50 planes).
+// Radix classes keep the register budget tight: class 0 = radices <= 16, class 1 = radices <= 32 (20, 23, 25);
+// the planner (rd_mixed_plan) prices every factorisation and picks the cheapest kernel variant.
+// A factor above 32 (the prime 127 of the 63 x 127, 127 x 32 and 254 x 50 planes) cannot sit in registers; such a
+// level (dft_level_big) keeps its inputs in the LDS, gives every wave a block of 8 outputs whose matrix entries are
+// again wave-uniform scalars, and goes through the spare LDS behind the plane to stay hazard-free.
 #pragma once
+#include <algorithm>
 #include "mmw_fft_generic.h"
 
 namespace mmw {
@@ -28,20 +32,27 @@ struct RdMixedArgs {
     const void *win_s, *win_c;          // T[S], T[C]
     const void *tw_s, *tw_c;            // cplx<T>[S], cplx<T>[C]: W_N^m
     const void *m_s1, *m_s2, *m_c1, *m_c2;   // cplx<T>[R][R] DFT matrices
+    int tmp_cells;           // cells of spare LDS behind the plane
+    unsigned mg_C, mg_S, mg_s1, mg_c1;        // ceil(2^32 / d): e / d == umulhi(e, mg) for e < 2^32 / d (d > 1)
 };
+
+__device__ __forceinline__ int fast_div(int e, unsigned magic, int d) {
+    return d == 1 ? e : (int)__umulhi((unsigned)e, magic);
+}
+inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // One level: groups (o, i), i fastest over the lanes; element j of a group sits at lds[i*inner_stride +
 // o*outer_stride + j*estride].  Output k replaces element k, times tw[(o * k) mod N] when tw != nullptr.
-template <int R, typename T>
-__device__ __forceinline__ void dft_level(cplx<T> *lds, int tid, int n_inner, int inner_stride, int n_outer,
+template <int R, int NT, typename T>
+__device__ __forceinline__ void dft_level(cplx<T> *lds, int tid, int n_inner, unsigned mg_inner, int inner_stride, int n_outer,
                                           int outer_stride, int estride, const cplx<T> *__restrict__ Wm,
                                           const cplx<T> *__restrict__ tw, int N) {
     const int n_groups = n_inner * n_outer;
-    for (int g = tid; g < n_groups; g += 256) {
-        const int o = g / n_inner, i = g - o * n_inner;
+    for (int g = tid; g < n_groups; g += NT) {
+        const int o = fast_div(g, mg_inner, n_inner), i = g - o * n_inner;
         cplx<T> *p = lds + i * inner_stride + o * outer_stride;
         cplx<T> x[R];
 #pragma unroll
@@ -76,8 +87,66 @@ __device__ __forceinline__ void dft_level(cplx<T> *lds, int tid, int n_inner, in
     }
 }
 
-template <int CLS, typename T, typename... A> __device__ __forceinline__ void dft_level_rt(int R, A... a) {
-#define MMW_R(r) case r: dft_level<r, T>(a...); break;
+// Same contract as dft_level for a run-time radix R > 32.  Outputs of up to tmp_cells / R groups at a time are
+// collected in tmp[group][k] and copied back over the inputs after a barrier.  Wm is symmetric, so row j holds
+// W^(jk) for consecutive k; rows are read up to 7 entries past R (the table is padded).
+constexpr int BIG_KB = 8;
+template <int NT, typename T>
+__device__ __forceinline__ void dft_level_big(int R, cplx<T> *lds, cplx<T> *tmp, int tmp_cells, int tid, int n_inner,
+                                              unsigned mg_inner, int inner_stride, int n_outer, int outer_stride,
+                                              int estride, const cplx<T> *__restrict__ Wm,
+                                              const cplx<T> *__restrict__ tw, int N) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n_groups = n_inner * n_outer;
+    int chunk = tmp_cells / R;
+    if (chunk > n_groups) chunk = n_groups;
+    if (chunk < 1) return;      // the planner reserves at least 32 groups
+    for (int g0 = 0; g0 < n_groups; g0 += chunk) {
+        const int ng = (n_groups - g0 < chunk) ? n_groups - g0 : chunk;
+        for (int k0 = wave * BIG_KB; k0 < R; k0 += (NT / 64) * BIG_KB) {
+            for (int gl = lane; gl < ng; gl += 64) {
+                const int g = g0 + gl;
+                const int o = fast_div(g, mg_inner, n_inner), i = g - o * n_inner;
+                const cplx<T> *p = lds + i * inner_stride + o * outer_stride;
+                cplx<T> acc[BIG_KB];
+#pragma unroll
+                for (int kb = 0; kb < BIG_KB; ++kb) acc[kb] = cplx<T>{(T)0, (T)0};
+#pragma unroll 2
+                for (int j = 0; j < R; ++j) {
+                    const cplx<T> xj = p[j * estride];
+                    const cplx<T> xr = cplx<T>{xj.x, xj.x}, xi = cplx<T>{-xj.y, xj.y};
+                    const cplx<T> *w = Wm + (long)j * R + k0;       // wave-uniform: scalar loads
+#pragma unroll
+                    for (int kb = 0; kb < BIG_KB; ++kb) {
+                        const cplx<T> wk = w[kb];
+                        acc[kb] = __builtin_elementwise_fma(xr, wk, acc[kb]);
+                        acc[kb] = __builtin_elementwise_fma(xi, cplx<T>{wk.y, wk.x}, acc[kb]);
+                    }
+                }
+#pragma unroll
+                for (int kb = 0; kb < BIG_KB; ++kb) {
+                    const int k = k0 + kb;
+                    if (k < R) {
+                        cplx<T> v = acc[kb];
+                        if (tw) v = cmul(v, tw[(o * k) % N]);
+                        tmp[gl * R + k] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < ng * R; e += NT) {
+            const int gl = e / R, k = e - gl * R;
+            const int g = g0 + gl;
+            const int o = fast_div(g, mg_inner, n_inner), i = g - o * n_inner;
+            lds[i * inner_stride + o * outer_stride + k * estride] = tmp[e];
+        }
+        __syncthreads();
+    }
+}
+
+template <int CLS, int NT, typename T, typename... A> __device__ __forceinline__ void dft_level_rt(int R, A... a) {
+#define MMW_R(r) case r: dft_level<r, NT, T>(a...); break;
     if (R <= 16) {
         switch (R) {
             MMW_R(2) MMW_R(3) MMW_R(4) MMW_R(5) MMW_R(6) MMW_R(7) MMW_R(8) MMW_R(9) MMW_R(10) MMW_R(11) MMW_R(12)
@@ -90,51 +159,60 @@ template <int CLS, typename T, typename... A> __device__ __forceinline__ void df
             MMW_R(27) MMW_R(28) MMW_R(29) MMW_R(30) MMW_R(31) MMW_R(32)
             default: break;
         }
-    } else if constexpr (CLS == 2) {
-        if (R == 127) dft_level<127, T>(a...);
     }
 #undef MMW_R
 }
 
-template <typename T, int CLS, bool MAG>
-__global__ __launch_bounds__(256) void k_rd_mixed(RdMixedArgs a) {
+template <int CLS, bool BIG, int NT, typename T>
+__device__ __forceinline__ void dft_level_any(int R, cplx<T> *lds, cplx<T> *tmp, int tmp_cells, int tid, int n_inner,
+                                              unsigned mg_inner, int inner_stride, int n_outer, int outer_stride,
+                                              int estride, const cplx<T> *Wm, const cplx<T> *tw, int N) {
+    if constexpr (BIG) {
+        if (R > 32) {       // ends with its own barrier
+            dft_level_big<NT, T>(R, lds, tmp, tmp_cells, tid, n_inner, mg_inner, inner_stride, n_outer, outer_stride, estride, Wm, tw, N);
+            return;
+        }
+    }
+    dft_level_rt<CLS, NT, T>(R, lds, tid, n_inner, mg_inner, inner_stride, n_outer, outer_stride, estride, Wm, tw, N);
+    __syncthreads();
+}
+
+template <typename T, int CLS, bool BIG, bool MAG, int NT>
+__global__ __launch_bounds__(NT) void k_rd_mixed(RdMixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<T> *lds = reinterpret_cast<cplx<T> *>(smem);          // [S][Cp]
     const int tid = threadIdx.x;
     const int S = a.S, C = a.C, Cp = a.Cp, cells = S * C;
     const cplx<float> *in = reinterpret_cast<const cplx<float> *>(a.in) + (long)blockIdx.x * a.in_plane_stride;
     const T *ws = reinterpret_cast<const T *>(a.win_s), *wc = reinterpret_cast<const T *>(a.win_c);
-    for (int e = tid; e < cells; e += 256) {
-        const int s = e / C, c = e - s * C;
+    for (int e = tid; e < cells; e += NT) {
+        const int s = fast_div(e, a.mg_C, C), c = e - s * C;
         const cplx<float> v = __builtin_nontemporal_load(in + e);
         const T w = ws[s] * wc[c];
         lds[s * Cp + c] = cplx<T>{(T)v.x * w, (T)v.y * w};
     }
     __syncthreads();
     typedef const cplx<T> *CP;
+    cplx<T> *tmp = lds + S * Cp;                 // spare LDS behind the plane (levels with a radix > 32 only)
     // range axis: element s = s2 * n1 + n2 lives in row s
-    dft_level_rt<CLS, T>(a.s1, lds, tid, C, 1, a.s2, Cp, a.s2 * Cp, (CP)a.m_s1, a.s2 > 1 ? (CP)a.tw_s : (CP) nullptr, S);
-    __syncthreads();
-    if (a.s2 > 1) {
-        dft_level_rt<CLS, T>(a.s2, lds, tid, C, 1, a.s1, a.s2 * Cp, Cp, (CP)a.m_s2, (CP) nullptr, S);
-        __syncthreads();
-    }
+    dft_level_any<CLS, BIG, NT, T>(a.s1, lds, tmp, a.tmp_cells, tid, C, a.mg_C, 1, a.s2, Cp, a.s2 * Cp, (CP)a.m_s1,
+                          a.s2 > 1 ? (CP)a.tw_s : (CP) nullptr, S);
+    if (a.s2 > 1)
+        dft_level_any<CLS, BIG, NT, T>(a.s2, lds, tmp, a.tmp_cells, tid, C, a.mg_C, 1, a.s1, a.s2 * Cp, Cp, (CP)a.m_s2, (CP) nullptr, S);
     // Doppler axis: element c = c2 * m1 + m2 lives in column c; lanes walk the rows (pitch Cp is odd)
-    dft_level_rt<CLS, T>(a.c1, lds, tid, S, Cp, a.c2, 1, a.c2, (CP)a.m_c1, a.c2 > 1 ? (CP)a.tw_c : (CP) nullptr, C);
-    __syncthreads();
-    if (a.c2 > 1) {
-        dft_level_rt<CLS, T>(a.c2, lds, tid, S, Cp, a.c1, a.c2, 1, (CP)a.m_c2, (CP) nullptr, C);
-        __syncthreads();
-    }
+    dft_level_any<CLS, BIG, NT, T>(a.c1, lds, tmp, a.tmp_cells, tid, S, a.mg_S, Cp, a.c2, 1, a.c2, (CP)a.m_c1,
+                          a.c2 > 1 ? (CP)a.tw_c : (CP) nullptr, C);
+    if (a.c2 > 1)
+        dft_level_any<CLS, BIG, NT, T>(a.c2, lds, tmp, a.tmp_cells, tid, S, a.mg_S, Cp, a.c1, a.c2, 1, (CP)a.m_c2, (CP) nullptr, C);
     // bin k = k1 + s1 k2 sits in row s2 k1 + k2 (same along the Doppler axis); fftshift: out[(d + C/2) % C] = X[d]
     const long obase = (long)blockIdx.x * cells;
     const int half = C / 2;
-    for (int e = tid; e < cells; e += 256) {
-        const int k = e / C, dd = e - k * C;
+    for (int e = tid; e < cells; e += NT) {
+        const int k = fast_div(e, a.mg_C, C), dd = e - k * C;
         int d = dd - half;
         if (d < 0) d += C;
-        const int k2 = k / a.s1, k1 = k - k2 * a.s1;
-        const int d2 = d / a.c1, d1 = d - d2 * a.c1;
+        const int k2 = fast_div(k, a.mg_s1, a.s1), k1 = k - k2 * a.s1;
+        const int d2 = fast_div(d, a.mg_c1, a.c1), d1 = d - d2 * a.c1;
         const cplx<T> v = lds[(a.s2 * k1 + k2) * Cp + a.c2 * d1 + d2];
         if constexpr (MAG)
             reinterpret_cast<T *>(a.out)[obase + e] = mag<T>(v);
@@ -144,47 +222,65 @@ __global__ __launch_bounds__(256) void k_rd_mixed(RdMixedArgs a) {
 }
 
 // ------------------------------------------------------------------ host side: factorisation and launch
-inline bool mixed_radix_ok(int r, int cls) {
-    if (r <= 16) return true;
-    if (cls == 1) return r <= 32;
-    if (cls == 2) return r == 127;
-    return false;
-}
-
-// N = n1 * n2 with both radices in the class, least (n1 + n2) plus a per-level overhead; n2 == 1: one level.
-inline bool mixed_axis(int N, int cls, int *n1, int *n2) {
+// N = n1 * n2 (n1 >= n2) with the least n1 + n2 plus a per-level overhead; n2 == 1: one level.  Radices up to
+// max_small run in registers, larger ones through dft_level_big when big_ok.
+inline int mixed_axis(int N, int max_small, bool big_ok, int *n1, int *n2) {
     int best = -1;
     for (int a = 1; a <= N; ++a) {
         if (N % a) continue;
         const int b = N / a;
-        if (a < b || !mixed_radix_ok(a, cls) || !mixed_radix_ok(b, cls)) continue;
-        const int cost = (b == 1) ? a + 3 : a + b + 6;
+        if (a < b || b > max_small) continue;
+        if (a > max_small && (a <= 32 || !big_ok)) continue;
+        const int ca = a > 32 ? 2 * a : a;      // a level out of the LDS costs about twice its MAC count
+        const int cost = (b == 1) ? ca + 3 : ca + b + 6;
         if (best < 0 || cost < best) {
             best = cost;
             *n1 = a;
             *n2 = b;
         }
     }
-    return best >= 0;
+    return best;     // -1: no factorisation in this class
 }
 
 struct RdMixedPlan {
-    int cls, s1, s2, c1, c2, Cp;
+    int cls, big, s1, s2, c1, c2, Cp, tmp_cells;
     size_t lds_bytes;
 };
 
-inline bool rd_mixed_plan(int S, int C, size_t elem_bytes, RdMixedPlan *pl) {
+constexpr size_t MIXED_LDS_MAX = 160 * 1024;
+
+// Cheapest of the four kernel variants (radices <= 16 or <= 32 in registers, with or without a big level).
+inline bool rd_mixed_plan(int S, int C, size_t elem_bytes, RdMixedPlan *out) {
     if (S < 1 || C < 1 || (long)S * C > (1 << 20)) return false;
-    pl->Cp = C | 1;
-    pl->lds_bytes = (size_t)S * pl->Cp * elem_bytes;
-    if (pl->lds_bytes > 160 * 1024) return false;
-    const int n_cls = (elem_bytes > 8 || !tune_int("MMW_MIXED_CLS2", 0)) ? 2 : 3;   // radix 127 spills: off by default
-    for (int cls = 0; cls < n_cls; ++cls)
-        if (mixed_axis(S, cls, &pl->s1, &pl->s2) && mixed_axis(C, cls, &pl->c1, &pl->c2)) {
-            pl->cls = cls;
-            return true;
+    const int Cp = C | 1;
+    const size_t plane = (size_t)S * Cp * elem_bytes;
+    if (plane > MIXED_LDS_MAX) return false;
+    const int spare = (int)((MIXED_LDS_MAX - plane) / elem_bytes);
+    int best = -1;
+    for (int cls = 0; cls < 2; ++cls)
+        for (int big = 0; big < 2; ++big) {
+            RdMixedPlan pl{};
+            const int max_small = cls == 0 ? 16 : 32;
+            const int cs = mixed_axis(S, max_small, big, &pl.s1, &pl.s2), cc = mixed_axis(C, max_small, big, &pl.c1, &pl.c2);
+            if (cs < 0 || cc < 0) continue;
+            const int r_big = std::max(pl.s1 > 32 ? pl.s1 : 0, pl.c1 > 32 ? pl.c1 : 0);
+            if (big && !r_big) continue;                        // same plan as the variant without the big level
+            if (r_big && spare < 32 * r_big) continue;          // a big level wants >= half a wave of groups in the spare LDS
+            const int cost = (cs + cc) * 8 + cls;               // ties: the leaner register class
+            if (best >= 0 && cost >= best) continue;
+            best = cost;
+            pl.cls = cls;
+            pl.big = r_big ? 1 : 0;
+            pl.Cp = Cp;
+            // spare LDS for the big levels: all their groups if they fit, at most two waves of groups
+            int g_big = 0;
+            if (pl.s1 > 32) g_big = std::max(g_big, C * pl.s2);
+            if (pl.c1 > 32) g_big = std::max(g_big, S * pl.c2);
+            pl.tmp_cells = r_big ? std::min(spare, std::min(128, g_big) * r_big) : 0;
+            pl.lds_bytes = plane + (size_t)pl.tmp_cells * elem_bytes;
+            *out = pl;
         }
-    return false;
+    return best >= 0;
 }
 
 inline bool rd_mixed_supported(int S, int C) {
@@ -210,6 +306,11 @@ int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
     a.s2 = pl.s2;
     a.c1 = pl.c1;
     a.c2 = pl.c2;
+    a.tmp_cells = pl.tmp_cells;
+    a.mg_C = div_magic(C);
+    a.mg_S = div_magic(S);
+    a.mg_s1 = div_magic(pl.s1);
+    a.mg_c1 = div_magic(pl.c1);
     MMW_TRY(get_table<T>(ctx, TAB_HANN, S, &a.win_s));
     MMW_TRY(get_table<T>(ctx, TAB_HANN, C, &a.win_c));
     MMW_TRY(get_table<T>(ctx, TAB_TWIDDLE, S, &a.tw_s));
@@ -218,19 +319,32 @@ int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
     MMW_TRY(get_table<T>(ctx, TAB_DFTMAT, pl.s2, &a.m_s2));
     MMW_TRY(get_table<T>(ctx, TAB_DFTMAT, pl.c1, &a.m_c1));
     MMW_TRY(get_table<T>(ctx, TAB_DFTMAT, pl.c2, &a.m_c2));
-    auto go = [&](auto kern) -> int {
+    auto go = [&](auto kern, int nt) -> int {
         if (pl.lds_bytes > 64 * 1024)
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
-        hipLaunchKernelGGL(kern, dim3(planes), dim3(256), pl.lds_bytes, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3(planes), dim3(nt), pl.lds_bytes, ctx->stream, a);
         return check_launch("rd_mixed");
     };
-    switch (pl.cls) {
-        case 0: return go(k_rd_mixed<T, 0, MAG>);
-        case 1: return go(k_rd_mixed<T, 1, MAG>);
-        default:
-            if constexpr (sizeof(T) == 4) return go(k_rd_mixed<T, 2, MAG>);
-            return set_error(MMW_ERR_UNSUPPORTED, "radix class 2 is float32 only");
+    // Workgroup size: 256 threads while the LDS lets several planes share a CU; when the plane (or the spare LDS of
+    // a big level) leaves room for one or two workgroups only, more waves per plane hide the LDS / scalar-load
+    // latency instead.  The register budget of the class caps it (class 1 holds 32 complex values per thread).
+    const int wgs = (int)(MIXED_LDS_MAX / pl.lds_bytes);
+    if constexpr (sizeof(T) == 4) {
+        const bool wide = pl.big || wgs < tune_int("MMW_MIXED_WIDE_BELOW", 3);
+        switch (pl.cls * 2 + pl.big) {
+            case 0: return wide ? go(k_rd_mixed<T, 0, false, MAG, 1024>, 1024) : go(k_rd_mixed<T, 0, false, MAG, 256>, 256);
+            case 1: return go(k_rd_mixed<T, 0, true, MAG, 1024>, 1024);
+            case 2: return wide ? go(k_rd_mixed<T, 1, false, MAG, 512>, 512) : go(k_rd_mixed<T, 1, false, MAG, 256>, 256);
+            default: return go(k_rd_mixed<T, 1, true, MAG, 512>, 512);
+        }
+    } else {
+        switch (pl.cls * 2 + pl.big) {
+            case 0: return go(k_rd_mixed<T, 0, false, MAG, 512>, 512);
+            case 1: return go(k_rd_mixed<T, 0, true, MAG, 512>, 512);
+            case 2: return go(k_rd_mixed<T, 1, false, MAG, 256>, 256);
+            default: return go(k_rd_mixed<T, 1, true, MAG, 256>, 256);
+        }
     }
 }
 

@@ -804,7 +804,7 @@ def test_overlapped_chain_on_an_lds_resident_shape():
 # factorisations: prime axis, radix-32 class, single-level axes, odd cell count
 MIXED_SHAPES = [(200, 40), (254, 50), (130, 50), (100, 30), (63, 115), (90, 100), (90, 80), (63, 100), (63, 127),
                 (127, 32), (63, 70), (70, 40), (512, 32), (64, 40), (100, 100), (120, 126), (512, 8),
-                (13, 11), (96, 23), (25, 49), (7, 3), (1, 6), (16, 1)]
+                (13, 11), (96, 23), (25, 49), (7, 3), (1, 6), (16, 1), (37, 41), (74, 10), (1024, 8)]
 
 
 @pytest.mark.parametrize("S,C", MIXED_SHAPES)
