@@ -326,14 +326,17 @@ int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
         hipLaunchKernelGGL(kern, dim3(planes), dim3(nt), pl.lds_bytes, ctx->stream, a);
         return check_launch("rd_mixed");
     };
-    // Workgroup size: 256 threads while the LDS lets several planes share a CU; when the plane (or the spare LDS of
-    // a big level) leaves room for one or two workgroups only, more waves per plane hide the LDS / scalar-load
-    // latency instead.  The register budget of the class caps it (class 1 holds 32 complex values per thread).
+    // Workgroup size: the register budget allows 24 waves per CU in class 0 (78 VGPRs) and 12 in class 1; the LDS
+    // footprint decides how many planes share a CU, so the threads per plane are chosen to fill those waves
+    // (measured on 63x100: 256 threads 0.68, 512 threads 0.53 us/frame; on 120x126: 256 -> 1024 threads 4.1 -> 1.7).
     const int wgs = (int)(MIXED_LDS_MAX / pl.lds_bytes);
     if constexpr (sizeof(T) == 4) {
         const bool wide = pl.big || wgs < tune_int("MMW_MIXED_WIDE_BELOW", 3);
         switch (pl.cls * 2 + pl.big) {
-            case 0: return wide ? go(k_rd_mixed<T, 0, false, MAG, 1024>, 1024) : go(k_rd_mixed<T, 0, false, MAG, 256>, 256);
+            case 0:
+                if (wide) return go(k_rd_mixed<T, 0, false, MAG, 1024>, 1024);
+                if (wgs < 6) return go(k_rd_mixed<T, 0, false, MAG, 512>, 512);
+                return go(k_rd_mixed<T, 0, false, MAG, 256>, 256);
             case 1: return go(k_rd_mixed<T, 0, true, MAG, 1024>, 1024);
             case 2: return wide ? go(k_rd_mixed<T, 1, false, MAG, 512>, 512) : go(k_rd_mixed<T, 1, false, MAG, 256>, 256);
             default: return go(k_rd_mixed<T, 1, true, MAG, 512>, 512);

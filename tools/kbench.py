@@ -2,7 +2,7 @@
 """Per-kernel micro-benchmark (HIP events on the ctx stream): angle FFT, range-Doppler, float64 CFAR plane,
 CA-CFAR + compaction, next to the in-situ copy / write / read ceilings of the same device.
 
-    python tools/kbench.py [--frames 512] [--reps 10]
+    python tools/kbench.py [--frames 512] [--reps 10] [--shape 12,63,100]
 Prints one JSON object; `GB/s` figures use ALGORITHMIC bytes: a kernel's compulsory read + write.
 """
 import argparse
@@ -32,14 +32,18 @@ def main():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--shape", default="", help="V,S,C of the cube (default: the headline 12,256,128)")
     args = ap.parse_args()
+    global V, S, C
+    if args.shape:
+        V, S, C = (int(x) for x in args.shape.split(","))
     F = args.frames
     ctx = _lib.Context(0)
     L = ctx.lib
     cube_b, out_b = V * S * C * 8, A * S * C * 8
     d_in, d_rd, d_out = ctx.alloc(F * cube_b), ctx.alloc(F * cube_b), ctx.alloc(F * out_b)
     _lib.check(L.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 99, 8, 30.0))
-    res = {"frames": F}
+    res = {"frames": F, "shape": [V, S, C]}
     want = set(args.only.split(",")) if args.only else None
 
     def run(name, fn, bytes_moved):
