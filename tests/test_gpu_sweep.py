@@ -22,13 +22,16 @@ def _oracle_dets(cube):
     return O.rd_detect_2d(cube)[2]
 
 
-def test_detection_indices_bit_exact_over_many_frames():
-    n_frames = int(os.environ.get("MMW_SWEEP_FRAMES", "96"))
+# the headline cube (fused register-resident RD kernel) and the shape of the 6843 ods cfgs the reference ships
+# (63 samples x 100 loops: mixed-radix LDS kernel, float64 CFAR plane through k_rd_mixed<double>)
+@pytest.mark.parametrize("shape,scale", [((12, 256, 128), 1), ((12, 63, 100), 4)])
+def test_detection_indices_bit_exact_over_many_frames(shape, scale):
+    n_frames = int(os.environ.get("MMW_SWEEP_FRAMES", "96")) * scale
     procs = int(os.environ.get("MMW_SWEEP_PROCS", "4"))
     cm = ConfigManager()
-    cm.load_cfg_text(synth.SYNTH_CFG_256x128x12)
-    batch = min(n_frames, 256)
-    pipe = FramePipeline(cm, max_frames=batch, shape=(12, 256, 128), cfar=CaCFAR2D((4, 4), (2, 2), 1e-5))
+    cm.load_cfg_text(synth.synth_cfg_text(num_samples=shape[1], num_loops=shape[2]))
+    batch = min(n_frames, 256 * scale)
+    pipe = FramePipeline(cm, max_frames=batch, shape=shape, cfar=CaCFAR2D((4, 4), (2, 2), 1e-5))
     total_dets = mismatched = 0
     with get_context("spawn").Pool(procs) as pool:
         for f0 in range(0, n_frames, batch):
@@ -41,6 +44,6 @@ def test_detection_indices_bit_exact_over_many_frames():
                 total_dets += ref[f].shape[0]
                 if not np.array_equal(dets[f], ref[f]):
                     mismatched += 1
-    print(f"sweep: {n_frames} frames, {total_dets} detections, {mismatched} frames with any index difference")
+    print(f"sweep {shape}: {n_frames} frames, {total_dets} detections, {mismatched} frames with any index difference")
     assert mismatched == 0
-    assert total_dets > 20 * n_frames
+    assert total_dets > 5 * n_frames
