@@ -226,6 +226,22 @@ def main():
         from oracle import oracle_np as O
         cube0 = d_in.download((V, S, C), np.complex64)
         got0 = d_out.download((A, S, C), np.complex64)
+        if "roofline" in out:
+            # what plain streaming kernels reach on this device, right now (16-B/lane grid-stride write and copy over
+            # 2 GiB of the output buffer, after frame 0 was saved): the practical ceiling next to the 8 TB/s spec peak
+            nb = min(F * A * S * C * 8, 2 << 30) // 32 * 32
+            insitu = {}
+            for name, mode, moved in (("write", 1, nb), ("copy", 0, nb)):
+                span = nb if mode == 1 else nb // 2
+                call = lambda: _lib.check(ctx.lib.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr + (0 if mode == 1 else span),
+                                                                 span, mode, 0))
+                call()
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(5):
+                    call()
+                insitu[name + "_GBs"] = moved / (ctx.timer_stop() / 5) / 1e6
+            out["roofline"]["insitu_streaming_ceiling"] = insitu
         ref0 = O.fft3d_windowed(cube0, A)
         out["parity_max_rel_err_frame0"] = float(np.max(np.abs(got0 - ref0)) / np.max(np.abs(ref0)))
         if world == 1 and not args.no_cpu_baseline:

@@ -8,6 +8,7 @@
 #include "mmw_beamform.h"
 
 #include <algorithm>
+#include <memory>
 #include <cstdlib>
 
 using namespace mmw;
@@ -29,7 +30,9 @@ int abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
 }
 
 // Range FFT (windows on both axes folded into the load) then in-place Doppler FFT + fftshift.
-int range_doppler_generic(mmw_ctx *ctx, const void *d_cubes, void *d_out, int F, int V, int S, int C) {
+// Frames go through in chunks of ~MMW_RD_GENERIC_CHUNK_MB of output so that the Doppler pass finds the range
+// pass's result still in the 256 MB Infinity Cache instead of re-reading it from HBM.
+static int range_doppler_generic_chunk(mmw_ctx *ctx, const void *d_cubes, void *d_out, int F, int V, int S, int C) {
     FftArgs a{};
     a.in = d_cubes;
     a.out = d_out;
@@ -54,6 +57,18 @@ int range_doppler_generic(mmw_ctx *ctx, const void *d_cubes, void *d_out, int F,
     b.scale = 1.0;
     b.shift = 1;
     return launch_fft_axis<float, float>(ctx, b, C, true);
+}
+
+int range_doppler_generic(mmw_ctx *ctx, const void *d_cubes, void *d_out, int F, int V, int S, int C) {
+    const size_t cube_bytes = (size_t)V * S * C * sizeof(float2);
+    long chunk = (long)(((size_t)tune_int("MMW_RD_GENERIC_CHUNK_MB", 96) << 20) / cube_bytes);
+    if (chunk < 1) chunk = 1;
+    for (long f0 = 0; f0 < F; f0 += chunk) {
+        const int nf = (int)((F - f0 < chunk) ? F - f0 : chunk);
+        MMW_TRY(range_doppler_generic_chunk(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes,
+                                            (char *)d_out + (size_t)f0 * cube_bytes, nf, V, S, C));
+    }
+    return MMW_OK;
 }
 
 template <typename T>
@@ -117,7 +132,8 @@ int mmw_ctx_create(mmw_ctx **out, int device) {
     MMW_HIP(hipGetDeviceCount(&n));
     MMW_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
     MMW_HIP(hipSetDevice(device));
-    mmw_ctx *c = new mmw_ctx();
+    // released to the caller on success; any early return below tears the half-built context down again
+    std::unique_ptr<mmw_ctx, int (*)(mmw_ctx *)> c(new mmw_ctx(), mmw_ctx_destroy);
     c->device = device;
     hipDeviceProp_t prop;
     MMW_HIP(hipGetDeviceProperties(&prop, device));
@@ -132,19 +148,19 @@ int mmw_ctx_create(mmw_ctx **out, int device) {
     }
     MMW_HIP(hipEventCreate(&c->t0));
     MMW_HIP(hipEventCreate(&c->t1));
-    *out = c;
+    *out = c.release();
     return MMW_OK;
 }
 
 int mmw_ctx_destroy(mmw_ctx *ctx) {
     if (!ctx) return MMW_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tables) (void)hipFree(kv.second);
     for (void *p : ctx->owned) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    (void)hipEventDestroy(ctx->t0);
-    (void)hipEventDestroy(ctx->t1);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     drain_profile(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->q_rd) {
@@ -158,7 +174,7 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
         (void)hipStreamDestroy(ctx->q_rd);
         (void)hipStreamDestroy(ctx->q_ang);
     }
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MMW_OK;
 }
