@@ -108,6 +108,16 @@ int mmw_angle_fft(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames,
                   int V, int S, int C, int A, int flags);
 int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames,
                 int V, int S, int C, int A, int flags);
+/* Raw-cube variants: d_raw[F][num_rx][S][num_tx * loops] c64 as the DCA1000 delivers it; the virtual-array
+ *   de-interleave of VirtualArrayReformatter.process (virtual antenna tx * num_rx + rx = every num_tx-th chirp from
+ *   tx, processors/virtual_array_reformater.py:53-63) is folded into the first kernel's loads, so
+ *   mmw_range_doppler_raw == mmw_virtual_array_reformat + mmw_range_doppler and
+ *   mmw_chain3d_raw == mmw_virtual_array_reformat + mmw_chain3d without the extra pass over HBM
+ *   (V = num_rx * num_tx, C = loops; outputs as for the non-raw calls). */
+int mmw_range_doppler_raw(mmw_ctx *ctx, const void *d_raw, void *d_out, int n_frames, int num_rx, int num_tx,
+                          int S, int loops);
+int mmw_chain3d_raw(mmw_ctx *ctx, const void *d_raw, void *d_rd, void *d_out, int n_frames, int num_rx, int num_tx,
+                    int S, int loops, int A, int flags);
 /* mmw_dbs_gather: d_out[F][S][n_out] float32 = d_mag[F][h_ang_idx[i]][s][h_vel_idx[i]] -- the Doppler-beam-
  *   sharpening column pick of perform_dbs_sharpen (processors/range_angle_resp_dbs_enhanced.py:216-263); the
  *   nearest-bin index tables are computed by the host from its angle / velocity bin tables. */

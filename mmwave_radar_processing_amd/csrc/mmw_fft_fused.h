@@ -113,6 +113,38 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     return check_launch("angle64");
 }
 
+// Raw DCA-style cube [F][num_rx][S][num_tx * C] read in place of the virtual-array cube [F][V][S][C]: virtual
+// antenna v = tx * num_rx + rx takes every num_tx-th chirp starting at tx
+// (VirtualArrayReformatter.process, processors/virtual_array_reformater.py:53-63).  Element (s, c) of plane
+// p = frame * V + v sits at raw_plane(...)[(s * C + c) * ntx]; the three tx planes of one rx share cache lines.
+struct RawView {
+    int ntx, nrx;       // ntx <= 1: the input already is the virtual-array cube
+};
+// Workgroup -> plane for raw cubes.  The num_tx planes of one (frame, rx) pair read the same raw rows, so they are
+// given to workgroups b, b + 8, b + 16 ...: hardware dispatch is round-robin over the 8 XCDs, which puts them on the
+// SAME XCD at about the same time and the shared lines come out of that XCD's L2 instead of being fetched once per
+// XCD.  Grid = raw_grid(planes, rv) workgroups; a workgroup past the last pair gets -1.
+__host__ __device__ __forceinline__ long raw_grid(long planes, RawView rv) {
+    const long pairs = planes / rv.ntx;              // (frame, rx) pairs
+    return (pairs + 7) / 8 * 8 * rv.ntx;
+}
+__device__ __forceinline__ long raw_block_plane(long b, long planes, RawView rv) {
+    const long slot = b >> 3;
+    const int xcd = (int)(b & 7), tx = (int)(slot % rv.ntx);
+    const long g = (slot / rv.ntx) * 8 + xcd;
+    if (g >= planes / rv.ntx) return -1;
+    const long f = g / rv.nrx;
+    const int rx = (int)(g - f * rv.nrx);
+    return f * (rv.nrx * rv.ntx) + tx * rv.nrx + rx;
+}
+__device__ __forceinline__ const cplx<float> *raw_plane(const cplx<float> *in, long plane, int S, int C, RawView rv) {
+    const int V = rv.nrx * rv.ntx;
+    const long f = plane / V;
+    const int v = (int)(plane - f * V);
+    const int tx = v / rv.nrx, rx = v - tx * rv.nrx;
+    return in + ((f * rv.nrx + rx) * S) * (long)C * rv.ntx + tx;
+}
+
 // ------------------------------------------------------------------ fused range-Doppler, 256 x 128
 // k_rd_fused_256x128: one workgroup (1024 threads = 16 waves) transforms one [256 samples][128 chirps]
 // plane in a single pass over HBM (reads 256 KiB, writes 256 KiB; algorithmic 6.29 MB/frame for 12 planes).
@@ -129,12 +161,13 @@ constexpr int RD_S = 256, RD_C = 128, RD_PITCH = 152;
 constexpr int RD_LDS_MAIN = 128 * RD_PITCH;                       // complex elements (>= 8*16*128 for X1)
 constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8;           // + W128 table
 
-template <bool NTIN, int ABL = 0>   // ABL: timing-only ablations (1 no stores, 2 no loads, 3 neither)
+// RAW: the input is the raw [F][num_rx][256][num_tx * 128] cube (two 8-B loads per lane and row instead of one 16-B)
+template <bool NTIN, int ABL = 0, bool RAW = false>   // ABL: timing-only ablations (1 no stores, 2 no loads, 3 neither)
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
                                                             const cplx<float> *__restrict__ tw256,
-                                                            const cplx<float> *__restrict__ tw128) {
+                                                            const cplx<float> *__restrict__ tw128, RawView rv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
     cplx<float> *tw128_l = lds + RD_LDS_MAIN;
@@ -145,8 +178,14 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
     const float hc0 = hann_c[2 * l], hc1 = hann_c[2 * l + 1];
 
     {
-        const int plane = blockIdx.x;
+        int plane = blockIdx.x;
+        if constexpr (RAW) {
+            plane = (int)raw_block_plane(blockIdx.x, planes, rv);
+            if (plane < 0) return;
+        }
         const f32x4 *src = in + (long)plane * (RD_S * RD_C / 2);
+        const cplx<float> *rsrc = nullptr;
+        if constexpr (RAW) rsrc = raw_plane(reinterpret_cast<const cplx<float> *>(in), plane, RD_S, RD_C, rv);
         cplx<float> *dst = out + (long)plane * (RD_S * RD_C);
         // ---- step 0: load, window, range pass 1 (n = 16*n1 + w)
         cplx<float> y0[16], y1[16];
@@ -155,7 +194,11 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
             const int n = 16 * n1 + w;
             f32x4 v;
             if constexpr (ABL & 2) v = f32x4{(float)(n + l), (float)(n - l), (float)(n ^ l), 1.0f};
-            else v = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l) : src[n * (RD_C / 2) + l];
+            else if constexpr (RAW) {
+                const cplx<float> *e = rsrc + (long)(n * RD_C + 2 * l) * rv.ntx;
+                const cplx<float> a = e[0], b = e[rv.ntx];
+                v = f32x4{a.x, a.y, b.x, b.y};
+            } else v = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l) : src[n * (RD_C / 2) + l];
             const float hs = hann_s[n];
             y0[n1] = cplx<float>{v.x, v.y} * (hs * hc0);
             y1[n1] = cplx<float>{v.z, v.w} * (hs * hc1);
@@ -354,20 +397,28 @@ template <int S, int C> struct RdLds {
     static_assert(CELLS <= 16384 && CELLS % NT == 0 && VPT % R2S == 0 && VPT % R2C == 0, "plane must fit the scheme");
 };
 
-template <int S, int C>
+template <int S, int C, bool RAW = false>
 __global__ __launch_bounds__((RdLds<S, C>::NT)) void k_rd_lds(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                                const float *__restrict__ hann_s,
                                                                const float *__restrict__ hann_c,
                                                                const cplx<float> *__restrict__ tw_s_g,
-                                                               const cplx<float> *__restrict__ tw_c_g) {
+                                                               const cplx<float> *__restrict__ tw_c_g, RawView rv,
+                                                               int planes) {
     typedef RdLds<S, C> K;
     constexpr int NT = K::NT, P = K::P, R1S = K::R1S, R2S = K::R2S, R1C = K::R1C, R2C = K::R2C, VPT = K::VPT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
     cplx<float> *tw_s = lds + S * P, *tw_c = tw_s + S;
     const int t = threadIdx.x;
-    const f32x4 *src = in + (long)blockIdx.x * (K::CELLS / 2);
-    cplx<float> *dst = out + (long)blockIdx.x * K::CELLS;
+    long plane = blockIdx.x;
+    if constexpr (RAW) {
+        plane = raw_block_plane(blockIdx.x, planes, rv);
+        if (plane < 0) return;
+    }
+    const f32x4 *src = in + plane * (K::CELLS / 2);
+    const cplx<float> *rsrc = nullptr;
+    if constexpr (RAW) rsrc = raw_plane(reinterpret_cast<const cplx<float> *>(in), plane, S, C, rv);
+    cplx<float> *dst = out + plane * K::CELLS;
     for (int i = t; i < S; i += NT) tw_s[i] = tw_s_g[i];
     for (int i = t; i < C; i += NT) tw_c[i] = tw_c_g[i];
     // ---- load + window
@@ -375,7 +426,12 @@ __global__ __launch_bounds__((RdLds<S, C>::NT)) void k_rd_lds(const f32x4 *__res
     for (int q = 0; q < VPT / 2; ++q) {
         const int idx = t + q * NT;                         // float4 index: two adjacent chirps of one sample row
         const int row = (2 * idx) / C, col = (2 * idx) % C;
-        const f32x4 v = __builtin_nontemporal_load(src + idx);
+        f32x4 v;
+        if constexpr (RAW) {
+            const cplx<float> *e = rsrc + (long)(2 * idx) * rv.ntx;
+            const cplx<float> a = e[0], b = e[rv.ntx];
+            v = f32x4{a.x, a.y, b.x, b.y};
+        } else v = __builtin_nontemporal_load(src + idx);
         const float w0 = hann_s[row] * hann_c[col], w1 = hann_s[row] * hann_c[col + 1];
         *reinterpret_cast<f32x4 *>(&lds[row * P + col]) = f32x4{v.x * w0, v.y * w0, v.z * w1, v.w * w1};
     }
@@ -462,20 +518,25 @@ __global__ __launch_bounds__((RdLds<S, C>::NT)) void k_rd_lds(const f32x4 *__res
     }
 }
 
-template <int S, int C> int launch_rd_lds_sc(mmw_ctx *ctx, const void *d_in, void *d_out, int planes) {
+template <int S, int C> int launch_rd_lds_sc(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, RawView rv) {
     const void *hs, *hc, *ts, *tc;
     MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &hs));
     MMW_TRY(get_table<float>(ctx, TAB_HANN, C, &hc));
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, S, &ts));
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, C, &tc));
     typedef RdLds<S, C> K;
-    if (K::LDS_BYTES > 64 * 1024)
-        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_lds<S, C>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
-    hipLaunchKernelGGL((k_rd_lds<S, C>), dim3(planes), dim3(K::NT), K::LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
-                       (cplx<float> *)d_out, (const float *)hs, (const float *)hc, (const cplx<float> *)ts,
-                       (const cplx<float> *)tc);
-    return check_launch("rd_lds");
+    auto go = [&](auto kern) -> int {
+        if (K::LDS_BYTES > 64 * 1024)
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        K::LDS_BYTES));
+        const unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)planes;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(K::NT), K::LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
+                           (cplx<float> *)d_out, (const float *)hs, (const float *)hc, (const cplx<float> *)ts,
+                           (const cplx<float> *)tc, rv, planes);
+        return check_launch("rd_lds");
+    };
+    if (rv.ntx > 1) return go(k_rd_lds<S, C, true>);
+    return go(k_rd_lds<S, C, false>);
 }
 
 // planes handled by k_rd_lds (S x C, both powers of two, S*C <= 16384)
@@ -490,8 +551,9 @@ inline bool rd_lds_supported(int S, int C) {
     return false;
 }
 
-inline int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C) {
-#define X(s, c) if (S == s && C == c) return launch_rd_lds_sc<s, c>(ctx, d_in, d_out, planes);
+inline int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C,
+                         RawView rv = RawView{1, 0}) {
+#define X(s, c) if (S == s && C == c) return launch_rd_lds_sc<s, c>(ctx, d_in, d_out, planes, rv);
     MMW_RD_LDS_SHAPES(X)
 #undef X
     return set_error(MMW_ERR_UNSUPPORTED, "no LDS-resident RD kernel for %dx%d", S, C);
@@ -499,7 +561,8 @@ inline int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes
 
 inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
 
-inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C) {
+inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C,
+                           RawView rv = RawView{1, 0}) {
     if (!rd_fused_supported(S, C)) return set_error(MMW_ERR_UNSUPPORTED, "fused RD kernel is 256x128 only");
     const void *hs, *hc, *t256, *t128;
     MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_S, &hs));
@@ -512,6 +575,14 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_fused_256x128<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
         ctx->rd_attr_set = true;
+    }
+    if (rv.ntx > 1) {            // raw cube: the de-interleave is folded into the row loads
+        auto kern = k_rd_fused_256x128<false, 0, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
+        hipLaunchKernelGGL(kern, dim3((unsigned)raw_grid(planes, rv)), dim3(1024), RD_LDS_BYTES, ctx->stream,
+                           (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                           (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
+        return check_launch("rd_fused_raw");
     }
     const int blocks = planes;   // one plane per workgroup: a persistent plane loop made hipcc hoist and spill
     // Standalone launches use the persistent variant with 8 rows prefetched (+12 %); inside the overlapped
@@ -535,7 +606,7 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
                                (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                               (const cplx<float> *)t256, (const cplx<float> *)t128);
+                               (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
         };
         if (abl == 1) launch(k_rd_fused_256x128<true, 1>);
         else if (abl == 2) launch(k_rd_fused_256x128<true, 2>);
@@ -545,11 +616,11 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
     if (tune_int("MMW_RD_NT", 1))
         hipLaunchKernelGGL(k_rd_fused_256x128<true>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
                            (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                           (const cplx<float> *)t256, (const cplx<float> *)t128);
+                           (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
     else
         hipLaunchKernelGGL(k_rd_fused_256x128<false>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
                            (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                           (const cplx<float> *)t256, (const cplx<float> *)t128);
+                           (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
     return check_launch("rd_fused");
 }
 

@@ -20,6 +20,7 @@
 #pragma once
 #include <algorithm>
 #include "mmw_fft_generic.h"
+#include "mmw_fft_fused.h"
 
 namespace mmw {
 
@@ -33,6 +34,8 @@ struct RdMixedArgs {
     const void *tw_s, *tw_c;            // cplx<T>[S], cplx<T>[C]: W_N^m
     const void *m_s1, *m_s2, *m_c1, *m_c2;   // cplx<T>[R][R] DFT matrices
     int tmp_cells;           // cells of spare LDS behind the plane
+    RawView raw;             // ntx > 1: `in` is the raw [F][nrx][S][ntx * C] cube (in_plane_stride unused)
+    long planes;             // raw only: planes in the launch (the grid is padded, see raw_block_plane)
     unsigned mg_C, mg_S, mg_s1, mg_c1;        // ceil(2^32 / d): e / d == umulhi(e, mg) for e < 2^32 / d (d > 1)
 };
 
@@ -183,11 +186,19 @@ __global__ __launch_bounds__(NT) void k_rd_mixed(RdMixedArgs a) {
     cplx<T> *lds = reinterpret_cast<cplx<T> *>(smem);          // [S][Cp]
     const int tid = threadIdx.x;
     const int S = a.S, C = a.C, Cp = a.Cp, cells = S * C;
-    const cplx<float> *in = reinterpret_cast<const cplx<float> *>(a.in) + (long)blockIdx.x * a.in_plane_stride;
+    const int ntx = a.raw.ntx > 1 ? a.raw.ntx : 1;       // element (s, c) at in[(s * C + c) * ntx]
+    long plane = blockIdx.x;
+    if (a.raw.ntx > 1) {
+        plane = raw_block_plane(blockIdx.x, a.planes, a.raw);
+        if (plane < 0) return;
+    }
+    const cplx<float> *in = a.raw.ntx > 1
+        ? raw_plane(reinterpret_cast<const cplx<float> *>(a.in), plane, S, C, a.raw)
+        : reinterpret_cast<const cplx<float> *>(a.in) + plane * a.in_plane_stride;
     const T *ws = reinterpret_cast<const T *>(a.win_s), *wc = reinterpret_cast<const T *>(a.win_c);
     for (int e = tid; e < cells; e += NT) {
         const int s = fast_div(e, a.mg_C, C), c = e - s * C;
-        const cplx<float> v = __builtin_nontemporal_load(in + e);
+        const cplx<float> v = __builtin_nontemporal_load(in + (long)e * ntx);
         const T w = ws[s] * wc[c];
         lds[s * Cp + c] = cplx<T>{(T)v.x * w, (T)v.y * w};
     }
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed(RdMixedArgs a) {
     if (a.c2 > 1)
         dft_level_any<CLS, BIG, NT, T>(a.c2, lds, tmp, a.tmp_cells, tid, S, a.mg_S, Cp, a.c1, a.c2, 1, (CP)a.m_c2, (CP) nullptr, C);
     // bin k = k1 + s1 k2 sits in row s2 k1 + k2 (same along the Doppler axis); fftshift: out[(d + C/2) % C] = X[d]
-    const long obase = (long)blockIdx.x * cells;
+    const long obase = plane * cells;
     const int half = C / 2;
     for (int e = tid; e < cells; e += NT) {
         const int k = fast_div(e, a.mg_C, C), dd = e - k * C;
@@ -291,7 +302,8 @@ inline bool rd_mixed_supported(int S, int C) {
 // planes x [S][C] complex64 at d_in (plane pitch in_plane_stride elements) -> d_out planes, contiguous:
 // T = float: complex64 spectrum; T = double, MAG: float64 magnitude (the CFAR plane).
 template <typename T, bool MAG>
-int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C) {
+int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C,
+                    RawView rv = RawView{1, 0}) {
     RdMixedPlan pl;
     if (!rd_mixed_plan(S, C, sizeof(cplx<T>), &pl))
         return set_error(MMW_ERR_UNSUPPORTED, "no mixed-radix RD plan for %dx%d", S, C);
@@ -307,6 +319,8 @@ int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
     a.c1 = pl.c1;
     a.c2 = pl.c2;
     a.tmp_cells = pl.tmp_cells;
+    a.raw = rv;
+    a.planes = planes;
     a.mg_C = div_magic(C);
     a.mg_S = div_magic(S);
     a.mg_s1 = div_magic(pl.s1);
@@ -323,7 +337,8 @@ int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
         if (pl.lds_bytes > 64 * 1024)
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
-        hipLaunchKernelGGL(kern, dim3(planes), dim3(nt), pl.lds_bytes, ctx->stream, a);
+        const unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)planes;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), pl.lds_bytes, ctx->stream, a);
         return check_launch("rd_mixed");
     };
     // Workgroup size: the register budget allows 24 waves per CU in class 0 (78 VGPRs) and 12 in class 1; the LDS

@@ -302,20 +302,29 @@ int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, in
 }
 
 // ------------------------------------------------------------------ FFT chain
+// rv.ntx > 1: d_cubes is the raw [F][num_rx][S][num_tx * C] cube and the virtual-array de-interleave is folded into
+// the load of the single-pass kernels (V == rv.ntx * rv.nrx).
 static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_mag_f32, int n_frames, int V,
-                             int S, int C) {
+                             int S, int C, RawView rv = RawView{1, 0}) {
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0, "bad shape");
     if (n_frames == 0) return MMW_OK;
     {
         ProfScope ps(ctx, "rd");
         if (fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
-            MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C));
+            MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
         else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
-            MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C));
+            MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
         else if (rd_mixed_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0))
-            MMW_TRY((launch_rd_mixed<float, false>(ctx, d_cubes, (long)S * C, d_out, n_frames * V, S, C)));
-        else
+            MMW_TRY((launch_rd_mixed<float, false>(ctx, d_cubes, (long)S * C, d_out, n_frames * V, S, C, rv)));
+        else if (rv.ntx > 1) {
+            // no single-pass kernel for this plane: de-interleave into the output buffer, then transform it in place
+            const long total = (long)n_frames * V * S * C;
+            hipLaunchKernelGGL(k_reformat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const float2 *)d_cubes, (float2 *)d_out, total, rv.nrx, rv.ntx, S, C);
+            MMW_TRY(check_launch("reformat"));
+            MMW_TRY(range_doppler_generic(ctx, d_out, d_out, n_frames, V, S, C));
+        } else
             MMW_TRY(range_doppler_generic(ctx, d_cubes, d_out, n_frames, V, S, C));
     }
     if (d_mag_f32) MMW_TRY(abs_c64(ctx, d_out, (float *)d_mag_f32, (size_t)n_frames * V * S * C));
@@ -545,8 +554,8 @@ static int ensure_pipe_queues(mmw_ctx *ctx, int rd_cus) {
     return MMW_OK;
 }
 
-int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames, int V, int S, int C,
-                int A, int flags) {
+static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_rd, void *d_out, int n_frames, int V,
+                        int S, int C, int A, int flags) {
     const int magnitude = flags & MMW_ANGLE_MAGNITUDE;
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
@@ -589,7 +598,7 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
             const int nf = std::min(chunk, n_frames - f0);
             const char *in = (const char *)d_cubes + (size_t)f0 * cube_bytes;
             char *rd = d_rd ? (char *)d_rd + (size_t)f0 * cube_bytes : (char *)rd_scratch;
-            MMW_TRY(range_doppler_impl(ctx, in, rd, nullptr, nf, V, S, C));
+            MMW_TRY(range_doppler_impl(ctx, in, rd, nullptr, nf, V, S, C, rv));
             MMW_TRY(angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, flags));
         }
         return MMW_OK;
@@ -601,7 +610,7 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         MMW_TRY(ensure_scratch(ctx, (size_t)big * cube_bytes));
         for (int f0 = 0; f0 < n_frames; f0 += big) {
             const int nf = std::min(big, n_frames - f0);
-            MMW_TRY(range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, ctx->scratch, nullptr, nf, V, S, C));
+            MMW_TRY(range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, ctx->scratch, nullptr, nf, V, S, C, rv));
             MMW_TRY(angle_fft_impl(ctx, ctx->scratch, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, flags));
         }
         return MMW_OK;
@@ -620,7 +629,7 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
         if (ctx->pipe_ang_used[buf]) MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[buf], 0));
         ctx->stream = ctx->q_rd;
         ctx->active_cus = rd_cus;
-        rc = range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C);
+        rc = range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C, rv);
         ctx->stream = main_stream;
         ctx->active_cus = 0;
         if (rc != MMW_OK) break;
@@ -636,6 +645,31 @@ int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int 
     // The context stream joins lazily (join_pipe) at the next entry point that uses it.
     ctx->pipe_pending = true;
     return rc;
+}
+
+int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames, int V, int S, int C,
+                int A, int flags) {
+    return chain3d_impl(ctx, d_cubes, RawView{1, 0}, d_rd, d_out, n_frames, V, S, C, A, flags);
+}
+
+static int raw_args_ok(int num_rx, int num_tx) {
+    MMW_REQUIRE(num_rx > 0 && num_tx > 0 && (long)num_rx * num_tx <= 4096, "bad antenna counts %d x %d", num_rx, num_tx);
+    return MMW_OK;
+}
+
+int mmw_range_doppler_raw(mmw_ctx *ctx, const void *d_raw, void *d_out, int n_frames, int num_rx, int num_tx, int S,
+                          int loops) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
+    MMW_TRY(raw_args_ok(num_rx, num_tx));
+    return range_doppler_impl(ctx, d_raw, d_out, nullptr, n_frames, num_rx * num_tx, S, loops, RawView{num_tx, num_rx});
+}
+
+int mmw_chain3d_raw(mmw_ctx *ctx, const void *d_raw, void *d_rd, void *d_out, int n_frames, int num_rx, int num_tx,
+                    int S, int loops, int A, int flags) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_TRY(raw_args_ok(num_rx, num_tx));
+    return chain3d_impl(ctx, d_raw, RawView{num_tx, num_rx}, d_rd, d_out, n_frames, num_rx * num_tx, S, loops, A, flags);
 }
 
 int mmw_range_profile(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C,

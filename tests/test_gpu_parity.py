@@ -841,3 +841,35 @@ def test_mixed_radix_rd_kernel_all_shipped_shapes(S, C, monkeypatch):
             np.testing.assert_array_equal(np.asarray(have).reshape(-1, 2), np.array(want, dtype=np.int64).reshape(-1, 2))
     for b in (d_in, d_rd, d_mag):
         b.free()
+
+
+@pytest.mark.parametrize("nrx,ntx,S,C", [(4, 3, 256, 128), (4, 3, 64, 32), (4, 3, 63, 70), (4, 2, 100, 30), (2, 2, 512, 64),
+                                         (4, 3, 63, 127)])
+def test_raw_cube_entry_points_fold_the_virtual_array_reformat(nrx, ntx, S, C):
+    """mmw_range_doppler_raw / mmw_chain3d_raw == mmw_virtual_array_reformat followed by the plain calls, on the
+    fused 256x128 kernel, an LDS-resident power-of-two plane, mixed-radix planes and the two-kernel fallback; and
+    against the oracle (virtual_array_reformater.py:53-63 + range_doppler_resp.py:94-103)."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, V, A = 5, nrx * ntx, 64
+    rng = np.random.default_rng(S * 1000 + C)
+    raw = (rng.integers(-500, 500, (F, nrx, S, ntx * C)) + 1j * rng.integers(-500, 500, (F, nrx, S, ntx * C))).astype(np.complex64)
+    n = V * S * C
+    d_raw, d_virt, d_a, d_b = ctx.alloc(F * n * 8), ctx.alloc(F * n * 8), ctx.alloc(F * n * 8), ctx.alloc(F * n * 8)
+    d_3a, d_3b = ctx.alloc(F * A * S * C * 8), ctx.alloc(F * A * S * C * 8)
+    d_raw.upload(raw)
+    _lib.check(L.mmw_virtual_array_reformat(h, d_raw.ptr, d_virt.ptr, F, nrx, ntx, S, C))
+    _lib.check(L.mmw_range_doppler(h, d_virt.ptr, d_a.ptr, None, F, V, S, C))
+    _lib.check(L.mmw_range_doppler_raw(h, d_raw.ptr, d_b.ptr, F, nrx, ntx, S, C))
+    rd_a, rd_b = d_a.download((F, V, S, C), np.complex64), d_b.download((F, V, S, C), np.complex64)
+    np.testing.assert_array_equal(rd_a, rd_b)                       # same arithmetic, only the load addresses differ
+    d_a.zero()
+    _lib.check(L.mmw_chain3d(h, d_virt.ptr, None, d_3a.ptr, F, V, S, C, A, 0))
+    _lib.check(L.mmw_chain3d_raw(h, d_raw.ptr, d_a.ptr, d_3b.ptr, F, nrx, ntx, S, C, A, 0))
+    np.testing.assert_array_equal(d_3a.download((F, A, S, C), np.complex64), d_3b.download((F, A, S, C), np.complex64))
+    np.testing.assert_array_equal(d_a.download((F, V, S, C), np.complex64), rd_b)      # kept RD cube
+    virt = O.virtual_array_reformat(raw[F - 1], nrx, 0, ntx - 1, C)
+    assert rel_err(rd_b[F - 1], O.range_doppler(virt)) <= SPEC_TOL
+    assert L.mmw_range_doppler_raw(h, d_raw.ptr, d_b.ptr, F, 0, ntx, S, C) == _lib.MMW_ERR_INVALID
+    for b in (d_raw, d_virt, d_a, d_b, d_3a, d_3b):
+        b.free()

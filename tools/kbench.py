@@ -65,6 +65,15 @@ def main():
         F * (cube_b + out_b // 2))
     run("chain3d", lambda: _lib.check(L.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0)),
         F * (cube_b + out_b))
+    # raw-cube ingest (V = 4 rx x V/4 tx): separate de-interleave pass vs the fused loads
+    if V % 4 == 0:
+        nrx, ntx = 4, V // 4
+        run("reformat", lambda: _lib.check(L.mmw_virtual_array_reformat(ctx.handle, d_in.ptr, d_rd.ptr, F, nrx, ntx, S, C)),
+            F * 2 * cube_b)
+        run("rd_raw", lambda: _lib.check(L.mmw_range_doppler_raw(ctx.handle, d_in.ptr, d_rd.ptr, F, nrx, ntx, S, C)),
+            F * 2 * cube_b)
+        run("chain3d_raw", lambda: _lib.check(L.mmw_chain3d_raw(ctx.handle, d_in.ptr, None, d_out.ptr, F, nrx, ntx, S, C, A, 0)),
+            F * (cube_b + out_b))
     d_mag = ctx.alloc(F * S * C * 8)
     run("rd_mag64", lambda: _lib.check(L.mmw_range_doppler_mag64(ctx.handle, d_in.ptr, d_mag.ptr, F, V, S, C, 0)),
         F * (S * C * 8 + S * C * 8))
