@@ -94,6 +94,30 @@ class FramePipeline:
         self.d_in.upload(cubes)
         self.n_frames = cubes.shape[0]
 
+    def load_raw(self, raw_cubes: np.ndarray, num_tx: int):
+        """``[F, num_rx, S, num_tx * loops]`` raw cubes (the layout ``VirtualArrayReformatter.process`` consumes,
+        virtual_array_reformater.py:44-65): uploaded once, de-interleaved on the device into the virtual-array
+        cubes every other method works on.  ``chain3d_raw`` skips even that pass."""
+        raw = np.ascontiguousarray(raw_cubes, dtype=np.complex64)
+        num_tx = int(num_tx)
+        if raw.ndim != 4 or num_tx < 1 or self.V % num_tx or raw.shape[1] != self.V // num_tx or \
+                raw.shape[2:] != (self.S, num_tx * self.C) or raw.shape[0] > self.max_frames:
+            raise ValueError(f"expected [F<={self.max_frames}, {self.V}/num_tx, {self.S}, num_tx*{self.C}] raw cubes, "
+                             f"got {raw.shape} with num_tx={num_tx}")
+        self.d_raw = self.bufs.get("raw", self.max_frames * self.cube_bytes)
+        self.d_raw.upload(raw)
+        self.n_frames, self._raw_tx = raw.shape[0], num_tx
+        _lib.check(self.ctx.lib.mmw_virtual_array_reformat(self.ctx.handle, self.d_raw.ptr, self.d_in.ptr, self.n_frames,
+                                                           self.V // num_tx, num_tx, self.S, self.C))
+
+    def chain3d_raw(self, magnitude: bool = False):
+        """3-D windowed FFT straight from the raw cubes of ``load_raw`` (``mmw_chain3d_raw``)."""
+        F, A, S, C = self.n_frames, self.A, self.S, self.C
+        self.d_cube3d = self.bufs.get("cube3d", max(F, 1) * A * S * C * (4 if magnitude else 8))
+        self._cube3d_mag = magnitude
+        _lib.check(self.ctx.lib.mmw_chain3d_raw(self.ctx.handle, self.d_raw.ptr, None, self.d_cube3d.ptr, F,
+                                                self.V // self._raw_tx, self._raw_tx, S, C, A, int(magnitude)))
+
     def synth(self, n_frames: int, seed0: int, num_targets: int = 8, noise_sigma: float = 30.0):
         if n_frames > self.max_frames:
             raise ValueError("n_frames exceeds max_frames")

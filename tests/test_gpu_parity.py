@@ -873,3 +873,24 @@ def test_raw_cube_entry_points_fold_the_virtual_array_reformat(nrx, ntx, S, C):
     assert L.mmw_range_doppler_raw(h, d_raw.ptr, d_b.ptr, F, 0, ntx, S, C) == _lib.MMW_ERR_INVALID
     for b in (d_raw, d_virt, d_a, d_b, d_3a, d_3b):
         b.free()
+
+
+def test_frame_pipeline_from_raw_cubes():
+    """FramePipeline.load_raw / chain3d_raw against the host-side VirtualArrayReformatter + per-frame processor."""
+    from mmwave_radar_processing_amd.batch import FramePipeline
+    from mmwave_radar_processing_amd.processors import VirtualArrayReformatter
+    cm = make_cm(synth.synth_cfg_text(num_samples=64, num_loops=32))
+    F, nrx, ntx, S, C = 4, 4, 3, 64, 32
+    rng = np.random.default_rng(77)
+    raw = (rng.integers(-300, 300, (F, nrx, S, ntx * C)) + 1j * rng.integers(-300, 300, (F, nrx, S, ntx * C))).astype(np.complex64)
+    pipe = FramePipeline(cm, max_frames=F, shape=(nrx * ntx, S, C))
+    pipe.load_raw(raw, ntx)
+    ref_virt = np.stack([VirtualArrayReformatter(cm).process(raw[f]) for f in range(F)])
+    np.testing.assert_array_equal(pipe.cubes(), ref_virt.astype(np.complex64))
+    pipe.chain3d_raw()
+    got = pipe.fetch_chain3d(F - 1)
+    assert rel_err(got, O.fft3d_windowed(ref_virt[F - 1], 64)) <= SPEC_TOL
+    pipe.chain3d()
+    np.testing.assert_array_equal(pipe.fetch_chain3d(F - 1), got)
+    with pytest.raises(ValueError):
+        pipe.load_raw(raw, 5)
