@@ -397,7 +397,7 @@ template <int S, int C> struct RdLds {
     static_assert(CELLS <= 16384 && CELLS % NT == 0 && VPT % R2S == 0 && VPT % R2C == 0, "plane must fit the scheme");
 };
 
-template <int S, int C, bool RAW = false>
+template <int S, int C>
 __global__ __launch_bounds__((RdLds<S, C>::NT)) void k_rd_lds(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                                const float *__restrict__ hann_s,
                                                                const float *__restrict__ hann_c,
@@ -410,14 +410,14 @@ __global__ __launch_bounds__((RdLds<S, C>::NT)) void k_rd_lds(const f32x4 *__res
     cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
     cplx<float> *tw_s = lds + S * P, *tw_c = tw_s + S;
     const int t = threadIdx.x;
+    const bool raw = rv.ntx > 1;                 // uniform: raw cube, de-interleave folded into the loads
     long plane = blockIdx.x;
-    if constexpr (RAW) {
+    if (raw) {
         plane = raw_block_plane(blockIdx.x, planes, rv);
         if (plane < 0) return;
     }
     const f32x4 *src = in + plane * (K::CELLS / 2);
-    const cplx<float> *rsrc = nullptr;
-    if constexpr (RAW) rsrc = raw_plane(reinterpret_cast<const cplx<float> *>(in), plane, S, C, rv);
+    const cplx<float> *rsrc = raw ? raw_plane(reinterpret_cast<const cplx<float> *>(in), plane, S, C, rv) : nullptr;
     cplx<float> *dst = out + plane * K::CELLS;
     for (int i = t; i < S; i += NT) tw_s[i] = tw_s_g[i];
     for (int i = t; i < C; i += NT) tw_c[i] = tw_c_g[i];
@@ -427,7 +427,7 @@ __global__ __launch_bounds__((RdLds<S, C>::NT)) void k_rd_lds(const f32x4 *__res
         const int idx = t + q * NT;                         // float4 index: two adjacent chirps of one sample row
         const int row = (2 * idx) / C, col = (2 * idx) % C;
         f32x4 v;
-        if constexpr (RAW) {
+        if (raw) {
             const cplx<float> *e = rsrc + (long)(2 * idx) * rv.ntx;
             const cplx<float> a = e[0], b = e[rv.ntx];
             v = f32x4{a.x, a.y, b.x, b.y};
@@ -535,8 +535,7 @@ template <int S, int C> int launch_rd_lds_sc(mmw_ctx *ctx, const void *d_in, voi
                            (const cplx<float> *)tc, rv, planes);
         return check_launch("rd_lds");
     };
-    if (rv.ntx > 1) return go(k_rd_lds<S, C, true>);
-    return go(k_rd_lds<S, C, false>);
+    return go(k_rd_lds<S, C>);
 }
 
 // planes handled by k_rd_lds (S x C, both powers of two, S*C <= 16384)
@@ -600,6 +599,7 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
         launch(k_rd_fused_256x128_persist<true, 8>);
         return check_launch("rd_fused_persist");
     }
+#ifdef MMW_ABLATE   // timing-only variants (no loads / no stores), build with EXTRA=-DMMW_ABLATE
     const int abl = tune_int("MMW_RD_ABLATE", 0);
     if (abl) {
         auto launch = [&](auto kern) {
@@ -613,6 +613,7 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
         else launch(k_rd_fused_256x128<true, 3>);
         return check_launch("rd_fused_ablate");
     }
+#endif
     if (tune_int("MMW_RD_NT", 1))
         hipLaunchKernelGGL(k_rd_fused_256x128<true>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
                            (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
