@@ -30,12 +30,16 @@ ALGO_BYTES_PER_FRAME = CUBE_BYTES + OUT_BYTES   # 19,922,944 B (co
 HBM_PEAK_GBS = 8000.0                           # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(seconds: float = 12.0):
-    """Oracle (float64 NumPy restatement of the reference chain) timed on one host core."""
+def cpu_baseline(seconds: float = 12.0, gpu_frame=None):
+    """Oracle (float64 NumPy restatement of the reference chain) timed on one host core.
+
+    ``gpu_frame = (cube, gpu_result)``: frame 0 of the bench's own batch and what the GPU made of it; the oracle's
+    result for that cube doubles as the parity check of the run (reported as ``parity_max_rel_err_frame0``)."""
     from mmwave_radar_processing_amd import synth
     from oracle import oracle_np as O
     cubes = [synth.synth_cube(1000 + i) for i in range(4)]
-    O.fft3d_windowed(cubes[0], A)               # warm numpy's FFT plan cache
+    ref0 = O.fft3d_windowed(cubes[0] if gpu_frame is None else gpu_frame[0], A)     # also warms numpy's FFT plan cache
+    parity = None if gpu_frame is None else float(np.max(np.abs(gpu_frame[1] - ref0)) / np.max(np.abs(ref0)))
     n, t0 = 0, time.perf_counter()
     while True:
         O.fft3d_windowed(cubes[n % len(cubes)], A)
@@ -45,7 +49,8 @@ def cpu_baseline(seconds: float = 12.0):
             break
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n} frames of the same synthetic 12x256x128 workload through oracle_np.fft3d_windowed "
-                      f"(float64 NumPy, single thread) in {dt:.1f} s"}
+                      f"(float64 NumPy, single thread) in {dt:.1f} s",
+            "parity_max_rel_err_frame0": parity}
 
 
 def _cpu_worker(args):
@@ -224,8 +229,7 @@ def main():
                 out["rd_kernel"] = {"avg_launch_us": avg_s * 1e6, "launches": rd_n,
                                     "achieved_GBs": fpl * 2 * CUBE_BYTES / avg_s / 1e9,
                                     "algorithmic_bytes_per_launch": fpl * 2 * CUBE_BYTES}
-        # one-frame parity gate on the bench's own data (not timed)
-        from oracle import oracle_np as O
+        # frame 0 of the bench's own data, saved for the parity check inside the cpu_baseline leg (not timed)
         cube0 = d_in.download((V, S, C), np.complex64)
         got0 = d_out.download((A, S, C), np.complex64)
         if "roofline" in out:
@@ -244,12 +248,13 @@ def main():
                     call()
                 insitu[name + "_GBs"] = moved / (ctx.timer_stop() / 5) / 1e6
             out["roofline"]["insitu_streaming_ceiling"] = insitu
-        ref0 = O.fft3d_windowed(cube0, A)
-        out["parity_max_rel_err_frame0"] = float(np.max(np.abs(got0 - ref0)) / np.max(np.abs(ref0)))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(gpu_frame=(cube0, got0))
+            out["parity_max_rel_err_frame0"] = out["cpu_baseline"]["parity_max_rel_err_frame0"]
             out["cpu_baseline_all_cores"] = cpu_baseline_pool()
         print(json.dumps(out))
+        if out.get("parity_max_rel_err_frame0") is not None and not out["parity_max_rel_err_frame0"] <= 1e-5:
+            sys.exit("bench.py: GPU chain output differs from the oracle beyond 1e-5 -- the figure above is invalid")
     if dist is not None:
         with stdout_to_stderr():
             dist.barrier()

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -227,6 +228,8 @@ struct ProfScope {
 // tuning knob read once per process from the environment (experiments only; defaults are the product path)
 inline int tune_int(const char *name, int dflt) {
     static std::map<std::string, int> cache;
+    static std::mutex mu;                       // contexts of different threads share the cache
+    std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(name);
     if (it != cache.end()) return it->second;
     const char *s = std::getenv(name);
