@@ -202,17 +202,21 @@ __global__ __launch_bounds__(NT) void k_rd_mixed(RdMixedArgs a) {
         const T w = ws[s] * wc[c];
         lds[s * Cp + c] = cplx<T>{(T)v.x * w, (T)v.y * w};
     }
+    // inter-level twiddles W_S^m, W_C^m next to the plane: an LDS read per output instead of a global one
+    cplx<T> *tw_s = lds + S * Cp, *tw_c = tw_s + S;
+    for (int i = tid; i < S; i += NT) tw_s[i] = reinterpret_cast<const cplx<T> *>(a.tw_s)[i];
+    for (int i = tid; i < C; i += NT) tw_c[i] = reinterpret_cast<const cplx<T> *>(a.tw_c)[i];
     __syncthreads();
     typedef const cplx<T> *CP;
-    cplx<T> *tmp = lds + S * Cp;                 // spare LDS behind the plane (levels with a radix > 32 only)
+    cplx<T> *tmp = tw_c + C;                     // spare LDS behind them (levels with a radix > 32 only)
     // range axis: element s = s2 * n1 + n2 lives in row s
     dft_level_any<CLS, BIG, NT, T>(a.s1, lds, tmp, a.tmp_cells, tid, C, a.mg_C, 1, a.s2, Cp, a.s2 * Cp, (CP)a.m_s1,
-                          a.s2 > 1 ? (CP)a.tw_s : (CP) nullptr, S);
+                          a.s2 > 1 ? (CP)tw_s : (CP) nullptr, S);
     if (a.s2 > 1)
         dft_level_any<CLS, BIG, NT, T>(a.s2, lds, tmp, a.tmp_cells, tid, C, a.mg_C, 1, a.s1, a.s2 * Cp, Cp, (CP)a.m_s2, (CP) nullptr, S);
     // Doppler axis: element c = c2 * m1 + m2 lives in column c; lanes walk the rows (pitch Cp is odd)
     dft_level_any<CLS, BIG, NT, T>(a.c1, lds, tmp, a.tmp_cells, tid, S, a.mg_S, Cp, a.c2, 1, a.c2, (CP)a.m_c1,
-                          a.c2 > 1 ? (CP)a.tw_c : (CP) nullptr, C);
+                          a.c2 > 1 ? (CP)tw_c : (CP) nullptr, C);
     if (a.c2 > 1)
         dft_level_any<CLS, BIG, NT, T>(a.c2, lds, tmp, a.tmp_cells, tid, S, a.mg_S, Cp, a.c1, a.c2, 1, (CP)a.m_c2, (CP) nullptr, C);
     // bin k = k1 + s1 k2 sits in row s2 k1 + k2 (same along the Doppler axis); fftshift: out[(d + C/2) % C] = X[d]
@@ -264,7 +268,7 @@ constexpr size_t MIXED_LDS_MAX = 160 * 1024;
 inline bool rd_mixed_plan(int S, int C, size_t elem_bytes, RdMixedPlan *out) {
     if (S < 1 || C < 1 || (long)S * C > (1 << 20)) return false;
     const int Cp = C | 1;
-    const size_t plane = (size_t)S * Cp * elem_bytes;
+    const size_t plane = ((size_t)S * Cp + S + C) * elem_bytes;      // plane + the two inter-level twiddle tables
     if (plane > MIXED_LDS_MAX) return false;
     const int spare = (int)((MIXED_LDS_MAX - plane) / elem_bytes);
     int best = -1;
