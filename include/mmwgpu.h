@@ -216,6 +216,11 @@ int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n);
  * grid-stride over `blocks` workgroups of 256 (0 = 8 per CU).  Used by tools/kbench.py to state what
  * a known-good streaming kernel reaches next to the hot-path kernels. */
 int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks);
+/* Which range-Doppler kernel mmw_range_doppler picks for an S x C plane, without touching a device (host logic
+ * only): plan[0] = 0 fused 256x128 | 1 LDS-resident power of two | 2 mixed radix | 3 generic two-kernel path;
+ * for the mixed-radix kernel plan[1..7] = register class, has a run-time-radix level, S1, S2, C1, C2 (S = S1 S2,
+ * C = C1 C2), dynamic LDS bytes.  float64 != 0 asks for the float64 CFAR-plane variant. */
+int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]);
 
 /* ---------------------------------------------------------------- per-kernel timing hook for bench.py
  * Average duration (ms) of the most recent launch group of the named kernel family measured

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "mmw_capon": [_vp, _vp, C.POINTER(_d), _vp, _i, _i, _i, _i, _d],
     "mmw_abs_c64": [_vp, _vp, _vp, _sz],
     "mmw_diag_membw": [_vp, _vp, _vp, _sz, _i, _i],
+    "mmw_diag_rd_plan": [_i, _i, _i, _ip],
     "mmw_profile_enable": [_vp, _i],
     "mmw_profile_get": [_vp, C.c_char_p, C.POINTER(_f), _ip],
     "mmw_profile_reset": [_vp],

@@ -890,6 +890,31 @@ int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
     return abs_c64(ctx, d_in, d_out, n);
 }
 
+int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]) {
+    MMW_REQUIRE(plan && S > 0 && C > 0, "bad argument");
+    for (int i = 0; i < 8; ++i) plan[i] = 0;
+    RdMixedPlan pl{};
+    if (float64) {
+        const bool pow2 = is_pow2(S) && is_pow2(C);
+        plan[0] = (!pow2 && rd_mixed_plan(S, C, sizeof(cplx<double>), &pl)) ? 2 : 3;
+    } else if (fused_rd_ok(S, C))
+        plan[0] = 0;
+    else if (rd_lds_supported(S, C))
+        plan[0] = 1;
+    else
+        plan[0] = rd_mixed_plan(S, C, sizeof(cplx<float>), &pl) ? 2 : 3;
+    if (plan[0] == 2) {
+        plan[1] = pl.cls;
+        plan[2] = pl.big;
+        plan[3] = pl.s1;
+        plan[4] = pl.s2;
+        plan[5] = pl.c1;
+        plan[6] = pl.c2;
+        plan[7] = (int)pl.lds_bytes;
+    }
+    return MMW_OK;
+}
+
 int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks) {
     MMW_REQUIRE(ctx && d_src && d_dst && bytes % 16 == 0 && mode >= 0 && mode <= 7, "bad argument");
     MMW_JOIN(ctx);

@@ -36,6 +36,38 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.mmw_version()
 
 
+def test_rd_kernel_plan_covers_every_shipped_cfg_shape():
+    """Host-side kernel selection (no device call): every (samples, loops) plane of the cfg files the reference ships
+    gets a single-pass range-Doppler kernel, with a factorisation that multiplies back to the shape and fits the LDS."""
+    import json
+    from conftest import GOLDEN
+    lib = _lib.load_library()
+    with open(os.path.join(GOLDEN, "cfg_scalars.json")) as fh:
+        cfgs = json.load(fh)
+    shapes = set()
+    for name, entry in cfgs.items():
+        e = entry["expect"]
+        shapes.add((int(e["num_samples"]), int(e["loops"])))
+    assert (63, 70) in shapes and (256, 128) in shapes and len(shapes) >= 15
+    plan = (ctypes.c_int * 8)()
+    kinds = {}
+    for S, C in sorted(shapes):
+        assert lib.mmw_diag_rd_plan(S, C, 0, plan) == 0
+        kinds[(S, C)] = plan[0]
+        assert plan[0] in (0, 1, 2), f"{S}x{C} falls back to the two-kernel path"
+        if plan[0] == 2:
+            cls, big, s1, s2, c1, c2, lds = plan[1:8]
+            assert s1 * s2 == S and c1 * c2 == C and s1 >= s2 and c1 >= c2
+            assert max(s2, c2) <= (16 if cls == 0 else 32)
+            assert all(r <= (16 if cls == 0 else 32) or big for r in (s1, c1))
+            assert (S * (C | 1) + S + C) * 8 <= lds <= 160 * 1024
+    assert kinds[(256, 128)] == 0 and kinds[(63, 70)] == 2
+    assert lib.mmw_diag_rd_plan(512, 128, 0, plan) == 0 and plan[0] == 3        # beyond the LDS
+    assert lib.mmw_diag_rd_plan(63, 100, 1, plan) == 0 and plan[0] == 2         # float64 CFAR plane
+    assert lib.mmw_diag_rd_plan(256, 128, 1, plan) == 0 and plan[0] == 3
+    assert lib.mmw_diag_rd_plan(0, 4, 0, plan) == _lib.MMW_ERR_INVALID
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No CPU fallback: without a HIP device every entry raises MmwGpuError (skipped where a GPU exists)."""
     try:
