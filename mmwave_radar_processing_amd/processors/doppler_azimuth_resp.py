@@ -9,14 +9,17 @@ valid angle columns -> mean over the kept range bins.  On the GPU this is the 3-
 ``use_precise_fft=True`` replaces the Doppler FFT by the reference's two ``scipy.signal.ZoomFFT`` calls (one per
 velocity sign) over ``precise_vel_range``; the host derives the frequency of every zoomed bin exactly as the reference
 does and ``mmw_doppler_azimuth_zoom`` evaluates range FFT -> zoom transform -> angle FFT -> |.| -> range mean on the
-GPU.  The scipy peak pickers (``detect_peaks_rows`` ...) are host-side post-processing and stay out of scope
-(SURVEY.md 8f-4).
+GPU.  ``detect_peaks_rows`` / ``detect_peak_zero_az`` (:336-417) are scipy peak pickers over the small
+``[vel, angle]`` map this processor returns; they run on the host exactly as in the reference and exist so that
+subclasses written against the reference (``VelocityEstimator(DopplerAzimuthProcessor)``, velocity_estimator.py:7)
+keep working when the base class is swapped.
 """
 from __future__ import annotations
 
 from typing import Union
 
 import numpy as np
+from scipy.signal import find_peaks
 
 from .. import _lib
 from ._processor import _Processor
@@ -92,6 +95,39 @@ class DopplerAzimuthProcessor(_Processor):
                 fz = fs * 2                       # the reference's "factor of 2" (:154-155)
                 freq[first:first + m] = f1 / fz + np.arange(m) * ((f2 - f1) / (m * fz))   # ZoomFFT(m, [f1, f2], fs=fz)
         return freq
+
+    # ------------------------------------------------------------------ host-side peak picking on the [vel, angle] map
+    @staticmethod
+    def _floored_db(resp_mag: np.ndarray, min_threshold_dB: float) -> np.ndarray:
+        """dB map with everything more than ``min_threshold_dB`` below the global maximum lifted to that floor."""
+        db = 20 * np.log10(np.abs(resp_mag) + 1e-12)
+        floor = np.max(db) - min_threshold_dB
+        db[db <= floor] = floor
+        return db
+
+    def detect_peaks_rows(self, doppler_azimuth_resp_mag: np.ndarray, vel_bins: np.ndarray,
+                          min_threshold_dB: float = 30.0) -> np.ndarray:
+        """One peak per velocity row: the strongest local maximum with at least 4 dB prominence.  ``(N, 2)`` rows of
+        (angle in radians, velocity) (:336-389)."""
+        db = self._floored_db(doppler_azimuth_resp_mag, min_threshold_dB)
+        angles, vels = [], []
+        for r, row in enumerate(db):
+            cand, _ = find_peaks(row, prominence=4.0)
+            if cand.size > 0:
+                angles.append(self.valid_angle_bins[cand[np.argmax(row[cand])]])
+                vels.append(vel_bins[r])
+        return np.stack([np.array(angles), np.array(vels)], axis=1)
+
+    def detect_peak_zero_az(self, doppler_azimuth_resp_mag: np.ndarray, vel_bins: np.ndarray,
+                            min_threshold_dB: float = 30.0) -> np.ndarray:
+        """Strongest local maximum down the column closest to zero azimuth: ``[0.0, velocity]``, or an empty
+        ``(0, 2)`` array when that column has no peak (:392-417)."""
+        db = self._floored_db(doppler_azimuth_resp_mag, min_threshold_dB)
+        col = db[:, np.argmin(np.abs(self.valid_angle_bins))]
+        cand, _ = find_peaks(col)
+        if cand.size > 0:
+            return np.array([0.0, vel_bins[cand[np.argmax(col[cand])]]])
+        return np.empty(shape=(0, 2))
 
     def process(self, adc_cube: np.ndarray, rx_antennas: Union[np.ndarray, list] = [],
                 range_window: Union[np.ndarray, list] = [], shift_angle: bool = True, use_precise_fft: bool = False,

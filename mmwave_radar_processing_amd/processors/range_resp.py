@@ -6,6 +6,7 @@ picking (:59-150) belongs to the altimeter path that SURVEY.md marks out of scop
 from __future__ import annotations
 
 import numpy as np
+from scipy.signal import find_peaks as _scipy_find_peaks
 
 from .. import _lib
 from ._processor import _Processor
@@ -44,6 +45,19 @@ class RangeProcessor(_Processor):
                                           float(f0), float(df)))
         zoom_avg = d_out.download((m,), np.float32).astype(np.float64)
         return zoom_avg, np.linspace(range_start_m, range_stop_m, m)
+
+    def find_peaks(self, rng_resp_db: np.ndarray, rng_bins: np.ndarray, max_peaks: int = 3, threshold_dB: int = 20):
+        """Host-side peak picker on a range profile in dB (reference :104-149; ``Altimeter(RangeProcessor)`` relies on
+        it): local maxima of >= 6 dB prominence, within ``threshold_dB`` of the strongest, strongest first, at most
+        ``max_peaks``.  Returns (ranges in metres, dB values); two empty arrays when there is no peak."""
+        idx, _ = _scipy_find_peaks(rng_resp_db, prominence=6)
+        if len(idx) == 0:
+            return np.array([]), np.array([])
+        vals = rng_resp_db[idx]
+        keep = vals >= (np.max(vals) - threshold_dB)
+        idx, vals = idx[keep], vals[keep]
+        top = idx[np.argsort(vals)[::-1]][:max_peaks]
+        return rng_bins[top], rng_resp_db[top]
 
     def process(self, adc_cube: np.ndarray, chirp_idx: int = 0, **kwargs) -> np.ndarray:
         return self.coarse_fft(adc_cube, chirp_idx)

@@ -271,6 +271,15 @@ def gen_doppler_azimuth():
     d["precise_ods"] = p2.process(virt, rx_antennas=[4, 5, 8, 9], range_window=[0.9, 2.0], use_precise_fft=True,
                                   precise_vel_range=np.array([-0.25, 0.25]))
     d["precise_ods_bins"] = np.array(p2.zoomed_vel_bins)
+    # host-side scipy peak pickers that subclasses of these processors call (velocity_estimator.py, altimeter.py)
+    d["peaks_rows_std_all"] = p.detect_peaks_rows(d["std_all"], p.vel_bins, 30.0)
+    d["peaks_rows_precise"] = p.detect_peaks_rows(d["precise_default"], d["precise_default_bins"], 20.0)
+    d["peak_zero_az_std_all"] = np.asarray(p.detect_peak_zero_az(d["std_all"], p.vel_bins, 30.0))
+    d["peak_zero_az_ods"] = np.asarray(p2.detect_peak_zero_az(d["ods_sub"], p2.vel_bins, 30.0))
+    prof = rp.process(cube, chirp_idx=2)
+    d["range_profile_chirp2"] = prof
+    pk_r, pk_v = rp.find_peaks(20 * np.log10(prof), rp.range_bins, max_peaks=3)
+    d["range_peaks_m"], d["range_peaks_db"] = pk_r, pk_v
     np.savez_compressed(os.path.join(HERE, "doppler_azimuth.npz"), **d)
     print("doppler_azimuth.npz:", {k: v.shape for k, v in d.items()})
 

@@ -120,6 +120,36 @@ def test_config_manager_bins_and_processor_tables():
     assert cm2.range_res_m == cm.range_res_m
 
 
+def test_host_side_peak_pickers_match_the_reference(golden):
+    """detect_peaks_rows / detect_peak_zero_az / RangeProcessor.find_peaks: scipy post-processing that subclasses of
+    the reference's processors call (velocity_estimator.py:278-337, altimeter.py:71-93); fixtures from the reference."""
+    from mmwave_radar_processing_amd.processors import DopplerAzimuthProcessor, RangeProcessor
+    g = golden("doppler_azimuth.npz")
+    cm = ConfigManager()
+    cm.load_cfg_text(synth.synth_cfg_text(num_samples=32, num_loops=16))
+    p = DopplerAzimuthProcessor(cm, num_angle_bins=64)
+    resp = g["std_all"].copy()
+    np.testing.assert_array_equal(p.detect_peaks_rows(resp, p.vel_bins, 30.0), g["peaks_rows_std_all"])
+    np.testing.assert_array_equal(resp, g["std_all"])                       # the input map is not modified
+    np.testing.assert_array_equal(p.detect_peaks_rows(g["precise_default"], g["precise_default_bins"], 20.0),
+                                  g["peaks_rows_precise"])
+    np.testing.assert_array_equal(p.detect_peak_zero_az(g["std_all"], p.vel_bins, 30.0), g["peak_zero_az_std_all"])
+    flat = np.ones((16, p.valid_angle_bins.size))
+    assert p.detect_peak_zero_az(flat, p.vel_bins).shape == (0, 2) and p.detect_peaks_rows(flat, p.vel_bins).shape == (0, 2)
+    cm2 = ConfigManager()
+    with open(os.path.join(os.path.dirname(HEADER), "..", "tests", "golden", "cfg_scalars.json")) as fh:
+        import json
+        cm2.load_cfg_text("\n".join(json.load(fh)["6843_RadVel_ods_20Hz.cfg"]["lines"]), array_geometry="ods")
+    p2 = DopplerAzimuthProcessor(cm2, num_angle_bins=64, valid_angle_range=[-1.04719755, 1.04719755])
+    np.testing.assert_array_equal(p2.detect_peak_zero_az(g["ods_sub"], p2.vel_bins, 30.0), g["peak_zero_az_ods"])
+    rp = RangeProcessor(cm)
+    r, v = rp.find_peaks(20 * np.log10(g["range_profile_chirp2"]), rp.range_bins, max_peaks=3)
+    np.testing.assert_array_equal(r, g["range_peaks_m"])
+    np.testing.assert_array_equal(v, g["range_peaks_db"])
+    r0, v0 = rp.find_peaks(np.zeros(32), rp.range_bins)
+    assert r0.size == 0 and v0.size == 0
+
+
 def test_register_fft_network_host_build(tmp_path):
     exe = tmp_path / "test_regfft"
     subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "mmwave_radar_processing_amd", "csrc"),

@@ -894,3 +894,38 @@ def test_frame_pipeline_from_raw_cubes():
     np.testing.assert_array_equal(pipe.fetch_chain3d(F - 1), got)
     with pytest.raises(ValueError):
         pipe.load_raw(raw, 5)
+
+
+def test_subclass_in_the_style_of_velocity_estimator():
+    """A processor derived from DopplerAzimuthProcessor the way the reference's VelocityEstimator is
+    (velocity_estimator.py:7,48-51,175-199,278-299): super().__init__(config_manager=..., ...), super().process(...),
+    self.detect_peaks_rows(...), reset() -- works unchanged on the drop-in base class."""
+    from mmwave_radar_processing_amd.processors import DopplerAzimuthProcessor
+
+    class Est(DopplerAzimuthProcessor):
+        def __init__(self, config_manager, precise_vel_bound=0.25, **kwargs):
+            super().__init__(config_manager=config_manager, num_angle_bins=64,
+                             valid_angle_range=np.array([np.deg2rad(-70), np.deg2rad(70)]))
+            self.precise_vel_bound = precise_vel_bound
+            self.azimuth_peaks = None
+
+        def process(self, adc_cube, **kwargs):
+            resp = super().process(adc_cube=adc_cube, rx_antennas=[0, 1, 2, 3, 4, 5, 6, 7], range_window=[1.0, 12.0],
+                                   use_precise_fft=True,
+                                   precise_vel_range=np.array([-self.precise_vel_bound, self.precise_vel_bound]))
+            self.azimuth_peaks = self.detect_peaks_rows(resp, vel_bins=self.zoomed_vel_bins, min_threshold_dB=30.0)
+            return resp
+
+    cm = make_cm(synth.SYNTH_CFG_256x128x12)
+    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    cube = synth.synth_cube(12)
+    est = Est(cm)
+    resp = est.process(cube)
+    ref, bins = O.doppler_azimuth_precise(cube, sc, rx_antennas=list(range(8)), range_window=[1.0, 12.0],
+                                          vel_range=[-0.25, 0.25], valid_angle_range=(np.deg2rad(-70), np.deg2rad(70)))
+    assert rel_err(resp, ref) <= SPEC_TOL
+    want = est.detect_peaks_rows(ref, vel_bins=bins, min_threshold_dB=30.0)      # same picker on the float64 map
+    assert est.azimuth_peaks.shape == want.shape and want.shape[0] > 0
+    np.testing.assert_array_equal(est.azimuth_peaks[:, 1], want[:, 1])
+    assert np.max(np.abs(est.azimuth_peaks[:, 0] - want[:, 0])) <= 0.06              # at most one angle bin apart
+    est.reset()
