@@ -129,6 +129,13 @@ int mmw_dbs_gather(mmw_ctx *ctx, const float *d_mag, const int *h_ang_idx, const
  *   2-D FFT over (chirp, antenna) -> |.| -> mean over the kept range bins. */
 int mmw_mean_over_range(mmw_ctx *ctx, const float *d_mag, float *d_out, int n_frames,
                         int A, int S, int C, int s_lo, int s_hi);
+/* mmw_doppler_azimuth: d_out[F][C][A] float32 = mean over range rows [s_lo, s_hi) of
+ *   | fftshift_A FFT_A( pad_{V->A}( hann(V) RD[v][s][c] ) ) |, RD = the windowed range-Doppler spectrum of mmw_range_doppler:
+ *   DopplerAzimuthProcessor.process, coarse path (processors/doppler_azimuth_resp.py:84-128,296-334,419-491) in one
+ *   call; the [A][S][C] magnitude cube is never written (the angle FFT, |.| and the range mean are one kernel).
+ *   flags: MMW_ANGLE_NO_WINDOW, MMW_ANGLE_NO_SHIFT.  Same result as mmw_chain3d(MAGNITUDE) + mmw_mean_over_range. */
+int mmw_doppler_azimuth(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int A,
+                        int s_lo, int s_hi, int flags);
 /* mmw_doppler_azimuth_zoom: d_out[F][M][A] float32 = mean over range rows [s_lo, s_hi) of
  *   | fftshift_A FFT_A( pad_{V->A}( hann(V)[v] sum_{c < n_used} R[v][s][c] exp(-j 2 pi c h_freq[k]) ) ) |,
  *   R = FFT_S( hann(S) hann(C) x ), h_freq[M] in cycles per chirp (host array; NaN = a bin the reference fills

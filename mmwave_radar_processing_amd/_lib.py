@@ -56,6 +56,7 @@ _SIGNATURES = {
     "mmw_chain3d_raw": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "mmw_dbs_gather": [_vp, _vp, _ip, _ip, _vp, _i, _i, _i, _i, _i],
     "mmw_mean_over_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "mmw_doppler_azimuth": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i],
     "mmw_doppler_azimuth_zoom": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_d), _i, _i],
     "mmw_range_profile": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_profile_f64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],

@@ -113,6 +113,111 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     return check_launch("angle64");
 }
 
+// k_angle64_rmean: angle FFT + |.| + mean over a range window in one pass -- the tail of
+// DopplerAzimuthProcessor.process (processors/doppler_azimuth_resp.py:320-332,486-489), which never needs the
+// [A][S][C] magnitude cube itself.  Same pruned 8 x 8 DFT as k_angle64; thread = (column, row lane): for each
+// of its rows of the range window it loads the V inputs once, runs the eight k1 passes and adds the 64 x 2 magnitudes
+// to running sums held in registers.  Partial sums per (range partition, row lane) go to
+// part[f][p][rl][a][c]; k_rmean_finish adds them in a fixed order (deterministic) and scales by 1 / rows, writing
+// out[f][c][a].  HBM traffic: the RD rows once plus 1/(rows per partition) of the magnitude cube.
+constexpr int RMEAN_RL = 4;     // row lanes per workgroup (256 threads = 64 columns x 4)
+template <int VIN, bool ZE>
+__global__ __launch_bounds__(256) void k_angle64_rmean(const cplx<float> *__restrict__ rd, float *__restrict__ part, int S,
+                                                        int C, int s_lo, int s_hi, int rows_per_part, AngleWin win,
+                                                        int shift_off) {
+    typedef cplx<float> Cx;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    if (c >= C) return;
+    const int p = blockIdx.y, P = gridDim.y;
+    const long f = blockIdx.z;
+    const long plane = (long)S * C;
+    const Cx *src = rd + f * VIN * plane + c;
+    const int r0 = s_lo + p * rows_per_part, r1 = min(s_hi, r0 + rows_per_part);
+    float *dst = part + (((f * P + p) * RMEAN_RL + rl) * 64) * C + c;
+    // the 64 running sums stay in registers (static indices), so every input row is read exactly once
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    for (int s = r0 + rl; s < r1; s += RMEAN_RL) {
+        Cx x[VIN];
+#pragma unroll
+        for (int v = 0; v < VIN; ++v) {
+            if (ZE && (v == 0 || v == VIN - 1)) {
+                x[v] = Cx{0.f, 0.f};
+                continue;
+            }
+            x[v] = __builtin_nontemporal_load(src + (long)v * plane + (long)s * C) * win.h[v];
+        }
+        static_for<8>([&](auto K1) {
+            constexpr int k1 = decltype(K1)::value;
+            Cx z[8];
+            static_for<8>([&](auto N2) {
+                constexpr int n2 = decltype(N2)::value;
+                Cx y = Cx{0.f, 0.f};
+                if constexpr (n2 < VIN) y = x[n2];
+                if constexpr (n2 + 8 < VIN) y = y + mul_w<8, k1, float, Cx>(x[n2 + 8]);
+                z[n2] = mul_w<64, n2 * k1, float, Cx>(y);
+            });
+            RegFFT<8, float, 8, 0, Cx>::run(z);
+            static_for<8>([&](auto K2) {
+                constexpr int k2 = decltype(K2)::value;
+                const Cx v = z[bitrev<8>(k2)];
+                // v_sqrt_f32 (1 ulp) instead of the refined sqrtf sequence
+                acc[k1 + 8 * k2] += __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y);
+            });
+        });
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k) dst[(long)((k + shift_off) & 63) * C] = acc[k];
+}
+
+// out[f][c][a] = (sum over partitions p and row lanes rl, in that order, of part[f][p][rl][a][c]) / rows
+__global__ __launch_bounds__(256) void k_rmean_finish(const float *__restrict__ part, float *__restrict__ out, long F,
+                                                       int P, int C, float inv_rows) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= F * 64 * C) return;
+    const int c = (int)(gid % C), a = (int)((gid / C) % 64);
+    const long f = gid / ((long)C * 64);
+    float acc = 0.f;
+    for (int q = 0; q < P * RMEAN_RL; ++q) acc += part[((f * P * RMEAN_RL + q) * 64 + a) * C + c];
+    out[(f * C + c) * 64 + a] = acc * inv_rows;
+}
+
+// rd [F][VIN][S][C] c64 -> out [F][C][64] float32; part: scratch of F * P * RMEAN_RL * 64 * C floats
+inline int rmean_partitions(int F, int S, int C, int rows) {
+    const int tiles = (C + 63) / 64;
+    int P = (2048 + F * tiles - 1) / (F * tiles);              // ~2048 workgroups in flight
+    const int max_p = (rows + RMEAN_RL - 1) / RMEAN_RL;        // at least one row per thread
+    if (P > max_p) P = max_p;
+    return P < 1 ? 1 : P;
+}
+
+template <int VIN>
+int launch_angle64_rmean(mmw_ctx *ctx, const void *rd, float *part, size_t part_bytes, float *out, int F, int S, int C,
+                         int s_lo, int s_hi, const float *h, bool shift) {
+    AngleWin w;
+    for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
+    const int rows = s_hi - s_lo;
+    int P = rmean_partitions(F, S, C, rows);
+    const size_t per_p = (size_t)F * RMEAN_RL * 64 * C * sizeof(float);
+    if ((size_t)P * per_p > part_bytes) P = (int)(part_bytes / per_p);     // a short last chunk may not use more scratch
+    if (P < 1) return set_error(MMW_ERR_INVALID, "range-mean scratch too small");
+    const int rpp = (rows + P - 1) / P;
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)P, (unsigned)F);
+    const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f;
+    if (ze)
+        hipLaunchKernelGGL((k_angle64_rmean<VIN, true>), grid, dim3(256), 0, ctx->stream, (const cplx<float> *)rd, part, S, C, s_lo,
+                           s_hi, rpp, w, shift ? 32 : 0);
+    else
+        hipLaunchKernelGGL((k_angle64_rmean<VIN, false>), grid, dim3(256), 0, ctx->stream, (const cplx<float> *)rd, part, S, C,
+                           s_lo, s_hi, rpp, w, shift ? 32 : 0);
+    MMW_TRY(check_launch("angle64_rmean"));
+    const long total = (long)F * 64 * C;
+    hipLaunchKernelGGL(k_rmean_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, part, out, (long)F, P,
+                       C, 1.0f / (float)rows);
+    return check_launch("rmean_finish");
+}
+
 // Raw DCA-style cube [F][num_rx][S][num_tx * C] read in place of the virtual-array cube [F][V][S][C]: virtual
 // antenna v = tx * num_rx + rx takes every num_tx-th chirp starting at tx
 // (VirtualArrayReformatter.process, processors/virtual_array_reformater.py:53-63).  Element (s, c) of plane

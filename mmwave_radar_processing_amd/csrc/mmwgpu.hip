@@ -463,6 +463,61 @@ int mmw_mean_over_range(mmw_ctx *ctx, const float *d_mag, float *d_out, int n_fr
     return check_launch("mean_over_range");
 }
 
+// |angle FFT| averaged over the range rows [s_lo, s_hi): d_rd [nf][V][S][C] c64 -> d_out [nf][C][A] float32.
+// Fused single pass (k_angle64_rmean) when the angle fast path applies, else |angle FFT| cube + k_mean_over_range.
+// d_work: scratch of angle_mean_work_bytes(...) bytes.
+static size_t angle_mean_work_bytes(int nf, int V, int S, int C, int A, int rows) {
+    const bool fused = A == 64 && (V == 4 || V == 8 || V == 12 || V == 16) && !env_int("MMW_NO_FUSED_ANGLE", 0);
+    if (fused) return (size_t)nf * rmean_partitions(nf, S, C, rows) * RMEAN_RL * 64 * C * sizeof(float);
+    return (size_t)nf * A * S * C * sizeof(float);
+}
+
+static int angle_mean_impl(mmw_ctx *ctx, const void *d_rd, void *d_work, size_t work_bytes, float *d_out, int nf, int V,
+                           int S, int C, int A, int s_lo, int s_hi, int flags) {
+    const bool window = !(flags & MMW_ANGLE_NO_WINDOW), shift = !(flags & MMW_ANGLE_NO_SHIFT);
+    const bool fused = A == 64 && (V == 4 || V == 8 || V == 12 || V == 16) && !env_int("MMW_NO_FUSED_ANGLE", 0);
+    if (fused) {
+        ProfScope ps(ctx, "angle_rmean");
+        float h[16];
+        for (int i = 0; i < V; ++i) h[i] = window ? (float)np_window(TAB_HANN, i, V) : 1.f;
+        switch (V) {
+            case 4: return launch_angle64_rmean<4>(ctx, d_rd, (float *)d_work, work_bytes, d_out, nf, S, C, s_lo, s_hi, h, shift);
+            case 8: return launch_angle64_rmean<8>(ctx, d_rd, (float *)d_work, work_bytes, d_out, nf, S, C, s_lo, s_hi, h, shift);
+            case 12: return launch_angle64_rmean<12>(ctx, d_rd, (float *)d_work, work_bytes, d_out, nf, S, C, s_lo, s_hi, h, shift);
+            default: return launch_angle64_rmean<16>(ctx, d_rd, (float *)d_work, work_bytes, d_out, nf, S, C, s_lo, s_hi, h, shift);
+        }
+    }
+    MMW_TRY(angle_fft_impl(ctx, d_rd, d_work, nf, V, S, C, A, (flags & (MMW_ANGLE_NO_WINDOW | MMW_ANGLE_NO_SHIFT)) | MMW_ANGLE_MAGNITUDE));
+    const long total = (long)nf * A * C;
+    hipLaunchKernelGGL(k_mean_over_range, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const float *)d_work, d_out, nf, A, S, C, s_lo, s_hi);
+    return check_launch("mean_over_range");
+}
+
+int mmw_doppler_azimuth(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int A,
+                        int s_lo, int s_hi, int flags) {
+    MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
+    MMW_REQUIRE(0 <= s_lo && s_lo < s_hi && s_hi <= S, "empty or out-of-range row interval [%d, %d)", s_lo, s_hi);
+    MMW_REQUIRE((flags & ~(MMW_ANGLE_NO_WINDOW | MMW_ANGLE_NO_SHIFT)) == 0, "unknown flag bits %d", flags);
+    if (n_frames == 0) return MMW_OK;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t cube_bytes = (size_t)V * S * C * sizeof(float2);
+    long chunk = std::min<long>(n_frames, 65535);
+    while (chunk > 1 && up(chunk * cube_bytes) + angle_mean_work_bytes((int)chunk, V, S, C, A, s_hi - s_lo) > ((size_t)1 << 30))
+        chunk = (chunk + 1) / 2;
+    const size_t work_bytes = angle_mean_work_bytes((int)chunk, V, S, C, A, s_hi - s_lo);
+    MMW_TRY(ensure_scratch(ctx, up(chunk * cube_bytes) + work_bytes));
+    char *d_rd = (char *)ctx->scratch, *d_work = d_rd + up(chunk * cube_bytes);
+    for (long f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = (int)std::min<long>(chunk, n_frames - f0);
+        MMW_TRY(range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, d_rd, nullptr, nf, V, S, C));
+        MMW_TRY(angle_mean_impl(ctx, d_rd, d_work, work_bytes, d_out + (size_t)f0 * C * A, nf, V, S, C, A, s_lo, s_hi, flags));
+    }
+    return MMW_OK;
+}
+
 int mmw_doppler_azimuth_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C, int A,
                              int s_lo, int s_hi, int n_used, const double *h_freq, int M, int flags) {
     MMW_REQUIRE(ctx && d_cubes && d_out && h_freq, "null argument");
@@ -478,14 +533,11 @@ int mmw_doppler_azimuth_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, in
     const int Sk = s_hi - s_lo;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_freq = up((size_t)M * sizeof(double)), b_tab = up((size_t)n_used * M * sizeof(float2));
-    const size_t f_rng = (size_t)V * S * C * sizeof(float2), f_zoom = (size_t)V * Sk * M * sizeof(float2),
-                 f_mag = (size_t)A * Sk * M * sizeof(float);
-    const size_t per_frame = up(f_rng) + up(f_zoom) + up(f_mag);
-    long chunk = (long)(((size_t)1 << 30) / per_frame);       // <= 1 GiB of intermediates per pass
-    if (chunk < 1) chunk = 1;
-    if (chunk > n_frames) chunk = n_frames;
-    if (chunk > 65535) chunk = 65535;
-    MMW_TRY(ensure_scratch(ctx, b_freq + b_tab + (size_t)chunk * per_frame));
+    const size_t f_rng = (size_t)V * S * C * sizeof(float2), f_zoom = (size_t)V * Sk * M * sizeof(float2);
+    long chunk = std::min<long>(n_frames, 65535);
+    auto need = [&](long c) { return up(c * f_rng) + up(c * f_zoom) + up(angle_mean_work_bytes((int)c, V, Sk, M, A, Sk)); };
+    while (chunk > 1 && need(chunk) > ((size_t)1 << 30)) chunk = (chunk + 1) / 2;    // <= 1 GiB of intermediates per pass
+    MMW_TRY(ensure_scratch(ctx, b_freq + b_tab + need(chunk)));
     char *base = (char *)ctx->scratch;
     double *d_freq = (double *)base;
     float2 *d_tab = (float2 *)(base + b_freq);
@@ -518,12 +570,9 @@ int mmw_doppler_azimuth_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, in
                            (size_t)RB * n_used * sizeof(float2), ctx->stream, (const float2 *)d_rng, d_tab,
                            (float2 *)d_zoom, S, C, s_lo, Sk, n_used, M, rows);
         MMW_TRY(check_launch("zoom_rows"));
-        // antenna window + zero-padded angle FFT + |.| on [nf][V][Sk][M], then the mean over the kept range bins
-        MMW_TRY(angle_fft_impl(ctx, d_zoom, d_mag, nf, V, Sk, M, A, flags | MMW_ANGLE_MAGNITUDE));
-        const long total = (long)nf * A * M;
-        hipLaunchKernelGGL(k_mean_over_range, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const float *)d_mag, d_out + (size_t)f0 * M * A, nf, A, Sk, M, 0, Sk);
-        MMW_TRY(check_launch("mean_over_range"));
+        // antenna window + zero-padded angle FFT + |.| on [nf][V][Sk][M] and the mean over the kept range bins
+        MMW_TRY(angle_mean_impl(ctx, d_zoom, d_mag, up(angle_mean_work_bytes((int)chunk, V, Sk, M, A, Sk)), d_out + (size_t)f0 * M * A, nf, V, Sk, M,
+                                A, 0, Sk, flags));
     }
     return MMW_OK;
 }

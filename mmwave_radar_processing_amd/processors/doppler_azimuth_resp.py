@@ -3,8 +3,8 @@
 
 antenna subset -> Hann(S) x Hann(C) (x Hann(V) on the "standard" geometry with virtual antennas) -> range FFT ->
 keep the range bins inside ``range_window`` -> 2-D FFT over (chirp, zero-padded antenna) -> fftshift -> |.| ->
-valid angle columns -> mean over the kept range bins.  On the GPU this is the 3-D chain of
-``mmw_chain3d`` (magnitude output) followed by ``mmw_mean_over_range``.
+valid angle columns -> mean over the kept range bins.  On the GPU this is ``mmw_doppler_azimuth``: the range-Doppler
+kernel followed by one kernel that does the angle FFT, |.| and the range mean without writing the magnitude cube.
 
 ``use_precise_fft=True`` replaces the Doppler FFT by the reference's two ``scipy.signal.ZoomFFT`` calls (one per
 velocity sign) over ``precise_vel_range``; the host derives the frequency of every zoomed bin exactly as the reference
@@ -169,10 +169,8 @@ class DopplerAzimuthProcessor(_Processor):
                 flags & (_lib.ANGLE_NO_WINDOW | _lib.ANGLE_NO_SHIFT)))
             resp = d_out.download((M, A), np.float32).astype(np.float64)
             return resp[:, self.valid_angle_mask]
-        d_mag = bufs.get("da_mag", A * S * C * 4)
         d_out = bufs.get("da_out", C * A * 4)
-        _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_cube.ptr, None, d_mag.ptr, 1, V, S, C, A, flags))
-        _lib.check(ctx.lib.mmw_mean_over_range(ctx.handle, d_mag.ptr, d_out.ptr, 1, A, S, C, int(keep[0]),
-                                               int(keep[-1]) + 1))
+        _lib.check(ctx.lib.mmw_doppler_azimuth(ctx.handle, d_cube.ptr, d_out.ptr, 1, V, S, C, A, int(keep[0]),
+                                               int(keep[-1]) + 1, flags & (_lib.ANGLE_NO_WINDOW | _lib.ANGLE_NO_SHIFT)))
         resp = d_out.download((C, A), np.float32).astype(np.float64)
         return resp[:, self.valid_angle_mask]

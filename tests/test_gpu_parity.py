@@ -929,3 +929,41 @@ def test_subclass_in_the_style_of_velocity_estimator():
     np.testing.assert_array_equal(est.azimuth_peaks[:, 1], want[:, 1])
     assert np.max(np.abs(est.azimuth_peaks[:, 0] - want[:, 0])) <= 0.06              # at most one angle bin apart
     est.reset()
+
+
+@pytest.mark.parametrize("V,S,C,A,win", [(12, 256, 128, 64, (0, 256)), (8, 64, 32, 64, (5, 41)), (4, 63, 70, 64, (0, 63)),
+                                         (12, 63, 100, 64, (10, 11)), (5, 32, 16, 32, (0, 32)), (12, 31, 15, 64, (3, 30))])
+def test_doppler_azimuth_entry_fused_range_mean(V, S, C, A, win, monkeypatch):
+    """mmw_doppler_azimuth (RD kernel + fused angle FFT / |.| / range mean) == mmw_chain3d(MAGNITUDE) +
+    mmw_mean_over_range == the oracle's coarse Doppler-azimuth map, for batches whose last chunk is short too."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F = 7
+    cubes = np.stack([synth.synth_cube(4100 + f, (V, S, C)) for f in range(F)]).astype(np.complex64)
+    d_in, d_mag = ctx.alloc(cubes.nbytes), ctx.alloc(F * A * S * C * 4)
+    d_a, d_b = ctx.alloc(F * C * A * 4), ctx.alloc(F * C * A * 4)
+    d_in.upload(cubes)
+    lo, hi = win
+    for flags in (0, _lib.ANGLE_NO_SHIFT, _lib.ANGLE_NO_WINDOW):
+        _lib.check(L.mmw_doppler_azimuth(h, d_in.ptr, d_a.ptr, F, V, S, C, A, lo, hi, flags))
+        _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_mag.ptr, F, V, S, C, A, flags | _lib.ANGLE_MAGNITUDE))
+        _lib.check(L.mmw_mean_over_range(h, d_mag.ptr, d_b.ptr, F, A, S, C, lo, hi))
+        got, two_pass = d_a.download((F, C, A), np.float32), d_b.download((F, C, A), np.float32)
+        assert rel_err(got, two_pass) <= 2e-6, flags
+        for f in (0, F - 1):
+            x = cubes[f].astype(complex) * np.hanning(S)[None, :, None] * np.hanning(C)[None, None, :]
+            rd = np.fft.fftshift(np.fft.fft2(x, axes=(1, 2)), axes=2)
+            if not flags & _lib.ANGLE_NO_WINDOW:
+                rd = rd * np.hanning(V)[:, None, None]
+            ang = np.fft.fft(rd, n=A, axis=0)
+            if not flags & _lib.ANGLE_NO_SHIFT:
+                ang = np.fft.fftshift(ang, axes=0)
+            ref = np.mean(np.abs(ang[:, lo:hi, :]), axis=1).T                    # [C][A]
+            assert rel_err(got[f], ref) <= SPEC_TOL, (flags, f)
+    monkeypatch.setenv("MMW_NO_FUSED_ANGLE", "1")                               # unfused tail inside the same entry
+    _lib.check(L.mmw_doppler_azimuth(h, d_in.ptr, d_b.ptr, F, V, S, C, A, lo, hi, _lib.ANGLE_NO_WINDOW))
+    assert rel_err(d_b.download((F, C, A), np.float32), got) <= 2e-6
+    assert L.mmw_doppler_azimuth(h, d_in.ptr, d_a.ptr, F, V, S, C, A, hi, hi, 0) == _lib.MMW_ERR_INVALID
+    assert L.mmw_doppler_azimuth(h, d_in.ptr, d_a.ptr, F, V, S, C, A, lo, hi, 1) == _lib.MMW_ERR_INVALID
+    for b in (d_in, d_mag, d_a, d_b):
+        b.free()

@@ -114,16 +114,19 @@ def main():
     run("detect_batch_config3", detect_batch, F * (2 * cube_b + S * C * 4))
     res["mean_detections_per_frame"] = float(d_cnt.download((F,), np.int32).mean())
     # ---- Doppler-azimuth: coarse (3-D chain + range mean) and precise (zoom transform, 2 x 128 bins) modes
-    Fz = min(F, 64)
+    Fz = min(F, 256)
     d_mag3 = ctx.alloc(Fz * A * S * C * 4)
     d_da = ctx.alloc(Fz * 2 * C * A * 4)
 
     def dopaz_coarse():
         _lib.check(L.mmw_chain3d(ctx.handle, d_in.ptr, None, d_mag3.ptr, Fz, V, S, C, A, 1))
         _lib.check(L.mmw_mean_over_range(ctx.handle, d_mag3.ptr, d_da.ptr, Fz, A, S, C, 0, S))
-    run("dopaz_coarse", dopaz_coarse, Fz * (cube_b + out_b // 2))
-    if "dopaz_coarse" in res:
-        res["dopaz_coarse"]["us_per_frame"] = round(1e3 * res["dopaz_coarse"]["ms"] / Fz, 3)
+    run("dopaz_coarse_two_pass", dopaz_coarse, Fz * (cube_b + out_b // 2))
+    run("dopaz_coarse", lambda: _lib.check(L.mmw_doppler_azimuth(ctx.handle, d_in.ptr, d_da.ptr, Fz, V, S, C, A, 0, S, 0)),
+        Fz * cube_b)
+    for key in ("dopaz_coarse_two_pass", "dopaz_coarse"):
+        if key in res:
+            res[key]["us_per_frame"] = round(1e3 * res[key]["ms"] / Fz, 3)
     import ctypes as ct
     zf = np.concatenate((np.linspace(0.974, 1.0, C, endpoint=False), np.linspace(0.0, 0.026, C, endpoint=False)))
     run("dopaz_zoom_256bins", lambda: _lib.check(L.mmw_doppler_azimuth_zoom(
