@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_angle64_rmean(const cplx<float> *__rest
 }
 
 // out[f][c][a] = (sum over partitions p and row lanes rl, in that order, of part[f][p][rl][a][c]) / rows
-__global__ __launch_bounds__(256) void k_rmean_finish(const float *__restrict__ part, float *__restrict__ out, long F,
+static __global__ __launch_bounds__(256) void k_rmean_finish(const float *__restrict__ part, float *__restrict__ out, long F,
                                                        int P, int C, float inv_rows) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= F * 64 * C) return;
@@ -655,18 +655,24 @@ inline bool rd_lds_supported(int S, int C) {
     return false;
 }
 
-inline int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C,
-                         RawView rv = RawView{1, 0}) {
+// launch_rd_lds / launch_rd_fused instantiate ~15 large kernels; they are compiled once, in mmw_tu_rd.hip
+// (MMW_TU_RD), and only declared for the other translation units.
+int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv = RawView{1, 0});
+int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv = RawView{1, 0});
+
+#ifdef MMW_TU_RD
+int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv) {
 #define X(s, c) if (S == s && C == c) return launch_rd_lds_sc<s, c>(ctx, d_in, d_out, planes, rv);
     MMW_RD_LDS_SHAPES(X)
 #undef X
     return set_error(MMW_ERR_UNSUPPORTED, "no LDS-resident RD kernel for %dx%d", S, C);
 }
+#endif  // MMW_TU_RD
 
 inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
 
-inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C,
-                           RawView rv = RawView{1, 0}) {
+#ifdef MMW_TU_RD
+int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv) {
     if (!rd_fused_supported(S, C)) return set_error(MMW_ERR_UNSUPPORTED, "fused RD kernel is 256x128 only");
     const void *hs, *hc, *t256, *t128;
     MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_S, &hs));
@@ -729,5 +735,6 @@ inline int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
                            (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
     return check_launch("rd_fused");
 }
+#endif  // MMW_TU_RD
 
 }  // namespace mmw

@@ -1,8 +1,6 @@
 // libmmwgpu.so -- extern "C" entry points declared in include/mmwgpu.h.
 #include "mmw_ctx.h"
-#include "mmw_fft_generic.h"
-#include "mmw_fft_fused.h"
-#include "mmw_fft_mixed.h"
+#include "mmw_launch.h"
 #include "mmw_cfar.h"
 #include "mmw_misc.h"
 #include "mmw_beamform.h"
