@@ -65,6 +65,90 @@ template <typename G> __device__ double kth_smallest(G get, int n, int k) {
     return f64_unkey(prefix);
 }
 
+// Bitonic sort of npad = 256 * EPT (key, position) pairs by key, 256 threads, element e = EPT * t + q held by thread t
+// in registers.  Exchange distance j < EPT: inside the thread; EPT <= j < 64 EPT: the partner is lane ^ (j / EPT) of the
+// same wave (cross-lane shuffles, no LDS round trip); larger j (3 of the 55 stages at npad = 1024): through the LDS
+// arrays with workgroup barriers.  Equal keys may end in either order (positions travel with their keys), which does
+// not change any order statistic.  On return lds_key / lds_pos hold the sorted sequence.
+template <int EPT>
+__device__ __forceinline__ void bitonic_sort_256(unsigned long long (&key)[EPT], unsigned (&pos)[EPT],
+                                                 unsigned long long *lds_key, unsigned short *lds_pos) {
+    const int t = threadIdx.x, npad = 256 * EPT;
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64 * EPT) {                                   // partner in another wave
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    lds_key[EPT * t + q] = key[q];
+                    lds_pos[EPT * t + q] = (unsigned short)pos[q];
+                }
+                __syncthreads();
+                unsigned long long ok[EPT];
+                unsigned op[EPT];
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    ok[q] = lds_key[(EPT * t + q) ^ j];
+                    op[q] = lds_pos[(EPT * t + q) ^ j];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const int e = EPT * t + q;
+                    const bool take_min = ((e & j) == 0) == ((e & k) == 0);
+                    const bool other_less = ok[q] < key[q];
+                    if (other_less == take_min && ok[q] != key[q]) {
+                        key[q] = ok[q];
+                        pos[q] = op[q];
+                    }
+                }
+            } else if (j >= EPT) {                                 // partner in another lane of this wave
+                const int lane_mask = j / EPT;
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    const unsigned long long ok = __shfl_xor(key[q], lane_mask);
+                    const unsigned op = __shfl_xor(pos[q], lane_mask);
+                    const int e = EPT * t + q;
+                    const bool take_min = ((e & j) == 0) == ((e & k) == 0);
+                    const bool other_less = ok < key[q];
+                    if (other_less == take_min && ok != key[q]) {
+                        key[q] = ok;
+                        pos[q] = op;
+                    }
+                }
+            } else {                                               // both elements in this thread (static register indices)
+                static_for<2>([&](auto JB) {
+                    constexpr int J = 1 << decltype(JB)::value;   // 1, 2
+                    if constexpr (J < EPT) {
+                        if (j == J) {
+                            static_for<EPT>([&](auto Q) {
+                                constexpr int q = decltype(Q)::value, r = q ^ J;
+                                if constexpr (r > q) {
+                                    const int e = EPT * t + q;
+                                    const bool up = (e & k) == 0;
+                                    if ((key[q] > key[r]) == up) {
+                                        const unsigned long long tk = key[q];
+                                        key[q] = key[r];
+                                        key[r] = tk;
+                                        const unsigned tp = pos[q];
+                                        pos[q] = pos[r];
+                                        pos[r] = tp;
+                                    }
+                                }
+                            });
+                        }
+                    }
+                });
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        lds_key[EPT * t + q] = key[q];
+        lds_pos[EPT * t + q] = (unsigned short)pos[q];
+    }
+    __syncthreads();
+}
+
 struct Cfar2dArgs {
     const double *X;
     double *thr, *noise;
@@ -161,28 +245,57 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
     unsigned short *os_integ = os_rank + ((TW * TH + 1) & ~1);
     if (p.kind == MMW_CFAR_OS) {
         const int NT = CFAR_TR * CFAR_TC;
-        for (int t = threadIdx.x; t < npad; t += NT) {
-            os_key[t] = t < TW * TH ? f64_key(tile[t]) : ~0ull;
-            os_pos[t] = (unsigned short)t;
-        }
-        __syncthreads();
-        for (int k = 2; k <= npad; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = threadIdx.x; t < npad / 2; t += NT) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j;
-                    const unsigned long long ka = os_key[i], kb = os_key[q];
-                    const unsigned short pa = os_pos[i], pb = os_pos[q];
-                    const bool a_gt_b = ka > kb || (ka == kb && pa > pb);
-                    if (a_gt_b == ((i & k) == 0)) {
-                        os_key[i] = kb; os_key[q] = ka;
-                        os_pos[i] = pb; os_pos[q] = pa;
+        auto load_sort = [&](auto E) {
+            constexpr int EPT = decltype(E)::value;
+            unsigned long long key[EPT];
+            unsigned pos[EPT];
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                const int e = EPT * threadIdx.x + q;
+                key[q] = e < TW * TH ? f64_key(tile[e]) : ~0ull;
+                pos[q] = (unsigned)e;
+            }
+            bitonic_sort_256<EPT>(key, pos, os_key, os_pos);
+        };
+        if (npad == 1024) load_sort(std::integral_constant<int, 4>{});
+        else if (npad == 512) load_sort(std::integral_constant<int, 2>{});
+        else if (npad == 256) load_sort(std::integral_constant<int, 1>{});
+        else {
+            for (int t = threadIdx.x; t < npad; t += NT) {
+                os_key[t] = t < TW * TH ? f64_key(tile[t]) : ~0ull;
+                os_pos[t] = (unsigned short)t;
+            }
+            __syncthreads();
+            // Compare-exchange t touches elements i and i | j.  For j <= 64 the 64 exchanges of one wave iteration stay
+            // inside one aligned 128-element block that no other wave touches in that stage, and a wave's LDS accesses
+            // complete in program order, so those 45 of the 55 stages (npad = 1024) need no workgroup barrier -- only a
+            // wavefront-scope fence to keep the compiler from carrying values across stages in registers.
+            bool need_barrier = false;
+            for (int k = 2; k <= npad; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    if (j > 64 || need_barrier) __syncthreads();
+                    else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    need_barrier = j > 64;          // the stage after a cross-wave stage must see every wave's writes
+                    for (int t = threadIdx.x; t < npad / 2; t += NT) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j;
+                        const unsigned long long ka = os_key[i], kb = os_key[q];
+                        const unsigned short pa = os_pos[i], pb = os_pos[q];
+                        const bool a_gt_b = ka > kb || (ka == kb && pa > pb);
+                        if (a_gt_b == ((i & k) == 0)) {
+                            os_key[i] = kb; os_key[q] = ka;
+                            os_pos[i] = pb; os_pos[q] = pa;
+                        }
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
-        for (int t = threadIdx.x; t < npad; t += NT)
-            if (os_pos[t] < TW * TH) os_rank[os_pos[t]] = (unsigned short)t;
+        for (int t = threadIdx.x; t < npad; t += NT) {
+            const int pos = os_pos[t];
+            if (pos < TW * TH) os_rank[pos] = (unsigned short)t;
+            // position of rank t as (row << 8 | column); padding entries can never fall inside a window
+            os_pos[t] = pos < TW * TH ? (unsigned short)(((pos / TW) << 8) | (pos % TW)) : (unsigned short)0xFFFF;
+        }
         __syncthreads();
         if (p.os_fast) {
             // integral images of [rank < j * npad/16], j = 1..15, with a zero border row / column
@@ -247,32 +360,23 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
                         below = c;
                     }
                 }
-                // (2) the answer is the (k - below)-th smallest rank inside [j*bucket, (j+1)*bucket): one sweep of
-                //     the window sets a bit per training cell of that bucket, then select the q-th set bit
+                // (2) the answer is the (k - below)-th smallest rank inside [j*bucket, (j+1)*bucket).  The sorted order
+                //     knows where each of those <= 64 ranks sits in the tile (os_pos, repacked as y << 8 | x), so walk
+                //     them in rank order and stop at the q-th one that is a training cell of this window -- about a
+                //     quarter of the tile is, so this takes ~4q steps instead of a sweep of the whole window.
                 const int base = j * bucket;
-                unsigned long long bits = 0;
-                for (int wr = 0; wr < Wr; ++wr) {
-                    const unsigned short *rrow = os_rank + (lr + wr) * TW + lc;
-                    const bool guard_row = wr >= p.tr && wr <= p.tr + 2 * p.gr;
-                    for (int wd = 0; wd < Wd; ++wd) {
-                        if (guard_row && wd >= p.td && wd <= p.td + 2 * p.gd) continue;
-                        const unsigned d = (unsigned)rrow[wd] - (unsigned)base;
-                        if (d < (unsigned)bucket) bits |= 1ull << d;
+                int q = p.k_rank - below;
+                prefix = base;
+                for (int d = 0; d < bucket; ++d) {
+                    const unsigned yx = os_pos[base + d];
+                    const unsigned y = yx >> 8, x = yx & 255u;
+                    const bool in_win = (y - (unsigned)wy0) < (unsigned)Wr && (x - (unsigned)wx0) < (unsigned)Wd;
+                    const bool in_grd = (y - (unsigned)gy0) < (unsigned)(2 * p.gr + 1) && (x - (unsigned)gx0) < (unsigned)(2 * p.gd + 1);
+                    if (in_win && !in_grd && --q == 0) {
+                        prefix = base + d;
+                        break;
                     }
                 }
-                int q = p.k_rank - below, pos = 0;
-                for (int half = 32; half >= 1; half >>= 1) {
-                    const unsigned long long lowmask = (1ull << half) - 1;
-                    const int c = __popcll(bits & lowmask);
-                    if (q > c) {
-                        q -= c;
-                        bits >>= half;
-                        pos += half;
-                    } else {
-                        bits &= lowmask;
-                    }
-                }
-                prefix = base + pos;
             } else {
             // Bisection over the log2(npad) rank bits instead of 64 key bits, on 2-byte LDS reads.
             for (int bit = os_bits - 1; bit >= 0; --bit) {
