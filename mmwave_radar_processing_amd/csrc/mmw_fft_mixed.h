@@ -24,6 +24,18 @@
 
 namespace mmw {
 
+// Rader's algorithm for a prime radix P > 32 (the 127 of the 63x127, 127x32 and 254x50 cfg planes): with a primitive
+// root g, X[g^-q] = x[0] + sum_m x[g^m] W_P^(g^(m-q)) is a cyclic convolution of length L = P - 1 = r1 * r2, evaluated
+// as inverse-DFT( DFT_L(a) * DFT_L(b) ) with the same small-radix levels as everything else:
+// 2 (r1 + r2) + 3 complex MACs per point instead of P.
+struct RaderTab {
+    int P, r1, r2;               // P == 0: no Rader plan for this level (dft_level_big handles it)
+    const int *idx;              // idx[n] = m with g^m = n (n = 1..P-1), idx[P + n] = q with g^-q = n
+    const void *B;               // cplx<T>[L]: DFT_L(b) / L in slot order (slot r2 k1 + k2 = bin k1 + r1 k2)
+    const void *twL;             // cplx<T>[L]: W_L^m
+    const void *m_r1, *m_r2;     // DFT matrices of the two convolution radices
+};
+
 struct RdMixedArgs {
     const void *in;          // cplx<float> planes
     void *out;               // cplx<T> planes, or T |.| planes when MAG
@@ -33,6 +45,7 @@ struct RdMixedArgs {
     const void *win_s, *win_c;          // T[S], T[C]
     const void *tw_s, *tw_c;            // cplx<T>[S], cplx<T>[C]: W_N^m
     const void *m_s1, *m_s2, *m_c1, *m_c2;   // cplx<T>[R][R] DFT matrices
+    RaderTab rad_s, rad_c;   // Rader plans of the first range / Doppler level (radix s1 / c1 > 32)
     int tmp_cells;           // cells of spare LDS behind the plane
     RawView raw;             // ntx > 1: `in` is the raw [F][nrx][S][ntx * C] cube (in_plane_stride unused)
     long planes;             // raw only: planes in the launch (the grid is padded, see raw_block_plane)
@@ -42,7 +55,7 @@ struct RdMixedArgs {
 __device__ __forceinline__ int fast_div(int e, unsigned magic, int d) {
     return d == 1 ? e : (int)__umulhi((unsigned)e, magic);
 }
-inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+__host__ __device__ inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -166,12 +179,85 @@ template <int CLS, int NT, typename T, typename... A> __device__ __forceinline__
 #undef MMW_R
 }
 
+// Same contract as dft_level for a prime radix with a Rader plan.  Works on up to tmp_cells / (P + 1) groups at a
+// time: gather the group in generator order into tmp[m][group] (+ x[0] and, later, the sum), run the forward levels
+// there, multiply by DFT(b)/L and conjugate, run the levels again in decimation-in-time order (an inverse DFT up to
+// the conjugations), and scatter x[0] + conj(.) back over the inputs in output order.
+template <int CLS, int NT, typename T>
+__device__ __forceinline__ void dft_level_rader(const RaderTab &rt, cplx<T> *lds, cplx<T> *tmp, int tmp_cells, int tid,
+                                                int n_inner, unsigned mg_inner, int inner_stride, int n_outer,
+                                                int outer_stride, int estride, const cplx<T> *__restrict__ tw, int N) {
+    const int P = rt.P, L = P - 1, r1 = rt.r1, r2 = rt.r2;
+    const int n_groups = n_inner * n_outer;
+    int chunk = tmp_cells / (P + 1);
+    if (chunk > n_groups) chunk = n_groups;
+    if (chunk < 1) return;
+    const cplx<T> *B = reinterpret_cast<const cplx<T> *>(rt.B), *twL = reinterpret_cast<const cplx<T> *>(rt.twL);
+    for (int g0 = 0; g0 < n_groups; g0 += chunk) {
+        const int ng = (n_groups - g0 < chunk) ? n_groups - g0 : chunk;
+        const unsigned mg = div_magic(ng);
+        cplx<T> *x0 = tmp + L * ng, *sum = x0 + ng;        // [ng] each, behind the [L][ng] work array
+        for (int e = tid; e < ng * P; e += NT) {           // gather, lanes along the groups
+            const int n = fast_div(e, mg, ng), gl = e - n * ng;
+            const int g = g0 + gl;
+            const int o = fast_div(g, mg_inner, n_inner), i = g - o * n_inner;
+            const cplx<T> v = lds[i * inner_stride + o * outer_stride + n * estride];
+            if (n == 0) x0[gl] = v;
+            else tmp[rt.idx[n] * ng + gl] = v;
+        }
+        __syncthreads();
+        // forward: level A over m1 (radix r1, slots r2 m1 + m2), level B over m2; then pointwise; then the same two
+        // radices in the opposite order (slots r2 k1 + k2 -> natural q = r2 n1 + n2)
+        for (int step = 0; step < 4; ++step) {
+            const bool first = (step == 0 || step == 3);   // the radix-r1 levels
+            const int R = first ? r1 : r2;
+            if (R > 1) {
+                const int n_out = first ? r2 : r1, o_stride = first ? ng : r2 * ng, e_stride = first ? r2 * ng : ng;
+                const bool twiddle = r2 > 1 && (step == 0 || step == 2);
+                dft_level_rt<CLS, NT, T>(R, tmp, tid, ng, mg, 1, n_out, o_stride, e_stride,
+                                         reinterpret_cast<const cplx<T> *>(first ? rt.m_r1 : rt.m_r2),
+                                         twiddle ? twL : (const cplx<T> *)nullptr, L);
+                __syncthreads();
+            }
+            if (step == 1) {
+                for (int e = tid; e < ng * L; e += NT) {
+                    const int sl = fast_div(e, mg, ng), gl = e - sl * ng;
+                    const cplx<T> a = tmp[e];
+                    if (sl == 0) sum[gl] = x0[gl] + a;      // bin 0 of DFT(a) is the sum of x[1..P-1]
+                    const cplx<T> v = cmul(a, B[sl]);
+                    tmp[e] = cplx<T>{v.x, -v.y};
+                }
+                __syncthreads();
+            }
+        }
+        for (int e = tid; e < ng * P; e += NT) {           // scatter in output order, inter-level twiddle folded in
+            const int n = fast_div(e, mg, ng), gl = e - n * ng;
+            const int g = g0 + gl;
+            const int o = fast_div(g, mg_inner, n_inner), i = g - o * n_inner;
+            cplx<T> v;
+            if (n == 0) v = sum[gl];
+            else {
+                const cplx<T> c = tmp[rt.idx[P + n] * ng + gl];
+                v = x0[gl] + cplx<T>{c.x, -c.y};
+            }
+            if (tw) v = cmul(v, tw[(o * n) % N]);
+            lds[i * inner_stride + o * outer_stride + n * estride] = v;
+        }
+        __syncthreads();
+    }
+}
+
 template <int CLS, bool BIG, int NT, typename T>
-__device__ __forceinline__ void dft_level_any(int R, cplx<T> *lds, cplx<T> *tmp, int tmp_cells, int tid, int n_inner,
-                                              unsigned mg_inner, int inner_stride, int n_outer, int outer_stride,
-                                              int estride, const cplx<T> *Wm, const cplx<T> *tw, int N) {
+__device__ __forceinline__ void dft_level_any(int R, const RaderTab &rt, cplx<T> *lds, cplx<T> *tmp, int tmp_cells, int tid,
+                                              int n_inner, unsigned mg_inner, int inner_stride, int n_outer,
+                                              int outer_stride, int estride, const cplx<T> *Wm, const cplx<T> *tw, int N) {
     if constexpr (BIG) {
-        if (R > 32) {       // ends with its own barrier
+        if (R > 32) {       // both end with their own barrier
+            if (rt.P == R) {
+                dft_level_rader<CLS, NT, T>(rt, lds, tmp, tmp_cells, tid, n_inner, mg_inner, inner_stride, n_outer, outer_stride,
+                                            estride, tw, N);
+                return;
+            }
             dft_level_big<NT, T>(R, lds, tmp, tmp_cells, tid, n_inner, mg_inner, inner_stride, n_outer, outer_stride, estride, Wm, tw, N);
             return;
         }
@@ -209,16 +295,46 @@ __global__ __launch_bounds__(NT) void k_rd_mixed(RdMixedArgs a) {
     __syncthreads();
     typedef const cplx<T> *CP;
     cplx<T> *tmp = tw_c + C;                     // spare LDS behind them (levels with a radix > 32 only)
-    // range axis: element s = s2 * n1 + n2 lives in row s
-    dft_level_any<CLS, BIG, NT, T>(a.s1, lds, tmp, a.tmp_cells, tid, C, a.mg_C, 1, a.s2, Cp, a.s2 * Cp, (CP)a.m_s1,
-                          a.s2 > 1 ? (CP)tw_s : (CP) nullptr, S);
-    if (a.s2 > 1)
-        dft_level_any<CLS, BIG, NT, T>(a.s2, lds, tmp, a.tmp_cells, tid, C, a.mg_C, 1, a.s1, a.s2 * Cp, Cp, (CP)a.m_s2, (CP) nullptr, S);
-    // Doppler axis: element c = c2 * m1 + m2 lives in column c; lanes walk the rows (pitch Cp is odd)
-    dft_level_any<CLS, BIG, NT, T>(a.c1, lds, tmp, a.tmp_cells, tid, S, a.mg_S, Cp, a.c2, 1, a.c2, (CP)a.m_c1,
-                          a.c2 > 1 ? (CP)tw_c : (CP) nullptr, C);
-    if (a.c2 > 1)
-        dft_level_any<CLS, BIG, NT, T>(a.c2, lds, tmp, a.tmp_cells, tid, S, a.mg_S, Cp, a.c1, a.c2, 1, (CP)a.m_c2, (CP) nullptr, C);
+    // range axis: element s = s2 * n1 + n2 lives in row s: groups (column, n2) radix s1, then (column, k1) radix s2;
+    // Doppler axis: element c = c2 * m1 + m2 lives in column c; lanes walk the rows (pitch Cp is odd).
+    if constexpr (!BIG) {
+        // four call sites: the strides that are 1 fold into the address arithmetic
+        const RaderTab none{};
+        dft_level_any<CLS, BIG, NT, T>(a.s1, none, lds, tmp, 0, tid, C, a.mg_C, 1, a.s2, Cp, a.s2 * Cp, (CP)a.m_s1,
+                                       a.s2 > 1 ? (CP)tw_s : (CP) nullptr, S);
+        if (a.s2 > 1)
+            dft_level_any<CLS, BIG, NT, T>(a.s2, none, lds, tmp, 0, tid, C, a.mg_C, 1, a.s1, a.s2 * Cp, Cp, (CP)a.m_s2, (CP) nullptr, S);
+        dft_level_any<CLS, BIG, NT, T>(a.c1, none, lds, tmp, 0, tid, S, a.mg_S, Cp, a.c2, 1, a.c2, (CP)a.m_c1,
+                                       a.c2 > 1 ? (CP)tw_c : (CP) nullptr, C);
+        if (a.c2 > 1)
+            dft_level_any<CLS, BIG, NT, T>(a.c2, none, lds, tmp, 0, tid, S, a.mg_S, Cp, a.c1, a.c2, 1, (CP)a.m_c2, (CP) nullptr, C);
+    } else {
+    // kernels with a big level: one call site in a loop over the four levels, so the Rader / big-radix code and the
+    // radix switch behind it are inlined once
+    for (int lvl = 0; lvl < 4; ++lvl) {
+        const bool rng = lvl < 2, lead = (lvl & 1) == 0;
+        const int ra = rng ? a.s1 : a.c1, rb = rng ? a.s2 : a.c2;
+        if (!lead && rb == 1) continue;
+        const int R = lead ? ra : rb;
+        const int n_inner = rng ? C : S, inner_stride = rng ? 1 : Cp, unit = rng ? Cp : 1;
+        const int n_outer = lead ? rb : ra, o_stride = lead ? unit : rb * unit, e_stride = lead ? rb * unit : unit;
+        const void *Wm = rng ? (lead ? a.m_s1 : a.m_s2) : (lead ? a.m_c1 : a.m_c2);
+        const cplx<T> *tw = (lead && rb > 1) ? (rng ? tw_s : tw_c) : (const cplx<T> *)nullptr;
+        // field-wise selects keep the plan in scalar registers (a run-time choice between the two structs would make
+        // the compiler copy the whole kernel argument block to scratch)
+        RaderTab rt;
+        rt.P = lead ? (rng ? a.rad_s.P : a.rad_c.P) : 0;
+        rt.r1 = rng ? a.rad_s.r1 : a.rad_c.r1;
+        rt.r2 = rng ? a.rad_s.r2 : a.rad_c.r2;
+        rt.idx = rng ? a.rad_s.idx : a.rad_c.idx;
+        rt.B = rng ? a.rad_s.B : a.rad_c.B;
+        rt.twL = rng ? a.rad_s.twL : a.rad_c.twL;
+        rt.m_r1 = rng ? a.rad_s.m_r1 : a.rad_c.m_r1;
+        rt.m_r2 = rng ? a.rad_s.m_r2 : a.rad_c.m_r2;
+        dft_level_any<CLS, BIG, NT, T>(R, rt, lds, tmp, a.tmp_cells, tid, n_inner,
+                                       rng ? a.mg_C : a.mg_S, inner_stride, n_outer, o_stride, e_stride, (CP)Wm, tw, rng ? S : C);
+    }
+    }
     // bin k = k1 + s1 k2 sits in row s2 k1 + k2 (same along the Doppler axis); fftshift: out[(d + C/2) % C] = X[d]
     const long obase = plane * cells;
     const int half = C / 2;
@@ -239,6 +355,20 @@ __global__ __launch_bounds__(NT) void k_rd_mixed(RdMixedArgs a) {
 // ------------------------------------------------------------------ host side: factorisation and launch
 // N = n1 * n2 (n1 >= n2) with the least n1 + n2 plus a per-level overhead; n2 == 1: one level.  Radices up to
 // max_small run in registers, larger ones through dft_level_big when big_ok.
+inline bool is_prime(int n) {
+    if (n < 2) return false;
+    for (int d = 2; (long)d * d <= n; ++d)
+        if (n % d == 0) return false;
+    return true;
+}
+
+inline int mixed_axis(int N, int max_small, bool big_ok, int *n1, int *n2);
+
+// Rader plan for a prime radix P > 32: P - 1 = r1 * r2 with both convolution radices in the register class.
+inline bool rader_factors(int P, int max_small, int *r1, int *r2) {
+    return P > 32 && is_prime(P) && mixed_axis(P - 1, max_small, false, r1, r2) >= 0;
+}
+
 inline int mixed_axis(int N, int max_small, bool big_ok, int *n1, int *n2) {
     int best = -1;
     for (int a = 1; a <= N; ++a) {
@@ -246,7 +376,11 @@ inline int mixed_axis(int N, int max_small, bool big_ok, int *n1, int *n2) {
         const int b = N / a;
         if (a < b || b > max_small) continue;
         if (a > max_small && (a <= 32 || !big_ok)) continue;
-        const int ca = a > 32 ? 2 * a : a;      // a level out of the LDS costs about twice its MAC count
+        int ca = a;
+        if (a > 32) {                           // out of the LDS: Rader (~2 (r1 + r2) MACs + 6 LDS passes) or direct (~2 a)
+            int r1, r2;
+            ca = rader_factors(a, max_small, &r1, &r2) ? 2 * (r1 + r2) + 16 : 2 * a;
+        }
         const int cost = (b == 1) ? ca + 3 : ca + b + 6;
         if (best < 0 || cost < best) {
             best = cost;
@@ -259,6 +393,7 @@ inline int mixed_axis(int N, int max_small, bool big_ok, int *n1, int *n2) {
 
 struct RdMixedPlan {
     int cls, big, s1, s2, c1, c2, Cp, tmp_cells;
+    int rad_s[2], rad_c[2];      // Rader convolution radices of a prime s1 / c1 > 32 ({0, 0}: none)
     size_t lds_bytes;
 };
 
@@ -280,18 +415,20 @@ inline bool rd_mixed_plan(int S, int C, size_t elem_bytes, RdMixedPlan *out) {
             if (cs < 0 || cc < 0) continue;
             const int r_big = std::max(pl.s1 > 32 ? pl.s1 : 0, pl.c1 > 32 ? pl.c1 : 0);
             if (big && !r_big) continue;                        // same plan as the variant without the big level
-            if (r_big && spare < 32 * r_big) continue;          // a big level wants >= half a wave of groups in the spare LDS
+            if (r_big && spare < 32 * (r_big + 1)) continue;    // a big level wants >= half a wave of groups in the spare LDS
             const int cost = (cs + cc) * 8 + cls;               // ties: the leaner register class
             if (best >= 0 && cost >= best) continue;
             best = cost;
             pl.cls = cls;
             pl.big = r_big ? 1 : 0;
             pl.Cp = Cp;
+            if (!rader_factors(pl.s1, max_small, &pl.rad_s[0], &pl.rad_s[1])) pl.rad_s[0] = pl.rad_s[1] = 0;
+            if (!rader_factors(pl.c1, max_small, &pl.rad_c[0], &pl.rad_c[1])) pl.rad_c[0] = pl.rad_c[1] = 0;
             // spare LDS for the big levels: all their groups if they fit, at most two waves of groups
             int g_big = 0;
             if (pl.s1 > 32) g_big = std::max(g_big, C * pl.s2);
             if (pl.c1 > 32) g_big = std::max(g_big, S * pl.c2);
-            pl.tmp_cells = r_big ? std::min(spare, std::min(128, g_big) * r_big) : 0;
+            pl.tmp_cells = r_big ? std::min(spare, std::min(128, g_big) * (r_big + 1)) : 0;
             pl.lds_bytes = plane + (size_t)pl.tmp_cells * elem_bytes;
             *out = pl;
         }
@@ -301,6 +438,76 @@ inline bool rd_mixed_plan(int S, int C, size_t elem_bytes, RdMixedPlan *out) {
 inline bool rd_mixed_supported(int S, int C) {
     RdMixedPlan pl;
     return rd_mixed_plan(S, C, sizeof(cplx<float>), &pl);
+}
+
+// Device tables of a Rader plan (cached in the context): index maps for the smallest primitive root g of P and
+// DFT_L(b) / L, b[m] = W_P^(g^-m), in the slot order of the two-level DFT (long double on the host, rounded once).
+template <typename T>
+int get_rader_tables(mmw_ctx *ctx, int P, int r1, int r2, RaderTab *rt) {
+    const int L = P - 1;
+    rt->P = P;
+    rt->r1 = r1;
+    rt->r2 = r2;
+    MMW_TRY(get_table<T>(ctx, TAB_TWIDDLE, L, &rt->twL));
+    MMW_TRY(get_table<T>(ctx, TAB_DFTMAT, r1, &rt->m_r1));
+    MMW_TRY(get_table<T>(ctx, TAB_DFTMAT, r2, &rt->m_r2));
+    const auto key_idx = std::make_tuple(100, P, 0);
+    const auto key_b = std::make_tuple(101, P * 4096 + r1 * 64 + r2, (int)(sizeof(T) == 8));
+    auto it_i = ctx->tables.find(key_idx), it_b = ctx->tables.find(key_b);
+    if (it_i != ctx->tables.end() && it_b != ctx->tables.end()) {
+        rt->idx = (const int *)it_i->second;
+        rt->B = it_b->second;
+        return MMW_OK;
+    }
+    auto powmod = [&](long b, long e) {
+        long r = 1;
+        for (b %= P; e > 0; e >>= 1, b = b * b % P)
+            if (e & 1) r = r * b % P;
+        return r;
+    };
+    int g = 2;
+    for (;; ++g) {                                      // smallest primitive root
+        bool ok = true;
+        int rest = L;
+        for (int q = 2; q <= rest && ok; ++q)
+            if (rest % q == 0) {
+                if (powmod(g, L / q) == 1) ok = false;
+                while (rest % q == 0) rest /= q;
+            }
+        if (ok) break;
+    }
+    std::vector<int> perm(L), idx(2 * P, 0);
+    for (int m = 0; m < L; ++m) perm[m] = (int)powmod(g, m);
+    for (int m = 0; m < L; ++m) idx[perm[m]] = m;
+    for (int n = 1; n < P; ++n) idx[P + n] = (L - idx[n]) % L;         // g^-q = n  <=>  q = (L - m) mod L
+    std::vector<T> hb(2 * (size_t)L);
+    for (int k1 = 0; k1 < r1; ++k1)
+        for (int k2 = 0; k2 < r2; ++k2) {
+            const int k = k1 + r1 * k2;
+            long double re = 0, im = 0;
+            for (int m = 0; m < L; ++m) {
+                const long e1 = perm[(L - m) % L];                       // b[m] = W_P^(g^-m)
+                const long double ang = -2.0L * M_PIl * ((long double)e1 / P + (long double)(((long)m * k) % L) / L);
+                re += cosl(ang);
+                im += sinl(ang);
+            }
+            hb[2 * (size_t)(r2 * k1 + k2)] = (T)(re / L);
+            hb[2 * (size_t)(r2 * k1 + k2) + 1] = (T)(im / L);
+        }
+    void *d_idx = nullptr, *d_b = nullptr;
+    if (it_i == ctx->tables.end()) {
+        if (hipMalloc(&d_idx, idx.size() * sizeof(int)) != hipSuccess) return set_error(MMW_ERR_NOMEM, "hipMalloc for Rader index table failed");
+        MMW_HIP(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        ctx->tables[key_idx] = d_idx;
+    } else
+        d_idx = it_i->second;
+    if (hipMalloc(&d_b, hb.size() * sizeof(T)) != hipSuccess) return set_error(MMW_ERR_NOMEM, "hipMalloc for Rader spectrum table failed");
+    MMW_HIP(hipMemcpyAsync(d_b, hb.data(), hb.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    MMW_HIP(hipStreamSynchronize(ctx->stream));         // host vectors go out of scope
+    ctx->tables[key_b] = d_b;
+    rt->idx = (const int *)d_idx;
+    rt->B = d_b;
+    return MMW_OK;
 }
 
 // planes x [S][C] complex64 at d_in (plane pitch in_plane_stride elements) -> d_out planes, contiguous:
@@ -323,6 +530,8 @@ int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
     a.c1 = pl.c1;
     a.c2 = pl.c2;
     a.tmp_cells = pl.tmp_cells;
+    if (pl.rad_s[0]) MMW_TRY(get_rader_tables<T>(ctx, pl.s1, pl.rad_s[0], pl.rad_s[1], &a.rad_s));
+    if (pl.rad_c[0]) MMW_TRY(get_rader_tables<T>(ctx, pl.c1, pl.rad_c[0], pl.rad_c[1], &a.rad_c));
     a.raw = rv;
     a.planes = planes;
     a.mg_C = div_magic(C);
