@@ -30,16 +30,22 @@ ALGO_BYTES_PER_FRAME = CUBE_BYTES + OUT_BYTES   # 19,922,944 B (co
 HBM_PEAK_GBS = 8000.0                           # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(seconds: float = 12.0, gpu_frame=None):
-    """Oracle (float64 NumPy restatement of the reference chain) timed on one host core.
+def parity_check(frames):
+    """``frames`` = [(label, cube, gpu_result)]: the oracle's result for the same bytes, max relative error per frame."""
+    from oracle import oracle_np as O
+    errs = {}
+    for label, cube, got in frames:
+        ref = O.fft3d_windowed(cube, A)
+        errs[label] = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+    return errs
 
-    ``gpu_frame = (cube, gpu_result)``: frame 0 of the bench's own batch and what the GPU made of it; the oracle's
-    result for that cube doubles as the parity check of the run (reported as ``parity_max_rel_err_frame0``)."""
+
+def cpu_baseline(seconds: float = 12.0):
+    """Oracle (float64 NumPy restatement of the reference chain) timed on one host core."""
     from mmwave_radar_processing_amd import synth
     from oracle import oracle_np as O
     cubes = [synth.synth_cube(1000 + i) for i in range(4)]
-    ref0 = O.fft3d_windowed(cubes[0] if gpu_frame is None else gpu_frame[0], A)     # also warms numpy's FFT plan cache
-    parity = None if gpu_frame is None else float(np.max(np.abs(gpu_frame[1] - ref0)) / np.max(np.abs(ref0)))
+    O.fft3d_windowed(cubes[0], A)     # warms numpy's FFT plan cache
     n, t0 = 0, time.perf_counter()
     while True:
         O.fft3d_windowed(cubes[n % len(cubes)], A)
@@ -49,8 +55,7 @@ def cpu_baseline(seconds: float = 12.0, gpu_frame=None):
             break
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n} frames of the same synthetic 12x256x128 workload through oracle_np.fft3d_windowed "
-                      f"(float64 NumPy, single thread) in {dt:.1f} s",
-            "parity_max_rel_err_frame0": parity}
+                      f"(float64 NumPy, single thread) in {dt:.1f} s"}
 
 
 def _cpu_worker(args):
@@ -65,10 +70,21 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_pool(per_proc_frames: int = 24):
-    """The embarrassingly-parallel bound of the CPU path: one process per host core, one frame per task."""
+def host_cores() -> int:
+    """Physical cores this process may use (the pool has one single-threaded process per physical core)."""
+    allowed = len(os.sched_getaffinity(0))
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or allowed
+    except Exception:
+        phys = allowed
+    return max(1, min(allowed, phys))
+
+
+def cpu_baseline_pool(per_proc_frames: int = 16):
+    """The embarrassingly-parallel bound of the CPU path: one process per physical host core, one frame per task."""
     import multiprocessing as mp
-    procs = max(1, min(len(os.sched_getaffinity(0)), 64))
+    procs = host_cores()
     with mp.get_context("spawn").Pool(procs) as pool:
         pool.map(_cpu_worker, [(2000 + i, 1) for i in range(procs)])          # warm-up / imports
         t0 = time.perf_counter()
@@ -76,8 +92,8 @@ def cpu_baseline_pool(per_proc_frames: int = 24):
         dt = time.perf_counter() - t0
     n = procs * per_proc_frames
     return {"value": n / dt, "unit": "frames/s", "cores": procs, "kind": "port",
-            "sample": f"{n} frames over a {procs}-process pool (one single-threaded NumPy process per host core) "
-                      f"in {dt:.1f} s"}
+            "sample": f"{n} frames over a {procs}-process pool (one single-threaded NumPy process per physical host "
+                      f"core; {len(os.sched_getaffinity(0))} logical CPUs allowed) in {dt:.1f} s"}
 
 
 def baseline_metric() -> str:
@@ -89,17 +105,40 @@ def baseline_metric() -> str:
         return "radar frames/s on 256\u00d7128\u00d712 ADC cube, 1/2/4/8 GPU; % HBM roofline"
 
 
-def chunk_frames(n_frames: int) -> int:
-    """Frames per kernel launch of mmw_chain3d's default overlapped schedule (csrc/mmwgpu.hip)."""
-    env = os.environ.get("MMW_CHAIN_CHUNK")
-    if env:
-        return max(1, min(int(env), n_frames))
-    rd_cus = int(os.environ.get("MMW_RD_CUS", 256 * 5 // 8))
-    auto = (250 << 20) // (2 * CUBE_BYTES)
-    waves = auto * V // rd_cus
-    if waves >= 1:
-        auto = waves * rd_cus // V
-    return max(1, min(auto, n_frames))
+def chain_plan(ctx, n_frames: int) -> dict:
+    """The schedule mmw_chain3d uses for this batch, asked of the library itself (mmw_diag_chain_plan)."""
+    import ctypes
+    from mmwave_radar_processing_amd import _lib
+    plan = (ctypes.c_int * 8)()
+    _lib.check(ctx.lib.mmw_diag_chain_plan(ctx.handle, n_frames, V, S, C, A, 0, plan))
+    return {"overlapped": bool(plan[0]), "frames_per_launch_max": plan[1], "ring": plan[2], "rd_cus": plan[3],
+            "rd_planes_per_frame": plan[4], "lean_angle_kernel": bool(plan[5]), "device_sync": bool(plan[6]),
+            "ring_frames": plan[7]}
+
+
+def insitu_ceiling(ctx, d_buf, nbytes: int) -> dict:
+    """What plain streaming kernels reach on this device, right now: 16-B/lane grid-stride kernels over up to 4 GiB of
+    the (already checked) output buffer, swept over the grid size, best of each kind reported -- the practical ceiling
+    next to the 8 TB/s spec peak.  mode 1 = plain stores, 3 = non-temporal stores, 0 = copy, 2 = read."""
+    from mmwave_radar_processing_amd import _lib
+    nb = min(nbytes, 4 << 30) // 64 * 64
+    best = {}
+    for name, mode in (("write", 1), ("write_nt", 3), ("copy", 0), ("read", 2)):
+        span = nb // 2 if mode == 0 else nb
+        for per_cu in (2, 4, 8, 16, 32):
+            blocks = per_cu * 256
+            call = lambda: _lib.check(ctx.lib.mmw_diag_membw(ctx.handle, d_buf.ptr, d_buf.ptr + (span if mode == 0 else 0),
+                                                             span, mode, blocks))
+            call()
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(3):
+                call()
+            gbs = nb / (ctx.timer_stop() / 3) / 1e6
+            if gbs > best.get(name + "_GBs", 0.0):
+                best[name + "_GBs"] = gbs
+                best[name + "_blocks_per_cu"] = per_cu
+    return best
 
 
 class stdout_to_stderr:
@@ -188,6 +227,8 @@ def main():
     if rank == 0:
         total_frames = world * F * args.steps
         value = total_frames / elapsed
+        plan = chain_plan(ctx, F)
+        n_launch = -(-F // plan["frames_per_launch_max"])           # kernel launches of each stage per step
         out = {
             "metric": baseline_metric(),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,9 +238,7 @@ def main():
                                    "64-bin angle FFT -> complex64 [64,256,128] (BASELINE configs[1])",
                        "frames_per_gpu": F, "cube": [V, S, C], "angle_bins": A,
                        "sharding": f"frame-sharded x{world}, no collective",
-                       "schedule": "overlapped: fused range-Doppler kernel on 5/8 of the CUs beside the angle kernel on "
-                                   "3/8, 40-frame chunks, RD->angle intermediate resident in Infinity Cache "
-                                   "(override: MMW_CHAIN_PIPELINE / MMW_CHAIN_CHUNK / MMW_RD_CUS)",
+                       "schedule": plan,
                        "device": info["name"], "arch": info["arch"]},
             "hip_event_ms_per_step_rank0": ev_ms / args.steps,
             "chain_hbm_frac_of_8TBs": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),
@@ -209,51 +248,43 @@ def main():
             rd_ms, rd_n = ctx.profile_get("rd")
             if ang_n:
                 # sampled launches: full 40-frame chunks and the tail chunk are hit in proportion
-                frames_per_launch = F / -(-F // chunk_frames(F))
+                frames_per_launch = F / n_launch
                 avg_s = ang_ms * 1e-3 / ang_n
                 achieved = frames_per_launch * ALGO_BYTES_PER_FRAME / avg_s / 1e9
-                traffic = None
+                traffic, traffic_src = None, None
                 if os.path.exists(args.traffic_json):
                     with open(args.traffic_json) as fh:
                         per_frame = json.load(fh).get("angle_bytes_per_frame")
                     traffic = per_frame * frames_per_launch if per_frame else None
+                    traffic_src = ("static: PMC bytes per frame from " + os.path.relpath(args.traffic_json, ROOT) +
+                                   " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, FETCH "
+                                   "doubled per the gfx950 note) x frames per launch; not measured in this run")
                 out["roofline"] = {"bound": "hbm", "kernel": "k_angle64 (angle FFT, reads V planes / writes 64)",
                                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                    "avg_launch_us": avg_s * 1e6, "launches": ang_n,
                                    "frames_per_launch": frames_per_launch,
                                    "algorithmic_bytes_per_launch": frames_per_launch * ALGO_BYTES_PER_FRAME}
             if rd_n:
-                fpl = F / -(-F // chunk_frames(F))
+                fpl = F / n_launch
                 avg_s = rd_ms * 1e-3 / rd_n
+                rd_bytes = 2 * CUBE_BYTES * plan["rd_planes_per_frame"] / V      # planes read + planes written
                 out["rd_kernel"] = {"avg_launch_us": avg_s * 1e6, "launches": rd_n,
-                                    "achieved_GBs": fpl * 2 * CUBE_BYTES / avg_s / 1e9,
-                                    "algorithmic_bytes_per_launch": fpl * 2 * CUBE_BYTES}
-        # frame 0 of the bench's own data, saved for the parity check inside the cpu_baseline leg (not timed)
-        cube0 = d_in.download((V, S, C), np.complex64)
-        got0 = d_out.download((A, S, C), np.complex64)
+                                    "achieved_GBs": fpl * rd_bytes / avg_s / 1e9,
+                                    "algorithmic_bytes_per_launch": fpl * rd_bytes}
+        # parity of this very run: first frame, a frame inside the last full launch and the batch's last frame (the
+        # short tail launch), against the oracle on the SAME bytes -- not timed
+        picks = sorted({0, max(0, (n_launch - 1) * plan["frames_per_launch_max"] - 1), F - 1})
+        saved = [(f"frame{f}", d_in.download((V, S, C), np.complex64, f * CUBE_BYTES),
+                  d_out.download((A, S, C), np.complex64, f * OUT_BYTES)) for f in picks]
         if "roofline" in out:
-            # what plain streaming kernels reach on this device, right now (16-B/lane grid-stride write and copy over
-            # 2 GiB of the output buffer, after frame 0 was saved): the practical ceiling next to the 8 TB/s spec peak
-            nb = min(F * A * S * C * 8, 2 << 30) // 32 * 32
-            insitu = {}
-            for name, mode, moved in (("write", 1, nb), ("copy", 0, nb)):
-                span = nb if mode == 1 else nb // 2
-                call = lambda: _lib.check(ctx.lib.mmw_diag_membw(ctx.handle, d_out.ptr, d_out.ptr + (0 if mode == 1 else span),
-                                                                 span, mode, 0))
-                call()
-                ctx.sync()
-                ctx.timer_start()
-                for _ in range(5):
-                    call()
-                insitu[name + "_GBs"] = moved / (ctx.timer_stop() / 5) / 1e6
-            out["roofline"]["insitu_streaming_ceiling"] = insitu
+            out["roofline"]["insitu_streaming_ceiling"] = insitu_ceiling(ctx, d_out, F * OUT_BYTES)
+        out["parity_max_rel_err"] = parity_check(saved)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(gpu_frame=(cube0, got0))
-            out["parity_max_rel_err_frame0"] = out["cpu_baseline"]["parity_max_rel_err_frame0"]
+            out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_all_cores"] = cpu_baseline_pool()
         print(json.dumps(out))
-        if out.get("parity_max_rel_err_frame0") is not None and not out["parity_max_rel_err_frame0"] <= 1e-5:
+        if not max(out["parity_max_rel_err"].values()) <= 1e-5:
             sys.exit("bench.py: GPU chain output differs from the oracle beyond 1e-5 -- the figure above is invalid")
     if dist is not None:
         with stdout_to_stderr():

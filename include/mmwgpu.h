@@ -228,6 +228,13 @@ int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, i
  * for the mixed-radix kernel plan[1..7] = register class, has a run-time-radix level, S1, S2, C1, C2 (S = S1 S2,
  * C = C1 C2), dynamic LDS bytes.  float64 != 0 asks for the float64 CFAR-plane variant. */
 int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]);
+/* Schedule mmw_chain3d(d_rd = NULL) would use for this batch on this context (host logic + environment knobs only):
+ * plan[0] = 1 overlapped (range-Doppler || angle on two queues) / 0 serial, plan[1] = frames per kernel launch,
+ * plan[2] = ring depth of range-Doppler chunks in flight, plan[3] = CUs of the range-Doppler queue (0 = unmasked),
+ * plan[4] = range-Doppler planes transformed per frame (V, or V - 2 when the zero-weight end antennas of the
+ * Hann(V) window are skipped), plan[5] = 1 if the register-lean angle kernel is selected.  bench.py derives its
+ * bytes-per-launch from this instead of restating the rule. */
+int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, int flags, int plan[8]);
 
 /* ---------------------------------------------------------------- per-kernel timing hook for bench.py
  * Average duration (ms) of the most recent launch group of the named kernel family measured

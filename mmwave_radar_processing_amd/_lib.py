@@ -72,6 +72,7 @@ _SIGNATURES = {
     "mmw_abs_c64": [_vp, _vp, _vp, _sz],
     "mmw_diag_membw": [_vp, _vp, _vp, _sz, _i, _i],
     "mmw_diag_rd_plan": [_i, _i, _i, _ip],
+    "mmw_diag_chain_plan": [_vp, _i, _i, _i, _i, _i, _i, _ip],
     "mmw_profile_enable": [_vp, _i],
     "mmw_profile_get": [_vp, C.c_char_p, C.POINTER(_f), _ip],
     "mmw_profile_reset": [_vp],

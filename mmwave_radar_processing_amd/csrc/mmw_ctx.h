@@ -56,6 +56,8 @@ struct ProfileSlot {
 
 enum TableKind { TAB_TWIDDLE = 0, TAB_HANN = 1, TAB_HAMMING = 2, TAB_DFTMAT = 3 };   // DFTMAT: W_N^(jk), [N][N]
 
+constexpr int PIPE_RING_MAX = 4;      // deepest ring of RD chunks of the overlapped chain
+
 struct PendingSpan {
     const char *family;
     hipEvent_t e0, e1;
@@ -69,10 +71,19 @@ struct mmw_ctx {
     int active_cus = 0;                         // CUs of the queue being launched on (0 = all), set by the chain
     hipStream_t stream = nullptr;
     // overlapped chain (DESIGN.md "chain schedule"): two CU-masked queues + ordering events, created lazily
-    hipStream_t q_rd = nullptr, q_ang = nullptr;
+    hipStream_t q_rd = nullptr, q_ang = nullptr, q_ang2 = nullptr;
     int q_rd_cus = 0;
-    hipEvent_t pipe_rd[2] = {nullptr, nullptr}, pipe_ang[2] = {nullptr, nullptr}, pipe_begin = nullptr;
-    bool pipe_ang_used[2] = {false, false};
+    hipEvent_t pipe_rd[mmw::PIPE_RING_MAX] = {}, pipe_ang[mmw::PIPE_RING_MAX] = {}, pipe_begin = nullptr;
+    bool pipe_ang_used[mmw::PIPE_RING_MAX] = {};
+    size_t pipe_slot_bytes = 0;  // ring layout of the last overlapped chain call (a change forces a full hand-over)
+    int pipe_ring = 0;
+    bool pipe_unavailable = false;   // queue creation failed once: the chain stays on its serial schedule
+    // device-synchronised chain (ChainSync in mmw_fft_fused.h): control block + host mirror of the monotone counters
+    unsigned *chain_ctl = nullptr;
+    unsigned long long chain_g = 0;          // frames handed through the ring since the layout was set up
+    unsigned chain_rd_base = 0, chain_ang_base = 0;
+    long chain_layout[6] = {0, 0, 0, 0, 0, 0};   // V, S*C, vskip, ring, tiles, ring base address
+    bool chain_dirty = false;                // sync-mode work was enqueued since the abort word was last checked
     bool rd_attr_set = false;    // hipFuncSetAttribute(max dynamic LDS) done for this context's device
     bool pipe_pending = false;   // chain work in flight on q_rd/q_ang that the context stream has not joined yet
     hipEvent_t t0 = nullptr, t1 = nullptr;      // mmw_timer_*
@@ -154,7 +165,7 @@ template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **
 inline int join_pipe(mmw_ctx *ctx) {
     MMW_HIP(hipSetDevice(ctx->device));     // several contexts (devices) may live in one process
     if (!ctx->pipe_pending) return MMW_OK;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < PIPE_RING_MAX; ++i)
         if (ctx->pipe_ang_used[i]) MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_ang[i], 0));
     ctx->pipe_pending = false;
     return MMW_OK;
@@ -167,6 +178,7 @@ inline int ensure_scratch(mmw_ctx *ctx, size_t bytes) {
         if (ctx->q_rd) {
             MMW_HIP(hipStreamSynchronize(ctx->q_rd));
             MMW_HIP(hipStreamSynchronize(ctx->q_ang));
+            MMW_HIP(hipStreamSynchronize(ctx->q_ang2));
         }
         MMW_HIP(hipStreamSynchronize(ctx->stream));
         MMW_HIP(hipFree(ctx->scratch));

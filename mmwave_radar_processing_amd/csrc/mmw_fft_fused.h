@@ -21,35 +21,63 @@ struct AngleWin {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// NT: streaming (non-temporal) stores for the write-once output cube.
-// ZE:  the window's end points are exactly zero (np.hanning): antennas 0 and V-1 contribute nothing, so their
-//      planes are neither loaded nor multiplied (identical results for finite input; -17 % loads, ~-10 % VALU).
-// The kernel is VALU-bound per CU (~44 GB/s/CU; it needs >= 128 CUs to saturate HBM).  hipcc CSEs the
-// x[n] +- rot(x[n+8]) terms across the eight unrolled k1 passes (172 VGPRs, 2 waves/SIMD); forcing the passes
-// apart (90 VGPRs, 5 waves/SIMD) or scalar re/im math (95 VGPRs) was 10-20 % SLOWER per CU -- measured.
-template <int VIN, bool MAG, bool NT, bool ZE>
-__global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, void *__restrict__ out,
-                                                  long pairs_per_frame, AngleWin win, int shift_off) {
-    typedef cplx<float> C;
-    // grid.x covers pairs of adjacent bins of one frame; grid.y = frame
-    const long pair = (long)blockIdx.x * 256 + threadIdx.x;
-    if (pair >= pairs_per_frame) return;
-    const long f = blockIdx.y;
-    const f32x4 *src = rd + f * VIN * pairs_per_frame + pair;
-    C xa[VIN], xb[VIN];
-#pragma unroll
-    for (int v = 0; v < VIN; ++v) {
-        if (ZE && (v == 0 || v == VIN - 1)) {
-            xa[v] = C{0.f, 0.f};
-            xb[v] = C{0.f, 0.f};
-            continue;
+// ------------------------------------------------------------------ device-side hand-off of the chain
+// One range-Doppler launch and one angle launch per chain call run side by side on their CU-masked queues and
+// synchronise through counters in device memory instead of one pair of launches + four event packets per chunk of
+// frames (which left the angle queue idle ~15 us per launch).  The RD cube of a frame lives in slot g % ring of a ring
+// of frames (g = frames since the layout was set up, monotone across calls); per slot two monotone counters:
+//   rd_cnt[s]  += 1 by every RD workgroup after its plane is stored       (angle waits for (use + 1) * v_live)
+//   ang_cnt[s] += 1 by every angle workgroup after its tile is loaded     (RD waits for use * tiles before overwriting)
+// Work is handed out by tickets (atomic counters), so whatever order workgroups become resident in, the lowest
+// unfinished item of either kind is always held by a running workgroup: no deadlock by construction.
+// Visibility (MI355X_MICROARCH.md, inter-workgroup hand-off table, counter row): every store of the RD cube is an
+// `sc1` (write-through) store, every storing wave drains `vmcnt(0)`, workgroup barrier, ONE lane adds to the counter
+// (agent-scope atomic); the consumer polls with an `sc1` load by one lane, workgroup barrier, then EVERY load of the
+// cube is an `sc1` load (L1 bypass).  Spins are bounded: a timeout sets ctl[CTL_ABORT] and everybody leaves.
+constexpr int CTL_RD_TICKET = 0, CTL_ANG_TICKET = 1, CTL_ABORT = 2, CTL_CNT = 32, CTL_RING_MAX = 256;
+constexpr int CTL_WORDS = CTL_CNT + 2 * CTL_RING_MAX;
+struct ChainSync {
+    unsigned *ctl;              // CTL_WORDS words: tickets, abort flag, rd_cnt[CTL_RING_MAX], ang_cnt[CTL_RING_MAX]
+    unsigned rd_base, ang_base; // ticket counter values at the start of this call
+    unsigned s0, u0;            // ring slot and use index of the call's frame 0
+    int ring;                   // frames in the ring
+    int V, vskip, v_live;       // planes per frame; vskip = V when the end planes are skipped, else 0; planes transformed
+    int tiles;                  // angle work items per frame
+    int n_frames;
+    unsigned long long timeout; // s_memrealtime ticks (100 MHz) a spin may last
+    int naps_rd, naps_ang;      // s_sleep(32) calls between two polls of a counter (RD runs a ring ahead: long naps are free)
+    int exp_flags;              // timing experiments only: 1 = RD stores not sc1, 2 = angle loads not sc1 (results may be stale)
+};
+#define MMW_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// one lane: wait until (int)(*cnt - target) >= 0; false on timeout / abort (and the abort flag is raised).
+// Polls are sc1 loads that go to the memory side every time, so they are spaced out (s_sleep) -- hundreds of
+// workgroups hammering one counter's memory channel slow the whole chip down.
+__device__ __forceinline__ bool chain_wait(unsigned *cnt, unsigned target, unsigned first, unsigned *ctl, unsigned long long timeout,
+                                           int naps) {
+    unsigned c = first;
+    if ((int)(c - target) >= 0) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spin = 1;; ++spin) {
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(32);      // 32 x 64 cycles ~ 0.9 us each
+        c = __hip_atomic_load(cnt, MMW_RLX_AGENT);
+        if ((int)(c - target) >= 0) return true;
+        if ((spin & 15) == 0) {
+            if (__hip_atomic_load(ctl + CTL_ABORT, MMW_RLX_AGENT)) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
+                __hip_atomic_store(ctl + CTL_ABORT, 1u, MMW_RLX_AGENT);
+                return false;
+            }
         }
-        const f32x4 t = src[(long)v * pairs_per_frame];
-        const float h = win.h[v];
-        xa[v] = C{t.x * h, t.y * h};
-        xb[v] = C{t.z * h, t.w * h};
     }
+}
+// The eight pruned k1 passes + stores of one thread's two bins (shared by k_angle64 and k_angle64_sync).
+template <int VIN, bool MAG, bool NT>
+__device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<float> (&xb)[VIN], void *__restrict__ out, long f,
+                                               long pairs_per_frame, long pair, int shift_off) {
+    typedef cplx<float> C;
     static_for<8>([&](auto K1) {
         constexpr int k1 = decltype(K1)::value;
         C za[8], zb[8];
@@ -87,6 +115,168 @@ __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, v
     });
 }
 
+template <int VIN, bool MAG, bool NT, bool ZE>
+__global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, void *__restrict__ out,
+                                                  long pairs_per_frame, AngleWin win, int shift_off) {
+    typedef cplx<float> C;
+    // grid.x covers pairs of adjacent bins of one frame; grid.y = frame
+    const long pair = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pair >= pairs_per_frame) return;
+    const long f = blockIdx.y;
+    const f32x4 *src = rd + f * VIN * pairs_per_frame + pair;
+    C xa[VIN], xb[VIN];
+#pragma unroll
+    for (int v = 0; v < VIN; ++v) {
+        if (ZE && (v == 0 || v == VIN - 1)) {
+            xa[v] = C{0.f, 0.f};
+            xb[v] = C{0.f, 0.f};
+            continue;
+        }
+        const f32x4 t = src[(long)v * pairs_per_frame];
+        const float h = win.h[v];
+        xa[v] = C{t.x * h, t.y * h};
+        xb[v] = C{t.z * h, t.w * h};
+    }
+    angle64_passes<VIN, MAG, NT>(xa, xb, out, f, pairs_per_frame, pair, shift_off);
+}
+
+// k_angle64_sync: the chain's device-synchronised angle stage (ChainSync above).  Persistent workgroups take
+// (frame, tile of 512 bins) items from a ticket counter, wait until the frame's RD planes are published, read them
+// from the ring with sc1 loads, release the slot and run the same passes + streaming stores as k_angle64.
+template <int VIN, bool MAG, bool ZE>
+__global__ __launch_bounds__(256, 3) void k_angle64_sync(const void *__restrict__ ring, void *__restrict__ out, long pairs_per_frame,
+                                                       AngleWin win, int shift_off, ChainSync cs) {
+    typedef cplx<float> C;
+    __shared__ int sh[4];       // [0] ticket, [1] abort
+    const int tid = threadIdx.x;
+    // wave-uniform descriptor of the ring (sc1 buffer loads: aux = 16)
+    const unsigned ring_bytes = (unsigned)((long)cs.ring * VIN * pairs_per_frame * 16);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ring), 0, (int)ring_bytes, 0x00020000);
+    const int n_items = cs.n_frames * cs.tiles;
+    int prev_slot = -1;
+    if (tid == 0) sh[1] = 0;
+    for (;;) {
+        if (tid == 0) sh[0] = (int)(__hip_atomic_fetch_add(cs.ctl + CTL_ANG_TICKET, 1u, MMW_RLX_AGENT) - cs.ang_base);
+        __syncthreads();    // every wave is past the previous item's loads (their values were consumed)
+        const int item = __builtin_amdgcn_readfirstlane(sh[0]);
+        if (tid == 0 && prev_slot >= 0) __hip_atomic_fetch_add(cs.ctl + CTL_CNT + CTL_RING_MAX + prev_slot, 1u, MMW_RLX_AGENT);
+        if (item >= n_items) return;
+        const int f = item / cs.tiles, tile = item - f * cs.tiles;
+        const unsigned g = cs.s0 + (unsigned)f;
+        const int slot = (int)(g % (unsigned)cs.ring);
+        if (tid == 0) {
+            const unsigned target = (cs.u0 + g / (unsigned)cs.ring + 1u) * (unsigned)cs.v_live;
+            unsigned *cnt = cs.ctl + CTL_CNT + slot;
+            if (!chain_wait(cnt, target, __hip_atomic_load(cnt, MMW_RLX_AGENT), cs.ctl, cs.timeout, cs.naps_ang)) sh[1] = 1;
+        }
+        __syncthreads();    // between the poll and EVERY load of the published bytes
+        if (__builtin_amdgcn_readfirstlane(sh[1])) return;
+        prev_slot = slot;
+        const long pair = (long)tile * 256 + tid;
+        if (pair < pairs_per_frame) {
+            C xa[VIN], xb[VIN];
+#pragma unroll
+            for (int v = 0; v < VIN; ++v) {
+                if (ZE && (v == 0 || v == VIN - 1)) {
+                    xa[v] = C{0.f, 0.f};
+                    xb[v] = C{0.f, 0.f};
+                    continue;
+                }
+                const unsigned off = (unsigned)((((long)slot * VIN + v) * pairs_per_frame + pair) * 16);
+                const f32x4 t = (cs.exp_flags & 2) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0))
+                                                   : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+                const float h = win.h[v];
+                xa[v] = C{t.x * h, t.y * h};
+                xb[v] = C{t.z * h, t.w * h};
+            }
+            angle64_passes<VIN, MAG, true>(xa, xb, out, f, pairs_per_frame, pair, shift_off);
+        }
+    }
+}
+
+// Lean variant: the eight k1 passes are a real loop (run-time k1, twiddles W8^k1 and W64^(n2 k1) from a small constant
+// table through the scalar cache) instead of eight unrolled specialisations.  ~8x less code and <= 96 VGPRs, so that a
+// 256-thread workgroup of it fits on a CU BESIDE a 1024-thread range-Doppler workgroup (104 VGPRs): the co-resident
+// schedule of the chain.  Same arithmetic up to the rounding of the general twiddle products (still ~1e-7 relative).
+struct AngleTwTab {
+    float c[64], s[64];     // [k1 * 8 + slot]: slot 0 = W8^k1, slot n2 = W64^(n2 k1); W = c - j s
+};
+constexpr AngleTwTab make_angle_tw() {
+    AngleTwTab t{};
+    for (int k1 = 0; k1 < 8; ++k1)
+        for (int n2 = 0; n2 < 8; ++n2) {
+            const int k = n2 == 0 ? (8 * k1) % 64 : (n2 * k1) % 64;
+            t.c[k1 * 8 + n2] = (float)twc::C64[k];
+            t.s[k1 * 8 + n2] = (float)twc::S64[k];
+        }
+    return t;
+}
+__constant__ const AngleTwTab ANGLE_TW = make_angle_tw();
+
+template <typename CT> __device__ __forceinline__ CT cmul_cs(CT a, float c, float s) {    // a * (c - j s)
+    return CT{a.x * c + a.y * s, a.y * c - a.x * s};
+}
+
+template <int VIN, bool MAG, bool NT, bool ZE>
+__global__ __launch_bounds__(256, 5) void k_angle64_lean(const f32x4 *__restrict__ rd, void *__restrict__ out,
+                                                       long pairs_per_frame, AngleWin win, int shift_off) {
+    typedef cplx<float> C;
+    const long pair = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pair >= pairs_per_frame) return;
+    const long f = blockIdx.y;
+    const f32x4 *src = rd + f * VIN * pairs_per_frame + pair;
+    constexpr int LO = ZE ? 1 : 0, HI = ZE ? VIN - 1 : VIN;       // live antennas [LO, HI)
+    C xa[VIN], xb[VIN];
+#pragma unroll
+    for (int v = LO; v < HI; ++v) {
+        const f32x4 t = src[(long)v * pairs_per_frame];
+        const float h = win.h[v];
+        xa[v] = C{t.x * h, t.y * h};
+        xb[v] = C{t.z * h, t.w * h};
+    }
+#pragma unroll 1
+    for (int k1 = 0; k1 < 8; ++k1) {
+        const float *tc = ANGLE_TW.c + k1 * 8, *ts = ANGLE_TW.s + k1 * 8;     // wave-uniform: scalar loads
+        C za[8], zb[8];
+        static_for<8>([&](auto N2) {
+            constexpr int n2 = decltype(N2)::value;
+            C ya = C{0.f, 0.f}, yb = C{0.f, 0.f};
+            if constexpr (n2 >= LO && n2 < HI) {
+                ya = xa[n2];
+                yb = xb[n2];
+            }
+            if constexpr (n2 + 8 >= LO && n2 + 8 < HI) {
+                ya = ya + cmul_cs(xa[n2 + 8], tc[0], ts[0]);
+                yb = yb + cmul_cs(xb[n2 + 8], tc[0], ts[0]);
+            }
+            if constexpr (n2 == 0) {
+                za[0] = ya;
+                zb[0] = yb;
+            } else {
+                za[n2] = cmul_cs(ya, tc[n2], ts[n2]);
+                zb[n2] = cmul_cs(yb, tc[n2], ts[n2]);
+            }
+        });
+        RegFFT<8, float, 8, 0, C>::run(za);
+        RegFFT<8, float, 8, 0, C>::run(zb);
+        static_for<8>([&](auto K2) {
+            constexpr int k2 = decltype(K2)::value;
+            const int a = (k1 + 8 * k2 + shift_off) & 63;
+            const C va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
+            const long o = (f * 64 + a) * pairs_per_frame + pair;
+            if constexpr (MAG) {
+                const f32x2 m = {hypotf(va.x, va.y), hypotf(vb.x, vb.y)};
+                if constexpr (NT) __builtin_nontemporal_store(m, reinterpret_cast<f32x2 *>(out) + o);
+                else reinterpret_cast<f32x2 *>(out)[o] = m;
+            } else {
+                const f32x4 q = {va.x, va.y, vb.x, vb.y};
+                if constexpr (NT) __builtin_nontemporal_store(q, reinterpret_cast<f32x4 *>(out) + o);
+                else reinterpret_cast<f32x4 *>(out)[o] = q;
+            }
+        });
+    }
+}
+
 template <int VIN>
 int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bool mag, const float *h, bool shift) {
     AngleWin w;
@@ -98,6 +288,20 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
 #define MMW_ANGLE_LAUNCH(MAGV, NTV, ZEV) \
     hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV, ZEV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, \
                        shift ? 32 : 0)
+    if (tune_int("MMW_ANGLE_LEAN", 0) && nt) {       // co-residency experiments / the co-resident chain
+#define MMW_ANGLE_LAUNCH_LEAN(MAGV, ZEV) \
+    hipLaunchKernelGGL((k_angle64_lean<VIN, MAGV, true, ZEV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, \
+                       w, shift ? 32 : 0)
+        if (ze) {
+            if (mag) MMW_ANGLE_LAUNCH_LEAN(true, true);
+            else MMW_ANGLE_LAUNCH_LEAN(false, true);
+        } else {
+            if (mag) MMW_ANGLE_LAUNCH_LEAN(true, false);
+            else MMW_ANGLE_LAUNCH_LEAN(false, false);
+        }
+#undef MMW_ANGLE_LAUNCH_LEAN
+        return check_launch("angle64_lean");
+    }
     if (ze) {
         if (mag && nt) MMW_ANGLE_LAUNCH(true, true, true);
         else if (mag) MMW_ANGLE_LAUNCH(true, false, true);
@@ -111,6 +315,27 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     }
 #undef MMW_ANGLE_LAUNCH
     return check_launch("angle64");
+}
+
+template <int VIN>
+int launch_angle64_sync(mmw_ctx *ctx, const void *ring, void *out, long bins, bool mag, const float *h, bool shift,
+                        ChainSync cs, int grid) {
+    AngleWin w;
+    for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
+    const long pairs = bins / 2;
+    const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f;
+#define MMW_ANGLE_SYNC(MAGV, ZEV) \
+    hipLaunchKernelGGL((k_angle64_sync<VIN, MAGV, ZEV>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, \
+                       shift ? 32 : 0, cs)
+    if (ze) {
+        if (mag) MMW_ANGLE_SYNC(true, true);
+        else MMW_ANGLE_SYNC(false, true);
+    } else {
+        if (mag) MMW_ANGLE_SYNC(true, false);
+        else MMW_ANGLE_SYNC(false, false);
+    }
+#undef MMW_ANGLE_SYNC
+    return check_launch("angle64_sync");
 }
 
 // k_angle64_rmean: angle FFT + |.| + mean over a range window in one pass -- the tail of
@@ -224,7 +449,24 @@ int launch_angle64_rmean(mmw_ctx *ctx, const void *rd, float *part, size_t part_
 // p = frame * V + v sits at raw_plane(...)[(s * C + c) * ntx]; the three tx planes of one rx share cache lines.
 struct RawView {
     int ntx, nrx;       // ntx <= 1: the input already is the virtual-array cube
+    int vskip;          // V > 2: do not transform the planes of virtual antennas 0 and V - 1 of every frame (their
+                        // Hann(V) weight is exactly 0 and the chain's angle kernel never loads them); 0 = all planes
 };
+// Planes a launch really transforms, and workgroup -> plane for the non-raw kernels (raw kernels keep their XCD-grouped
+// mapping and the workgroups of a skipped plane exit at once).
+__host__ __device__ __forceinline__ long skip_planes(long planes, RawView rv) {
+    return rv.vskip > 2 ? planes / rv.vskip * (rv.vskip - 2) : planes;
+}
+__device__ __forceinline__ long skip_block_plane(long b, RawView rv) {
+    if (rv.vskip <= 2) return b;
+    const long f = b / (rv.vskip - 2);
+    return f * rv.vskip + 1 + (b - f * (rv.vskip - 2));
+}
+__device__ __forceinline__ bool skip_raw_plane(long plane, RawView rv) {
+    if (rv.vskip <= 2) return false;
+    const int v = (int)(plane % rv.vskip);
+    return v == 0 || v == rv.vskip - 1;
+}
 // Workgroup -> plane for raw cubes.  The num_tx planes of one (frame, rx) pair read the same raw rows, so they are
 // given to workgroups b, b + 8, b + 16 ...: hardware dispatch is round-robin over the 8 XCDs, which puts them on the
 // SAME XCD at about the same time and the shared lines come out of that XCD's L2 instead of being fetched once per
@@ -264,7 +506,7 @@ __device__ __forceinline__ const cplx<float> *raw_plane(const cplx<float> *in, l
 // Range FFT = processors/range_doppler_resp.py:99-101 axis -2, Doppler = axis -1, shift = :98,103.
 constexpr int RD_S = 256, RD_C = 128, RD_PITCH = 152;
 constexpr int RD_LDS_MAIN = 128 * RD_PITCH;                       // complex elements (>= 8*16*128 for X1)
-constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8;           // + W128 table
+constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8 + 16;      // + W128 table + ticket words
 
 // RAW: the input is the raw [F][num_rx][256][num_tx * 128] cube (two 8-B loads per lane and row instead of one 16-B)
 template <bool NTIN, int ABL = 0, bool RAW = false>   // ABL: timing-only ablations (1 no stores, 2 no loads, 3 neither)
@@ -286,8 +528,8 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
         int plane = blockIdx.x;
         if constexpr (RAW) {
             plane = (int)raw_block_plane(blockIdx.x, planes, rv);
-            if (plane < 0) return;
-        }
+            if (plane < 0 || skip_raw_plane(plane, rv)) return;
+        } else plane = (int)skip_block_plane(blockIdx.x, rv);
         const f32x4 *src = in + (long)plane * (RD_S * RD_C / 2);
         const cplx<float> *rsrc = nullptr;
         if constexpr (RAW) rsrc = raw_plane(reinterpret_cast<const cplx<float> *>(in), plane, RD_S, RD_C, rv);
@@ -377,32 +619,66 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
 // loads as soon as the y registers die (after the second X1 write), so the load latency hides under the rest of
 // the current plane.  PF = rows prefetched that early; the rest load at the loop top.  PF = 8 fits the register
 // budget (126 VGPRs, no scratch) and is 12 % faster than one plane per workgroup; PF = 16 spilled and was slower.
-template <bool NTIN, int PF>
+// SYNC: the chain's device-synchronised form (ChainSync above): planes come from a ticket counter, `out` is the ring of
+// RD frames, stores are sc1, and the workgroup waits for / signals the per-slot counters.
+template <bool NTIN, int PF, bool SYNC = false>
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
                                                             const cplx<float> *__restrict__ tw256,
-                                                            const cplx<float> *__restrict__ tw128) {
+                                                            const cplx<float> *__restrict__ tw128, ChainSync cs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
     cplx<float> *tw128_l = lds + RD_LDS_MAIN;
+    int *lds_ctl = reinterpret_cast<int *>(tw128_l + 128);      // SYNC: [0] / [1] tickets (double buffered), [2] abort
     if (threadIdx.x < 128) tw128_l[threadIdx.x] = tw128[threadIdx.x];
     const int t0 = threadIdx.x;
     const int l0 = t0 & 63;
     const int w0 = __builtin_amdgcn_readfirstlane(t0 >> 6);
 
     f32x4 nx[16];
-    auto issue_loads = [&](int plane, auto FIRST, auto LAST) {
-        const f32x4 *src = in + (long)plane * (RD_S * RD_C / 2);
+    // work item -> input plane (SYNC: item = frame * v_live + live antenna)
+    auto in_plane = [&](int item) {
+        if constexpr (!SYNC) return item;
+        else {
+            const int f = item / cs.v_live, vi = item - f * cs.v_live;
+            return f * cs.V + (cs.vskip > 2 ? vi + 1 : vi);
+        }
+    };
+    auto issue_loads = [&](int item, auto FIRST, auto LAST) {
+        const f32x4 *src = in + (long)in_plane(item) * (RD_S * RD_C / 2);
 #pragma unroll
         for (int n1 = decltype(FIRST)::value; n1 < decltype(LAST)::value; ++n1) {
             const int n = 16 * n1 + w0;
             nx[n1] = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l0) : src[n * (RD_C / 2) + l0];
         }
     };
-    if ((int)blockIdx.x < planes) issue_loads(blockIdx.x, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
-    for (int plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+    int first = blockIdx.x, iter = 0;
+    if constexpr (SYNC) {
+        if (t0 == 0) {
+            lds_ctl[0] = (int)(__hip_atomic_fetch_add(cs.ctl + CTL_RD_TICKET, 1u, MMW_RLX_AGENT) - cs.rd_base);
+            lds_ctl[2] = 0;
+        }
+        __syncthreads();
+        first = __builtin_amdgcn_readfirstlane(lds_ctl[0]);     // uniform: the slot arithmetic stays on the scalar unit
+    }
+    if (first < planes) issue_loads(first, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
+    for (int plane = first; plane < planes; ++iter) {
         cplx<float> *dst = out + (long)plane * (RD_S * RD_C);
+        // SYNC: slot bookkeeping and (thread 0) the early, un-waited poll of the slot's consumer counter + next ticket
+        int slot = 0;
+        unsigned free_target = 0, free_seen = 0, next_ticket = 0;
+        if constexpr (SYNC) {
+            const int f = plane / cs.v_live, vi = plane - f * cs.v_live;
+            const unsigned g = cs.s0 + (unsigned)f;
+            slot = (int)(g % (unsigned)cs.ring);
+            free_target = (cs.u0 + g / (unsigned)cs.ring) * (unsigned)cs.tiles;
+            dst = out + ((long)slot * cs.V + (cs.vskip > 2 ? vi + 1 : vi)) * (RD_S * RD_C);
+            if (t0 == 0) {
+                free_seen = __hip_atomic_load(cs.ctl + CTL_CNT + CTL_RING_MAX + slot, MMW_RLX_AGENT);
+                next_ticket = __hip_atomic_fetch_add(cs.ctl + CTL_RD_TICKET, 1u, MMW_RLX_AGENT) - cs.rd_base;
+            }
+        }
         // Re-derive the thread indices behind an opaque asm every plane: otherwise hipcc hoists every
         // lane-constant LDS / global address out of the plane loop and spills them around it.
         int t = t0;
@@ -423,6 +699,10 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
         }
         RegFFT<16, float>::run(y0);
         RegFFT<16, float>::run(y1);
+        bool dead = false;      // SYNC: hand-off timed out / aborted: no stores, leave after this plane's barriers
+        unsigned ring_soff = 0;
+        auto ring_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000);      // SYNC: set once the slot is free
+        if constexpr (SYNC) ring_soff = (unsigned)(dst - out) * 8u;
         static_for<2>([&](auto H) {
             constexpr int h = decltype(H)::value;
             // ---- X1: [k1l][j = w][c], twiddle applied on the way out
@@ -434,11 +714,28 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
                 const cplx<float> a = cmul(y0[br], tw), b = cmul(y1[br], tw);
                 *reinterpret_cast<f32x4 *>(&lds[(k1l * 16 + w) * 128 + 2 * l]) = f32x4{a.x, a.y, b.x, b.y};
             });
-            if constexpr (h == 1) {     // y0 / y1 are dead from here on: their registers take the next plane
+            if constexpr (h == 1 && !SYNC) {     // y0 / y1 are dead from here on: their registers take the next plane
                 const int next = plane + gridDim.x;
                 if (next < planes) issue_loads(next, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
             }
+            if constexpr (h == 0 && SYNC) {
+                // the slot must be free before this plane's first store (end of this half); the next ticket goes to
+                // the other waves through LDS at the same barrier
+                if (t == 0) {
+                    if (!chain_wait(cs.ctl + CTL_CNT + CTL_RING_MAX + slot, free_target, free_seen, cs.ctl, cs.timeout, cs.naps_rd)) lds_ctl[2] = 1;
+                    lds_ctl[(iter + 1) & 1] = (int)next_ticket;
+                }
+            }
             __syncthreads();
+            if constexpr (SYNC) {
+                if constexpr (h == 0) {
+                    dead = __builtin_amdgcn_readfirstlane(lds_ctl[2]) != 0;
+                    ring_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, dead ? 0 : (int)((unsigned)cs.ring * (unsigned)cs.V * (RD_S * RD_C * 8u)), 0x00020000);
+                } else {
+                    const int next = __builtin_amdgcn_readfirstlane(lds_ctl[(iter + 1) & 1]);
+                    if (next < planes) issue_loads(next, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
+                }
+            }
             const int k1l = w & 7, c = 64 * (w >> 3) + l;
             cplx<float> b[16];
 #pragma unroll
@@ -476,11 +773,28 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
                 static_for<8>([&](auto K) {
                     constexpr int k2d = decltype(K)::value;
                     const int kk = (k1d + 16 * k2d) ^ 64;       // fftshift over the 128 Doppler bins
-                    dst[kr * RD_C + kk] = e[bitrev<8>(k2d)];
+                    if constexpr (SYNC) {
+                        // sc1 (write-through, aux = 16) buffer store; 16 lanes write one whole 128-B line.  Plane base
+                        // in soffset (scalar), lane part in voffset, the Doppler bin's constant in the immediate;
+                        // after an abort the descriptor has zero records and the store is dropped.
+                        constexpr int kc = ((16 * k2d) ^ 64) * 8;
+                        if (cs.exp_flags & 1)
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e[bitrev<8>(k2d)]), ring_rs,
+                                                                  (unsigned)((kr * RD_C + k1d) * 8 + kc), ring_soff, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e[bitrev<8>(k2d)]), ring_rs,
+                                                                  (unsigned)((kr * RD_C + k1d) * 8 + kc), ring_soff, 16);
+                    } else dst[kr * RD_C + kk] = e[bitrev<8>(k2d)];
                 });
             }
+            if constexpr (SYNC && h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
             __syncthreads();
         });
+        if constexpr (SYNC) {
+            if (dead) return;
+            if (t == 0) __hip_atomic_fetch_add(cs.ctl + CTL_CNT + slot, 1u, MMW_RLX_AGENT);   // plane published
+            plane = __builtin_amdgcn_readfirstlane(lds_ctl[(iter + 1) & 1]);
+        } else plane += gridDim.x;
     }
 }
 
@@ -519,8 +833,8 @@ __global__ __launch_bounds__((RdLds<S, C>::NT)) void k_rd_lds(const f32x4 *__res
     long plane = blockIdx.x;
     if (raw) {
         plane = raw_block_plane(blockIdx.x, planes, rv);
-        if (plane < 0) return;
-    }
+        if (plane < 0 || skip_raw_plane(plane, rv)) return;
+    } else plane = skip_block_plane(blockIdx.x, rv);
     const f32x4 *src = in + plane * (K::CELLS / 2);
     const cplx<float> *rsrc = raw ? raw_plane(reinterpret_cast<const cplx<float> *>(in), plane, S, C, rv) : nullptr;
     cplx<float> *dst = out + plane * K::CELLS;
@@ -634,7 +948,7 @@ template <int S, int C> int launch_rd_lds_sc(mmw_ctx *ctx, const void *d_in, voi
         if (K::LDS_BYTES > 64 * 1024)
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         K::LDS_BYTES));
-        const unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)planes;
+        const unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)skip_planes(planes, rv);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(K::NT), K::LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
                            (cplx<float> *)d_out, (const float *)hs, (const float *)hc, (const cplx<float> *)ts,
                            (const cplx<float> *)tc, rv, planes);
@@ -670,8 +984,23 @@ int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S
 #endif  // MMW_TU_RD
 
 inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
+// the chain's device-synchronised RD stage: `grid` persistent workgroups, n_items = frames * live planes
+int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid);
 
 #ifdef MMW_TU_RD
+int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid) {
+    const void *hs, *hc, *t256, *t128;
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_S, &hs));
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_C, &hc));
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 256, &t256));
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 128, &t128));
+    auto kern = k_rd_fused_256x128_persist<true, 8, true>;
+    MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in, (cplx<float> *)d_ring,
+                       n_items, (const float *)hs, (const float *)hc, (const cplx<float> *)t256, (const cplx<float> *)t128, cs);
+    return check_launch("rd_fused_sync");
+}
+
 int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv) {
     if (!rd_fused_supported(S, C)) return set_error(MMW_ERR_UNSUPPORTED, "fused RD kernel is 256x128 only");
     const void *hs, *hc, *t256, *t128;
@@ -694,18 +1023,18 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
                            (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
         return check_launch("rd_fused_raw");
     }
-    const int blocks = planes;   // one plane per workgroup: a persistent plane loop made hipcc hoist and spill
+    const int blocks = (int)skip_planes(planes, rv);   // one plane per workgroup
     // Standalone launches use the persistent variant with 8 rows prefetched (+12 %); inside the overlapped
     // chain the one-plane-per-workgroup kernel is faster (measured), so the chain sets active_cus and gets it.
     const int pf = tune_int("MMW_RD_PERSIST", -1) >= 0 ? tune_int("MMW_RD_PERSIST", -1) : (ctx->active_cus > 0 ? 0 : 8);
-    if (pf == 8) {
+    if (pf == 8 && rv.vskip <= 2) {
         int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu) * tune_int("MMW_RD_PERSIST_WGS_PER_CU", 1);
         if (grid > planes) grid = planes;
         auto launch = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
                                (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                               (const cplx<float> *)t256, (const cplx<float> *)t128);
+                               (const cplx<float> *)t256, (const cplx<float> *)t128, ChainSync{});
         };
         launch(k_rd_fused_256x128_persist<true, 8>);
         return check_launch("rd_fused_persist");

@@ -276,8 +276,8 @@ __global__ __launch_bounds__(NT) void k_rd_mixed(RdMixedArgs a) {
     long plane = blockIdx.x;
     if (a.raw.ntx > 1) {
         plane = raw_block_plane(blockIdx.x, a.planes, a.raw);
-        if (plane < 0) return;
-    }
+        if (plane < 0 || skip_raw_plane(plane, a.raw)) return;
+    } else plane = skip_block_plane(blockIdx.x, a.raw);
     const cplx<float> *in = a.raw.ntx > 1
         ? raw_plane(reinterpret_cast<const cplx<float> *>(a.in), plane, S, C, a.raw)
         : reinterpret_cast<const cplx<float> *>(a.in) + plane * a.in_plane_stride;
@@ -550,7 +550,7 @@ int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
         if (pl.lds_bytes > 64 * 1024)
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pl.lds_bytes));
-        const unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)planes;
+        const unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)skip_planes(planes, rv);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), pl.lds_bytes, ctx->stream, a);
         return check_launch("rd_mixed");
     };

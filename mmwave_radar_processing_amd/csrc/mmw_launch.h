@@ -19,6 +19,7 @@ MMW_FFT_AXIS_INSTANCES(X)
 #ifndef MMW_TU_ANGLE
 #define X(V)                                                                                                        \
     extern template int launch_angle64<V>(mmw_ctx *, const void *, void *, int, long, bool, const float *, bool);  \
+    extern template int launch_angle64_sync<V>(mmw_ctx *, const void *, void *, long, bool, const float *, bool, ChainSync, int); \
     extern template int launch_angle64_rmean<V>(mmw_ctx *, const void *, float *, size_t, float *, int, int, int, int, int, \
                                                 const float *, bool);
 MMW_ANGLE_V_INSTANCES(X)

@@ -157,6 +157,7 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
     for (auto &kv : ctx->tables) (void)hipFree(kv.second);
     for (void *p : ctx->owned) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     drain_profile(ctx);
@@ -164,13 +165,17 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
     if (ctx->q_rd) {
         (void)hipStreamSynchronize(ctx->q_rd);
         (void)hipStreamSynchronize(ctx->q_ang);
-        for (int i = 0; i < 2; ++i) {
-            (void)hipEventDestroy(ctx->pipe_rd[i]);
-            (void)hipEventDestroy(ctx->pipe_ang[i]);
-        }
-        (void)hipEventDestroy(ctx->pipe_begin);
+        (void)hipStreamSynchronize(ctx->q_ang2);
         (void)hipStreamDestroy(ctx->q_rd);
         (void)hipStreamDestroy(ctx->q_ang);
+        (void)hipStreamDestroy(ctx->q_ang2);
+    }
+    if (ctx->pipe_begin) {
+        for (int i = 0; i < PIPE_RING_MAX; ++i) {
+            if (ctx->pipe_rd[i]) (void)hipEventDestroy(ctx->pipe_rd[i]);
+            if (ctx->pipe_ang[i]) (void)hipEventDestroy(ctx->pipe_ang[i]);
+        }
+        (void)hipEventDestroy(ctx->pipe_begin);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -181,6 +186,16 @@ int mmw_sync(mmw_ctx *ctx) {
     MMW_REQUIRE(ctx, "ctx is null");
     MMW_JOIN(ctx);
     MMW_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->chain_dirty) {
+        // did a bounded spin of the device-synchronised chain give up?  (never expected; results would be incomplete)
+        unsigned aborted = 0;
+        MMW_HIP(hipMemcpy(&aborted, ctx->chain_ctl + CTL_ABORT, sizeof(unsigned), hipMemcpyDeviceToHost));
+        ctx->chain_dirty = false;
+        if (aborted) {
+            ctx->chain_layout[0] = 0;       // counters are inconsistent: the next call starts a fresh layout
+            return set_error(MMW_ERR_HIP, "chain hand-off timed out on the device (output incomplete)");
+        }
+    }
     return MMW_OK;
 }
 
@@ -383,6 +398,8 @@ int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, in
     return range_doppler_mag64_impl(ctx, d_cubes, d_mag, n_frames, V, S, C, rx_idx);
 }
 
+static bool angle_fast_path(int V, long bins, int A);
+
 static int angle_fft_impl(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
                          int flags) {
     MMW_REQUIRE(ctx && d_rd && d_out, "null argument");
@@ -393,8 +410,7 @@ static int angle_fft_impl(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_fra
                shift = !(flags & MMW_ANGLE_NO_SHIFT);
     ProfScope ps(ctx, "angle");
     const long bins = (long)S * C;
-    if (A == 64 && bins % 2 == 0 && n_frames <= 65535 && !env_int("MMW_NO_FUSED_ANGLE", 0) &&
-        (V == 4 || V == 8 || V == 12 || V == 16)) {
+    if (n_frames <= 65535 && angle_fast_path(V, bins, A)) {
         float h[16];
         for (int i = 0; i < V; ++i) h[i] = window ? (float)np_window(TAB_HANN, i, V) : 1.f;
         switch (V) {
@@ -577,27 +593,208 @@ int mmw_doppler_azimuth_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, in
 
 // Lazily create the two CU-masked queues of the overlapped chain: the RD queue owns the first rd_cus
 // CU-mask bits, the angle queue the rest, so workgroups of the two kernels are co-resident on the chip.
+// rd_cus == 0: no masks (both queues may use every CU).  A failure leaves the context without chain queues
+// (pipe_unavailable) and the chain falls back to its serial schedule.
 static int ensure_pipe_queues(mmw_ctx *ctx, int rd_cus) {
+    if (ctx->pipe_unavailable) return set_error(MMW_ERR_UNSUPPORTED, "chain queues unavailable on this runtime");
     if (ctx->q_rd && ctx->q_rd_cus == rd_cus) return MMW_OK;
     if (ctx->q_rd) {
         MMW_HIP(hipStreamSynchronize(ctx->q_rd));
         MMW_HIP(hipStreamSynchronize(ctx->q_ang));
+        MMW_HIP(hipStreamSynchronize(ctx->q_ang2));
         MMW_HIP(hipStreamDestroy(ctx->q_rd));
         MMW_HIP(hipStreamDestroy(ctx->q_ang));
-        ctx->q_rd = ctx->q_ang = nullptr;
-    } else {
-        for (int i = 0; i < 2; ++i) {
+        MMW_HIP(hipStreamDestroy(ctx->q_ang2));
+        ctx->q_rd = ctx->q_ang = ctx->q_ang2 = nullptr;
+    }
+    if (!ctx->pipe_begin) {                         // events are created once per context
+        for (int i = 0; i < PIPE_RING_MAX; ++i) {
             MMW_HIP(hipEventCreateWithFlags(&ctx->pipe_rd[i], hipEventDisableTiming));
             MMW_HIP(hipEventCreateWithFlags(&ctx->pipe_ang[i], hipEventDisableTiming));
         }
         MMW_HIP(hipEventCreateWithFlags(&ctx->pipe_begin, hipEventDisableTiming));
     }
-    const int words = (ctx->num_cu + 31) / 32;
-    std::vector<uint32_t> m_rd(words, 0u), m_ang(words, 0u);
-    for (int i = 0; i < ctx->num_cu; ++i) ((i < rd_cus) ? m_rd : m_ang)[i / 32] |= 1u << (i % 32);
-    MMW_HIP(hipExtStreamCreateWithCUMask(&ctx->q_rd, (uint32_t)words, m_rd.data()));
-    MMW_HIP(hipExtStreamCreateWithCUMask(&ctx->q_ang, (uint32_t)words, m_ang.data()));
+    // Two angle queues on the same CUs take alternate chunks: the barrier / marker packets around one launch are
+    // processed while the other queue's kernel runs (one queue alone idles ~15 us per launch).
+    hipError_t e1, e2 = hipSuccess, e3 = hipSuccess;
+    if (rd_cus > 0) {
+        const int words = (ctx->num_cu + 31) / 32;
+        std::vector<uint32_t> m_rd(words, 0u), m_ang(words, 0u);
+        for (int i = 0; i < ctx->num_cu; ++i) ((i < rd_cus) ? m_rd : m_ang)[i / 32] |= 1u << (i % 32);
+        e1 = hipExtStreamCreateWithCUMask(&ctx->q_rd, (uint32_t)words, m_rd.data());
+        if (e1 == hipSuccess) e2 = hipExtStreamCreateWithCUMask(&ctx->q_ang, (uint32_t)words, m_ang.data());
+        if (e1 == hipSuccess && e2 == hipSuccess) e3 = hipExtStreamCreateWithCUMask(&ctx->q_ang2, (uint32_t)words, m_ang.data());
+    } else {
+        e1 = hipStreamCreateWithFlags(&ctx->q_rd, hipStreamNonBlocking);
+        if (e1 == hipSuccess) e2 = hipStreamCreateWithFlags(&ctx->q_ang, hipStreamNonBlocking);
+        if (e1 == hipSuccess && e2 == hipSuccess) e3 = hipStreamCreateWithFlags(&ctx->q_ang2, hipStreamNonBlocking);
+    }
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        if (ctx->q_rd) (void)hipStreamDestroy(ctx->q_rd);
+        if (ctx->q_ang) (void)hipStreamDestroy(ctx->q_ang);
+        ctx->q_rd = ctx->q_ang = ctx->q_ang2 = nullptr;
+        ctx->pipe_unavailable = true;
+        (void)hipGetLastError();
+        return set_error(MMW_ERR_UNSUPPORTED, "chain queue creation failed: %s",
+                         hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
+    }
     ctx->q_rd_cus = rd_cus;
+    for (int i = 0; i < PIPE_RING_MAX; ++i) ctx->pipe_ang_used[i] = false;   // the old queues were drained above
+    return MMW_OK;
+}
+
+// Does the angle stage of this call run k_angle64's ZE variant (planes 0 and V-1 never loaded)?
+static bool angle_fast_path(int V, long bins, int A) {      // per launch of at most 65535 frames
+    return A == 64 && bins % 2 == 0 && !env_int("MMW_NO_FUSED_ANGLE", 0) && (V == 4 || V == 8 || V == 12 || V == 16);
+}
+static bool angle_skips_end_planes(int V, long bins, int A, int flags) {
+    return angle_fast_path(V, bins, A) && V > 2 && !(flags & MMW_ANGLE_NO_WINDOW) &&
+           np_window(TAB_HANN, 0, V) == 0.0 && np_window(TAB_HANN, V - 1, V) == 0.0 && tune_int("MMW_ANGLE_ZE", 1) != 0;
+}
+
+// Schedule of one chain call (DESIGN.md "chain schedule"), also reported by mmw_diag_chain_plan.
+//  serial    : RD then angle over chunks of frames on the context stream.
+//  overlapped: RD(k+1) on a queue masked to rd_cus CUs runs beside angle(k) on the remaining CUs.  RD is
+//              LDS/ALU/latency bound, angle is HBM-write bound (a CU sustains ~44 GB/s of stores, so it needs
+//              about half the chip), and the ring of RD chunks stays resident in the 256 MB Infinity
+//              Cache, so the RD->angle intermediate never goes to HBM.  Default for batches of the fused
+//              shape; MMW_CHAIN_PIPELINE=0/1 forces a schedule.
+struct ChainPlan {
+    bool pipelined;
+    int chunk, ring, rd_cus, vskip;
+    bool sync;              // device-synchronised form: one RD launch + one angle launch per call (ChainSync)
+    int ring_frames;        // sync: frames in the ring of RD cubes
+};
+static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_frames, int V, int S, int C, int A, int flags) {
+    ChainPlan p{};
+    // Planes nobody reads are not transformed: with the Hann(V) antenna window the end antennas have weight exactly 0
+    // (np.hanning end points) and k_angle64's ZE variant never loads them, so when the RD cube is only an internal
+    // intermediate (d_rd == NULL) their range-Doppler transform is skipped: 1/6 of the RD work at V = 12.
+    // (Non-finite samples in an end antenna: the reference's 0 * inf gives NaN everywhere, this path stays finite.)
+    p.vskip = (!keep_rd && angle_skips_end_planes(V, (long)S * C, A, flags) && tune_int("MMW_CHAIN_SKIP_ENDS", 1)) ? V : 0;
+    const int v_live = p.vskip > 2 ? V - 2 : V;
+    p.rd_cus = env_int("MMW_RD_CUS", ctx->num_cu * 5 / 8);
+    if (p.rd_cus < 0 || p.rd_cus >= ctx->num_cu) p.rd_cus = ctx->num_cu / 2;     // 0: unmasked queues
+    p.ring = std::max(2, std::min(env_int("MMW_CHAIN_RING", 3), (int)PIPE_RING_MAX));
+    // chunk: whole RD waves (rd_cus planes each) and `ring` chunks of live RD planes within ~250 MB of cache
+    const size_t live_bytes = (size_t)v_live * S * C * sizeof(cplx<float>);
+    int chunk_auto = (int)((250u << 20) / ((size_t)p.ring * live_bytes));
+    {
+        const int wave_cus = p.rd_cus > 0 ? p.rd_cus : ctx->num_cu;
+        const int waves = (int)((long)chunk_auto * v_live / wave_cus);
+        if (waves >= 1) chunk_auto = (int)((long)waves * wave_cus / v_live);
+    }
+    if (chunk_auto < 1) chunk_auto = 1;
+    const bool fused_shape = (fused_rd_ok(S, C) || rd_lds_supported(S, C) || rd_mixed_supported(S, C)) &&
+                             angle_fast_path(V, (long)S * C, A);   // both stages have a single-pass kernel
+    const int want_pipe = env_int("MMW_CHAIN_PIPELINE", -1);
+    p.pipelined = !keep_rd && !ctx->pipe_unavailable &&
+                  (want_pipe == 1 || (want_pipe == -1 && fused_shape && n_frames >= 2 * chunk_auto));
+    p.chunk = env_int("MMW_CHAIN_CHUNK", p.pipelined ? chunk_auto : 1024);
+    p.chunk = std::max(1, std::min(p.chunk, std::min(n_frames, 65535)));          // 65535: grid.y of the angle kernel
+    // Device-synchronised form (256 x 128 planes): needs the two disjoint CU sets, because persistent angle workgroups
+    // that filled every CU would keep the range-Doppler workgroups they wait for from ever becoming resident.
+    const char *mode = std::getenv("MMW_CHAIN_MODE");
+    p.sync = p.pipelined && !raw && fused_rd_ok(S, C) && p.rd_cus > 0 && !(mode && !std::strcmp(mode, "events"));
+    // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
+    // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
+    p.ring_frames = env_int("MMW_CHAIN_RING_FRAMES", (int)((120u << 20) / live_bytes));
+    p.ring_frames = std::max(2, std::min(p.ring_frames, (int)CTL_RING_MAX));
+    while ((size_t)p.ring_frames * V * S * C * sizeof(cplx<float>) >= ((size_t)1 << 31)) --p.ring_frames;   // 32-bit buffer offsets
+    if (p.sync) p.chunk = n_frames;
+    return p;
+}
+
+// One RD launch + one angle launch for the whole call, synchronised through device counters (ChainSync).
+static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes, void *d_out, int n_frames, int V, int S,
+                        int C, int flags) {
+    const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
+    const long bins = (long)S * C;
+    const int tiles = (int)((bins / 2 + 255) / 256), v_live = plan.vskip > 2 ? V - 2 : V;
+    MMW_REQUIRE((long)n_frames * std::max(tiles, v_live) < (1L << 30), "too many frames for one chain call");
+    if (ensure_pipe_queues(ctx, plan.rd_cus) != MMW_OK) return MMW_ERR_UNSUPPORTED;
+    MMW_TRY(ensure_scratch(ctx, (size_t)plan.ring_frames * cube_bytes));
+    if (!ctx->chain_ctl) {
+        MMW_HIP(hipMalloc((void **)&ctx->chain_ctl, CTL_WORDS * sizeof(unsigned)));
+        ctx->chain_layout[0] = 0;       // forces the reset below
+    }
+    const long layout[6] = {V, bins, plan.vskip, plan.ring_frames, tiles, (long)(uintptr_t)ctx->scratch};
+    if (std::memcmp(layout, ctx->chain_layout, sizeof(layout)) != 0) {
+        // new ring layout: nothing of the old one may be in flight, counters restart from zero
+        MMW_HIP(hipStreamSynchronize(ctx->q_rd));
+        MMW_HIP(hipStreamSynchronize(ctx->q_ang));
+        MMW_HIP(hipStreamSynchronize(ctx->q_ang2));
+        MMW_HIP(hipMemsetAsync(ctx->chain_ctl, 0, CTL_WORDS * sizeof(unsigned), ctx->stream));
+        MMW_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(ctx->chain_layout, layout, sizeof(layout));
+        ctx->chain_g = 0;
+        ctx->chain_rd_base = ctx->chain_ang_base = 0;
+    }
+    const bool window = !(flags & MMW_ANGLE_NO_WINDOW), shift = !(flags & MMW_ANGLE_NO_SHIFT), mag = flags & MMW_ANGLE_MAGNITUDE;
+    float h[16];
+    for (int i = 0; i < V; ++i) h[i] = window ? (float)np_window(TAB_HANN, i, V) : 1.f;
+    ChainSync cs{};
+    cs.ctl = ctx->chain_ctl;
+    cs.rd_base = ctx->chain_rd_base;
+    cs.ang_base = ctx->chain_ang_base;
+    cs.s0 = (unsigned)(ctx->chain_g % (unsigned long long)plan.ring_frames);
+    cs.u0 = (unsigned)(ctx->chain_g / (unsigned long long)plan.ring_frames);
+    cs.ring = plan.ring_frames;
+    cs.V = V;
+    cs.vskip = plan.vskip;
+    cs.v_live = v_live;
+    cs.tiles = tiles;
+    cs.n_frames = n_frames;
+    cs.timeout = (unsigned long long)tune_int("MMW_CHAIN_TIMEOUT_MS", 2000) * 100000ull;      // 100 MHz ticks
+    cs.naps_rd = std::max(0, env_int("MMW_SYNC_NAPS_RD", 32));
+    cs.naps_ang = std::max(0, env_int("MMW_SYNC_NAPS_ANG", 4));
+    cs.exp_flags = env_int("MMW_SYNC_EXP", 0);
+    const int n_rd_items = n_frames * v_live, n_ang_items = n_frames * tiles;
+    const int rd_grid = std::min(plan.rd_cus, n_rd_items);
+    const int ang_grid = std::min((ctx->num_cu - plan.rd_cus) * std::max(1, tune_int("MMW_ANGLE_WGS_PER_CU", 3)), n_ang_items);
+    hipStream_t main_stream = ctx->stream;
+    MMW_HIP(hipEventRecord(ctx->pipe_begin, main_stream));
+    MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_begin, 0));
+    MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_begin, 0));
+    // an event-mode call that is still running reads the same scratch: order behind it
+    for (int i = 0; i < PIPE_RING_MAX; ++i)
+        if (ctx->pipe_ang_used[i] && (ctx->pipe_ring != -1)) MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[i], 0));
+    ctx->pipe_ring = -1;            // marks "last chain call was device-synchronised" for the event-mode layout check
+    ctx->pipe_slot_bytes = 0;
+    ctx->pipe_pending = true;
+    ctx->chain_dirty = true;
+    // the counters advance by exactly these amounts whether or not the launches below succeed in full
+    ctx->chain_g += (unsigned long long)n_frames;
+    ctx->chain_rd_base += (unsigned)(n_rd_items + rd_grid);       // every workgroup draws one ticket past the end
+    ctx->chain_ang_base += (unsigned)(n_ang_items + ang_grid);
+    int rc;
+    {
+        ctx->stream = ctx->q_rd;
+        ProfScope ps(ctx, "rd");
+        rc = launch_rd_fused_sync(ctx, d_cubes, ctx->scratch, n_rd_items, cs, rd_grid);
+    }
+    if (rc == MMW_OK) {
+        ctx->stream = ctx->q_ang;
+        ProfScope ps(ctx, "angle");
+        switch (V) {
+            case 4: rc = launch_angle64_sync<4>(ctx, ctx->scratch, d_out, bins, mag, h, shift, cs, ang_grid); break;
+            case 8: rc = launch_angle64_sync<8>(ctx, ctx->scratch, d_out, bins, mag, h, shift, cs, ang_grid); break;
+            case 12: rc = launch_angle64_sync<12>(ctx, ctx->scratch, d_out, bins, mag, h, shift, cs, ang_grid); break;
+            default: rc = launch_angle64_sync<16>(ctx, ctx->scratch, d_out, bins, mag, h, shift, cs, ang_grid); break;
+        }
+    }
+    ctx->stream = main_stream;
+    if (rc != MMW_OK) {
+        // a launch failed: the counters no longer match the host mirror; drain and force a fresh layout next time
+        (void)hipStreamSynchronize(ctx->q_rd);
+        (void)hipStreamSynchronize(ctx->q_ang);
+        ctx->chain_layout[0] = 0;
+        return rc;
+    }
+    MMW_HIP(hipEventRecord(ctx->pipe_ang[0], ctx->q_ang));
+    MMW_HIP(hipEventRecord(ctx->pipe_ang[1], ctx->q_rd));
+    ctx->pipe_ang_used[0] = ctx->pipe_ang_used[1] = true;
+    for (int i = 2; i < PIPE_RING_MAX; ++i) ctx->pipe_ang_used[i] = false;
     return MMW_OK;
 }
 
@@ -610,37 +807,26 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
     MMW_HIP(hipSetDevice(ctx->device));
     const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
     const size_t out_frame_bytes = (size_t)A * S * C * (magnitude ? sizeof(float) : sizeof(cplx<float>));
-    // Two schedules (DESIGN.md "chain schedule").
-    //  serial    : RD then angle over chunks of frames on the context stream.
-    //  overlapped: RD(k+1) on a queue masked to rd_cus CUs runs beside angle(k) on the remaining CUs.  RD is
-    //              LDS/ALU/latency bound, angle is HBM-write bound and saturates HBM from ~3/8 of the CUs, and
-    //              the double-buffered RD scratch (2 chunks ~ 250 MB) stays resident in the 256 MB Infinity
-    //              Cache, so the RD->angle intermediate never goes to HBM.  Default for batches of the fused
-    //              shape; MMW_CHAIN_PIPELINE=0/1 forces a schedule.
-    int rd_cus = env_int("MMW_RD_CUS", ctx->num_cu * 5 / 8);
-    if (rd_cus < 1 || rd_cus >= ctx->num_cu) rd_cus = ctx->num_cu / 2;
-    // chunk: whole RD waves (rd_cus planes each) and two chunks of RD output within ~250 MB of cache
-    int chunk_auto = (int)((250u << 20) / (2 * cube_bytes));
-    if (V > 0 && rd_cus % 1 == 0) {
-        const int per_wave_num = rd_cus, per_wave_den = V;     // frames per RD wave = rd_cus / V
-        int waves = (int)((long)chunk_auto * per_wave_den / per_wave_num);
-        if (waves >= 1) chunk_auto = (int)((long)waves * per_wave_num / per_wave_den);
+    const ChainPlan plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags);
+    rv.vskip = plan.vskip;
+    const bool pipelined = plan.pipelined;
+    const int ring = plan.ring, rd_cus = plan.rd_cus;
+    int chunk = plan.chunk;
+    if (plan.sync) {
+        const int rc = chain3d_sync(ctx, plan, d_cubes, d_out, n_frames, V, S, C, flags);
+        if (rc != MMW_ERR_UNSUPPORTED) return rc;          // queues unavailable: the serial schedule below
+        chunk = std::min(n_frames, 1024);
     }
-    if (chunk_auto < 1) chunk_auto = 1;
-    const bool fused_shape = (fused_rd_ok(S, C) || rd_lds_supported(S, C) || rd_mixed_supported(S, C)) && A == 64 && ((long)S * C) % 2 == 0 &&
-                             (V == 4 || V == 8 || V == 12 || V == 16);   // both stages have a single-pass kernel
-    const int want_pipe = env_int("MMW_CHAIN_PIPELINE", -1);
-    const bool pipelined = !d_rd && (want_pipe == 1 || (want_pipe == -1 && fused_shape && n_frames >= 2 * chunk_auto));
-    int chunk = env_int("MMW_CHAIN_CHUNK", pipelined ? chunk_auto : 1024);
-    if (chunk < 1) chunk = 1;
-    if (chunk > n_frames) chunk = n_frames;
-    void *rd_scratch = nullptr;
-    if (!d_rd) {
-        MMW_TRY(ensure_scratch(ctx, (size_t)(pipelined ? 2 : 1) * chunk * cube_bytes));
-        rd_scratch = ctx->scratch;
-    }
-    if (!pipelined) {
+    const bool queues_ok = pipelined && ensure_pipe_queues(ctx, rd_cus) == MMW_OK;
+    if (!queues_ok) {
+        // serial schedule (also the fallback when the chain queues cannot be created: same results)
         MMW_JOIN(ctx);
+        if (pipelined) chunk = std::min(n_frames, 1024);
+        void *rd_scratch = nullptr;
+        if (!d_rd) {
+            MMW_TRY(ensure_scratch(ctx, (size_t)chunk * cube_bytes));
+            rd_scratch = ctx->scratch;
+        }
         for (int f0 = 0; f0 < n_frames; f0 += chunk) {
             const int nf = std::min(chunk, n_frames - f0);
             const char *in = (const char *)d_cubes + (size_t)f0 * cube_bytes;
@@ -650,48 +836,65 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
         }
         return MMW_OK;
     }
-    if (ensure_pipe_queues(ctx, rd_cus) != MMW_OK) {
-        // CU-masked queues unavailable on this runtime: fall back to the serial schedule (same results)
-        MMW_JOIN(ctx);
-        const int big = std::min(n_frames, 1024);
-        MMW_TRY(ensure_scratch(ctx, (size_t)big * cube_bytes));
-        for (int f0 = 0; f0 < n_frames; f0 += big) {
-            const int nf = std::min(big, n_frames - f0);
-            MMW_TRY(range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, ctx->scratch, nullptr, nf, V, S, C, rv));
-            MMW_TRY(angle_fft_impl(ctx, ctx->scratch, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, flags));
-        }
-        return MMW_OK;
-    }
+    MMW_TRY(ensure_scratch(ctx, (size_t)ring * chunk * cube_bytes));
+    char *rd_scratch = (char *)ctx->scratch;
     hipStream_t main_stream = ctx->stream;
     // both queues start after whatever the caller enqueued on the context stream
     MMW_HIP(hipEventRecord(ctx->pipe_begin, main_stream));
     MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_begin, 0));
     MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_begin, 0));
-    int k = 0, rc = MMW_OK;
-    for (int f0 = 0; f0 < n_frames && rc == MMW_OK; f0 += chunk, ++k) {
-        const int nf = std::min(chunk, n_frames - f0), buf = k & 1;
-        char *rd = (char *)rd_scratch + (size_t)buf * chunk * cube_bytes;
-        // RD(k) may overwrite its buffer only after angle(k-2) has read it
-        // (also across calls: the events persist, so a back-to-back chain keeps the pipeline full)
-        if (ctx->pipe_ang_used[buf]) MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[buf], 0));
-        ctx->stream = ctx->q_rd;
-        ctx->active_cus = rd_cus;
-        rc = range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C, rv);
+    MMW_HIP(hipStreamWaitEvent(ctx->q_ang2, ctx->pipe_begin, 0));
+    const int n_angq = env_int("MMW_ANGLE_QUEUES", 2) >= 2 ? 2 : 1;
+    // The ring slots of this call overlay those of the previous (possibly still running) chain call only if the
+    // layout is the same; otherwise RD must not start before every earlier angle launch has read its slot.
+    const size_t slot_bytes = (size_t)chunk * cube_bytes;
+    if (ctx->pipe_slot_bytes != slot_bytes || ctx->pipe_ring != ring) {
+        for (int i = 0; i < PIPE_RING_MAX; ++i)
+            if (ctx->pipe_ang_used[i]) MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[i], 0));
+        ctx->pipe_slot_bytes = slot_bytes;
+        ctx->pipe_ring = ring;
+    }
+    ctx->pipe_pending = true;       // from here on work may be in flight on the chain queues, whatever the exit path
+    auto fail = [&](int rc) {           // leave nothing in flight that join_pipe's events do not cover
         ctx->stream = main_stream;
         ctx->active_cus = 0;
-        if (rc != MMW_OK) break;
-        MMW_HIP(hipEventRecord(ctx->pipe_rd[buf], ctx->q_rd));
-        MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_rd[buf], 0));
-        ctx->stream = ctx->q_ang;
+        (void)hipStreamSynchronize(ctx->q_rd);
+        (void)hipStreamSynchronize(ctx->q_ang);
+        (void)hipStreamSynchronize(ctx->q_ang2);
+        return rc;
+    };
+#define MMW_PIPE_HIP(call)                                                                                        \
+    do {                                                                                                          \
+        hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return fail(set_error(MMW_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+    int k = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk, ++k) {
+        const int nf = std::min(chunk, n_frames - f0), slot = k % ring;
+        char *rd = rd_scratch + (size_t)slot * slot_bytes;
+        // RD(k) may overwrite its slot only after angle(k - ring) has read it
+        // (also across calls: the events persist, so a back-to-back chain keeps the pipeline full)
+        if (ctx->pipe_ang_used[slot]) MMW_PIPE_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[slot], 0));
+        ctx->stream = ctx->q_rd;
+        ctx->active_cus = rd_cus > 0 ? rd_cus : ctx->num_cu;
+        int rc = range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C, rv);
+        ctx->stream = main_stream;
+        ctx->active_cus = 0;
+        if (rc != MMW_OK) return fail(rc);
+        MMW_PIPE_HIP(hipEventRecord(ctx->pipe_rd[slot], ctx->q_rd));
+        hipStream_t q_a = (n_angq == 2 && (k & 1)) ? ctx->q_ang2 : ctx->q_ang;
+        MMW_PIPE_HIP(hipStreamWaitEvent(q_a, ctx->pipe_rd[slot], 0));
+        ctx->stream = q_a;
         rc = angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, flags);
         ctx->stream = main_stream;
-        if (rc != MMW_OK) break;
-        MMW_HIP(hipEventRecord(ctx->pipe_ang[buf], ctx->q_ang));
-        ctx->pipe_ang_used[buf] = true;
+        if (rc != MMW_OK) return fail(rc);
+        MMW_PIPE_HIP(hipEventRecord(ctx->pipe_ang[slot], q_a));
+        ctx->pipe_ang_used[slot] = true;
     }
+#undef MMW_PIPE_HIP
     // The context stream joins lazily (join_pipe) at the next entry point that uses it.
-    ctx->pipe_pending = true;
-    return rc;
+    return MMW_OK;
 }
 
 int mmw_chain3d(mmw_ctx *ctx, const void *d_cubes, void *d_rd, void *d_out, int n_frames, int V, int S, int C,
@@ -959,6 +1162,21 @@ int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]) {
         plan[6] = pl.c2;
         plan[7] = (int)pl.lds_bytes;
     }
+    return MMW_OK;
+}
+
+int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, int flags, int plan[8]) {
+    MMW_REQUIRE(ctx && plan && n_frames > 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad argument");
+    const ChainPlan p = chain_plan(ctx, false, false, n_frames, V, S, C, A, flags);
+    for (int i = 0; i < 8; ++i) plan[i] = 0;
+    plan[0] = p.pipelined;
+    plan[1] = p.chunk;
+    plan[2] = p.ring;
+    plan[3] = p.rd_cus;
+    plan[4] = p.vskip > 2 ? V - 2 : V;      // range-Doppler planes transformed per frame
+    plan[5] = tune_int("MMW_ANGLE_LEAN", 0);
+    plan[6] = p.sync;
+    plan[7] = p.sync ? p.ring_frames : 0;
     return MMW_OK;
 }
 
