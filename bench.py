@@ -112,8 +112,7 @@ def chain_plan(ctx, n_frames: int) -> dict:
     plan = (ctypes.c_int * 8)()
     _lib.check(ctx.lib.mmw_diag_chain_plan(ctx.handle, n_frames, V, S, C, A, 0, plan))
     return {"overlapped": bool(plan[0]), "frames_per_launch_max": plan[1], "ring": plan[2], "rd_cus": plan[3],
-            "rd_planes_per_frame": plan[4], "lean_angle_kernel": bool(plan[5]), "device_sync": bool(plan[6]),
-            "ring_frames": plan[7]}
+            "rd_planes_per_frame": plan[4], "device_sync": bool(plan[6]), "ring_frames": plan[7]}
 
 
 def insitu_ceiling(ctx, d_buf, nbytes: int) -> dict:

@@ -196,11 +196,29 @@ int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_ma
 
 /* ---------------------------------------------------------------- point cloud
  * mmw_angle_argmax: for each detection (r, v) of frame f gather rd[f][ant[i]][r][v], zero-pad to A,
- *   FFT, optional fftshift, |.|, first-max argmax -> d_idx[F][cap] int32.
- *   replaces PointCloudGenerator._compute_angle_estimation (processors/point_cloud_generator.py:143-214). */
+ *   FFT, optional fftshift, |.|, first-max argmax (a NaN magnitude wins, as in np.argmax) -> d_idx[F][cap] int32.
+ *   replaces PointCloudGenerator._compute_angle_estimation (processors/point_cloud_generator.py:143-214).
+ *   float32 arithmetic on the float32 cube: where the reference's two best float64 magnitudes are within ~1e-6 of
+ *   each other the index may differ -- the exact variant below removes that.
+ * mmw_plane_l1: d_l1[F][V] float32 = sum over each plane of hann(S) hann(C) (|re| + |im|): the scale of the rounding-
+ *   error bound the exact variant uses (computed once per batch, shared by the azimuth and elevation calls).
+ * mmw_angle_argmax_exact: same result contract as the reference's complex128 computation (:186-206).  The float32
+ *   pass bounds how far its magnitudes can be from the float64 ones (from d_l1 and the gathered cells); a detection
+ *   whose best and second-best magnitudes are closer than twice that bound is re-evaluated in float64 from the raw cube
+ *   d_cubes (its range-Doppler cells as direct float64 2-D DFT sums, then the float64 angle DFT + argmax).
+ *   h_n_refined (may be NULL): number of re-evaluated detections; passing it makes the call synchronise.
+ * mmw_angle_argmax_cells64: the float64 angle DFT + first-max argmax for rows of n_ant complex128 cells the caller
+ *   gathered itself (a caller-supplied complex128 range-Doppler cube, :168-178); d_cells [n_rows][n_ant]. */
 int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, const int32_t *d_counts,
                      int32_t *d_idx, int n_frames, int V, int S, int C, int cap,
                      const int *h_ant, int n_ant, int A, int shift);
+int mmw_plane_l1(mmw_ctx *ctx, const void *d_cubes, float *d_l1, int n_frames, int V, int S, int C);
+int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1, const void *d_rd,
+                           const int32_t *d_dets, const int32_t *d_counts, int32_t *d_idx, int n_frames,
+                           int V, int S, int C, int cap, const int *h_ant, int n_ant, int A, int shift,
+                           int *h_n_refined);
+int mmw_angle_argmax_cells64(mmw_ctx *ctx, const void *d_cells, int32_t *d_idx, int n_rows, int n_ant, int A,
+                             int shift);
 
 /* ---------------------------------------------------------------- beamformers
  * mmw_bartlett: delay-and-sum steering-matrix contraction on MFMA,
@@ -232,8 +250,10 @@ int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]);
  * plan[0] = 1 overlapped (range-Doppler || angle on two queues) / 0 serial, plan[1] = frames per kernel launch,
  * plan[2] = ring depth of range-Doppler chunks in flight, plan[3] = CUs of the range-Doppler queue (0 = unmasked),
  * plan[4] = range-Doppler planes transformed per frame (V, or V - 2 when the zero-weight end antennas of the
- * Hann(V) window are skipped), plan[5] = 1 if the register-lean angle kernel is selected.  bench.py derives its
- * bytes-per-launch from this instead of restating the rule. */
+ * Hann(V) window are skipped), plan[5] = 0 (reserved), plan[6] = 1 for the device-synchronised form (ONE range-Doppler
+ * launch and ONE angle launch per call, handing frames over through counters in device memory; plan[1] is then the
+ * whole batch), plan[7] = frames in its ring of range-Doppler cubes.  bench.py derives its bytes-per-launch from
+ * this instead of restating the rule. */
 int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, int flags, int plan[8]);
 
 /* ---------------------------------------------------------------- per-kernel timing hook for bench.py

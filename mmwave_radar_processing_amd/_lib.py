@@ -67,6 +67,9 @@ _SIGNATURES = {
     "mmw_compact2d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_detect_batch": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i],
     "mmw_angle_argmax": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i],
+    "mmw_plane_l1": [_vp, _vp, _vp, _i, _i, _i, _i],
+    "mmw_angle_argmax_exact": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip],
+    "mmw_angle_argmax_cells64": [_vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_bartlett": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d],
     "mmw_capon": [_vp, _vp, C.POINTER(_d), _vp, _i, _i, _i, _i, _d],
     "mmw_abs_c64": [_vp, _vp, _vp, _sz],

@@ -79,6 +79,7 @@ class FramePipeline:
         self.ctx = ctx if ctx is not None else _lib.default_context()
         self.bufs = _lib.BufferSet(self.ctx)
         self.n_frames = 0
+        self.n_refined, self._l1_valid = 0, False
         cm = config_manager
         self.vel_bins = np.arange(-cm.vel_max_m_s, cm.vel_max_m_s - cm.vel_res_m_s + 1e-3, cm.vel_res_m_s)
         self.range_bins = np.arange(0, cm.range_max_m - cm.range_res_m / 2 + 1e-3, cm.range_res_m)
@@ -173,20 +174,29 @@ class FramePipeline:
         return self.dets
 
     def _argmax(self, ant, shift) -> np.ndarray:
+        """Exact (float64-equivalent) argmax bins of every detection: ``mmw_angle_argmax_exact``."""
         F, cap = self.n_frames, self.cap
         d_idx = self.bufs.get("angle_idx", max(F, 1) * cap * 4)
+        d_l1 = self.bufs.get("plane_l1", max(F, 1) * self.V * 4)
+        L, h = self.ctx.lib, self.ctx.handle
+        if not self._l1_valid:
+            _lib.check(L.mmw_plane_l1(h, self.d_in.ptr, d_l1.ptr, F, self.V, self.S, self.C))
+            self._l1_valid = True
         arr, n_ant = _lib.int_array(ant)
-        for f0 in range(0, F, 65535):
-            nf = min(65535, F - f0)
-            _lib.check(self.ctx.lib.mmw_angle_argmax(self.ctx.handle, self.d_rd.at(f0 * self.cube_bytes),
-                                                     self.d_dets.at(f0 * cap * 8), self.d_cnt.at(f0 * 4),
-                                                     d_idx.at(f0 * cap * 4), nf, self.V, self.S, self.C, cap, arr, n_ant,
-                                                     self.A, int(shift)))
+        n_ref = _lib.C.c_int(0)
+        for f0 in range(0, F, 32768):
+            nf = min(32768, F - f0)
+            _lib.check(L.mmw_angle_argmax_exact(h, self.d_in.at(f0 * self.cube_bytes), d_l1.at(f0 * self.V * 4),
+                                                self.d_rd.at(f0 * self.cube_bytes), self.d_dets.at(f0 * cap * 8),
+                                                self.d_cnt.at(f0 * 4), d_idx.at(f0 * cap * 4), nf, self.V, self.S, self.C,
+                                                cap, arr, n_ant, self.A, int(shift), _lib.C.byref(n_ref)))
+            self.n_refined += n_ref.value
         return d_idx.download((F, cap), np.int32)
 
     def point_clouds(self) -> List[np.ndarray]:
         """Per-frame float64 ``(N, 4)`` (x, y, z, velocity), FLU frame (point_cloud_generator.py:216-248)."""
         dets = self.detect()
+        self.n_refined, self._l1_valid = 0, False   # detections re-evaluated in float64 (near-ties of the float32 pass)
         az_idx = self._argmax(self.az, self.shift_az) if self.az else None
         el_idx = self._argmax(self.el, self.shift_el) if self.el else None
         out = []
@@ -200,4 +210,6 @@ class FramePipeline:
             rng, vel = self.range_bins[d[:, 0]], self.vel_bins[d[:, 1]]
             cos_el = np.cos(el)
             out.append(np.column_stack((rng * cos_el * np.cos(az), rng * cos_el * np.sin(az), rng * np.sin(el), vel)))
+        self.az_idx = None if az_idx is None else [az_idx[f, :len(d)].astype(np.int64) for f, d in enumerate(dets)]
+        self.el_idx = None if el_idx is None else [el_idx[f, :len(d)].astype(np.int64) for f, d in enumerate(dets)]
         return out

@@ -194,89 +194,6 @@ __global__ __launch_bounds__(256, 3) void k_angle64_sync(const void *__restrict_
     }
 }
 
-// Lean variant: the eight k1 passes are a real loop (run-time k1, twiddles W8^k1 and W64^(n2 k1) from a small constant
-// table through the scalar cache) instead of eight unrolled specialisations.  ~8x less code and <= 96 VGPRs, so that a
-// 256-thread workgroup of it fits on a CU BESIDE a 1024-thread range-Doppler workgroup (104 VGPRs): the co-resident
-// schedule of the chain.  Same arithmetic up to the rounding of the general twiddle products (still ~1e-7 relative).
-struct AngleTwTab {
-    float c[64], s[64];     // [k1 * 8 + slot]: slot 0 = W8^k1, slot n2 = W64^(n2 k1); W = c - j s
-};
-constexpr AngleTwTab make_angle_tw() {
-    AngleTwTab t{};
-    for (int k1 = 0; k1 < 8; ++k1)
-        for (int n2 = 0; n2 < 8; ++n2) {
-            const int k = n2 == 0 ? (8 * k1) % 64 : (n2 * k1) % 64;
-            t.c[k1 * 8 + n2] = (float)twc::C64[k];
-            t.s[k1 * 8 + n2] = (float)twc::S64[k];
-        }
-    return t;
-}
-__constant__ const AngleTwTab ANGLE_TW = make_angle_tw();
-
-template <typename CT> __device__ __forceinline__ CT cmul_cs(CT a, float c, float s) {    // a * (c - j s)
-    return CT{a.x * c + a.y * s, a.y * c - a.x * s};
-}
-
-template <int VIN, bool MAG, bool NT, bool ZE>
-__global__ __launch_bounds__(256, 5) void k_angle64_lean(const f32x4 *__restrict__ rd, void *__restrict__ out,
-                                                       long pairs_per_frame, AngleWin win, int shift_off) {
-    typedef cplx<float> C;
-    const long pair = (long)blockIdx.x * 256 + threadIdx.x;
-    if (pair >= pairs_per_frame) return;
-    const long f = blockIdx.y;
-    const f32x4 *src = rd + f * VIN * pairs_per_frame + pair;
-    constexpr int LO = ZE ? 1 : 0, HI = ZE ? VIN - 1 : VIN;       // live antennas [LO, HI)
-    C xa[VIN], xb[VIN];
-#pragma unroll
-    for (int v = LO; v < HI; ++v) {
-        const f32x4 t = src[(long)v * pairs_per_frame];
-        const float h = win.h[v];
-        xa[v] = C{t.x * h, t.y * h};
-        xb[v] = C{t.z * h, t.w * h};
-    }
-#pragma unroll 1
-    for (int k1 = 0; k1 < 8; ++k1) {
-        const float *tc = ANGLE_TW.c + k1 * 8, *ts = ANGLE_TW.s + k1 * 8;     // wave-uniform: scalar loads
-        C za[8], zb[8];
-        static_for<8>([&](auto N2) {
-            constexpr int n2 = decltype(N2)::value;
-            C ya = C{0.f, 0.f}, yb = C{0.f, 0.f};
-            if constexpr (n2 >= LO && n2 < HI) {
-                ya = xa[n2];
-                yb = xb[n2];
-            }
-            if constexpr (n2 + 8 >= LO && n2 + 8 < HI) {
-                ya = ya + cmul_cs(xa[n2 + 8], tc[0], ts[0]);
-                yb = yb + cmul_cs(xb[n2 + 8], tc[0], ts[0]);
-            }
-            if constexpr (n2 == 0) {
-                za[0] = ya;
-                zb[0] = yb;
-            } else {
-                za[n2] = cmul_cs(ya, tc[n2], ts[n2]);
-                zb[n2] = cmul_cs(yb, tc[n2], ts[n2]);
-            }
-        });
-        RegFFT<8, float, 8, 0, C>::run(za);
-        RegFFT<8, float, 8, 0, C>::run(zb);
-        static_for<8>([&](auto K2) {
-            constexpr int k2 = decltype(K2)::value;
-            const int a = (k1 + 8 * k2 + shift_off) & 63;
-            const C va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
-            const long o = (f * 64 + a) * pairs_per_frame + pair;
-            if constexpr (MAG) {
-                const f32x2 m = {hypotf(va.x, va.y), hypotf(vb.x, vb.y)};
-                if constexpr (NT) __builtin_nontemporal_store(m, reinterpret_cast<f32x2 *>(out) + o);
-                else reinterpret_cast<f32x2 *>(out)[o] = m;
-            } else {
-                const f32x4 q = {va.x, va.y, vb.x, vb.y};
-                if constexpr (NT) __builtin_nontemporal_store(q, reinterpret_cast<f32x4 *>(out) + o);
-                else reinterpret_cast<f32x4 *>(out)[o] = q;
-            }
-        });
-    }
-}
-
 template <int VIN>
 int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bool mag, const float *h, bool shift) {
     AngleWin w;
@@ -288,20 +205,6 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
 #define MMW_ANGLE_LAUNCH(MAGV, NTV, ZEV) \
     hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV, ZEV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, \
                        shift ? 32 : 0)
-    if (tune_int("MMW_ANGLE_LEAN", 0) && nt) {       // co-residency experiments / the co-resident chain
-#define MMW_ANGLE_LAUNCH_LEAN(MAGV, ZEV) \
-    hipLaunchKernelGGL((k_angle64_lean<VIN, MAGV, true, ZEV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, \
-                       w, shift ? 32 : 0)
-        if (ze) {
-            if (mag) MMW_ANGLE_LAUNCH_LEAN(true, true);
-            else MMW_ANGLE_LAUNCH_LEAN(false, true);
-        } else {
-            if (mag) MMW_ANGLE_LAUNCH_LEAN(true, false);
-            else MMW_ANGLE_LAUNCH_LEAN(false, false);
-        }
-#undef MMW_ANGLE_LAUNCH_LEAN
-        return check_launch("angle64_lean");
-    }
     if (ze) {
         if (mag && nt) MMW_ANGLE_LAUNCH(true, true, true);
         else if (mag) MMW_ANGLE_LAUNCH(true, false, true);

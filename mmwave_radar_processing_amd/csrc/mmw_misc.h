@@ -259,12 +259,59 @@ struct AntList {
     int idx[MAX_ANT];
 };
 
+// np.argmax order on magnitudes: a NaN beats everything that is not a NaN, the FIRST maximum wins
+template <typename T> __device__ __forceinline__ bool mag_gt(T a, T b) {
+    if (a != a) return !(b != b);
+    if (b != b) return false;
+    return a > b;
+}
+template <typename T> __device__ __forceinline__ bool mag_better(T a, int ia, T b, int ib) {   // (a, ia) ahead of (b, ib)
+    return mag_gt(a, b) || (!mag_gt(b, a) && ia < ib);
+}
+
+// l1[plane] = sum over the plane of hann(S)[s] hann(C)[c] (|re| + |im|)  >=  sum |w x|: the scale of the rounding-error
+// bound of the float32 range-Doppler cell values (see k_angle_argmax).  One workgroup per plane.
+__global__ __launch_bounds__(256) void k_plane_l1(const float2 *__restrict__ in, float *__restrict__ l1, int S, int C,
+                                                   const float *__restrict__ ws, const float *__restrict__ wc) {
+    __shared__ float part[4];
+    const float2 *src = in + (long)blockIdx.x * S * C;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) {
+        float row = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float2 v = src[(long)s * C + c];
+            row += wc[c] * (fabsf(v.x) + fabsf(v.y));
+        }
+        acc += ws[s] * row;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) l1[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// Detections whose float32 argmax is not provably the float64 one are appended here and re-evaluated in float64.
+struct ArgmaxRefine {
+    const float *l1;        // [F][V] from k_plane_l1; nullptr: no refinement (plain float32 argmax)
+    int *n_flag;            // number of flagged detections (may exceed list_cap)
+    int *list;              // f * cap + det of the flagged detections
+    int list_cap;
+    float k_fft, k_ang;     // error-bound constants (see below)
+};
+
 // One wave per detection: gather rd[f][ant[i]][r][v], lane k evaluates angle bins k, k+64, ... of the
 // zero-padded A-point DFT, first-max argmax over the (optionally fftshifted) response.
 // (processors/point_cloud_generator.py:168-214; np.argmax returns the FIRST maximum.)
+// The reference does this in complex128 on a complex128 range-Doppler cube.  Here the cube is float32, so the kernel also
+// bounds how far its magnitudes can be from the float64 ones:
+//   |rd32 - rd64| <= k_fft * l1(plane)   (each RD cell is a sum of S*C products w x W with <= log2(S) + log2(C) + 2
+//                                          roundings on the way: (log2 S + log2 C + 2) eps sum|w x| <= 17 eps l1 for
+//                                          256 x 128; k_fft = 32 eps leaves a factor ~2)
+//   |m32[k] - m64[k]| <= B = sum_i k_fft l1_i + k_ang sum_i |x_i|   (n_ant-term float32 sum + hypotf)
+// and flags the detection unless best - second > 2 B: the float64 argmax of an unflagged detection is the one found.
 __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const int32_t *dets, const int32_t *counts,
                                                        int32_t *out_idx, int V, int S, int C, int cap,
-                                                       AntList ants, int A, int shift, const float2 *twA) {
+                                                       AntList ants, int A, int shift, const float2 *twA, ArgmaxRefine rf) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int det = blockIdx.x * 4 + wave;
     const int f = blockIdx.y;
@@ -273,10 +320,17 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
     if (det >= n_det) return;
     const int r = dets[((long)f * cap + det) * 2], v = dets[((long)f * cap + det) * 2 + 1];
     float2 x[MAX_ANT];
+    float sum_abs = 0.f, sum_l1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_ANT; ++i)
+    for (int i = 0; i < MAX_ANT; ++i) {
         x[i] = (i < ants.n) ? rd[(((long)f * V + ants.idx[i]) * S + r) * C + v] : make_float2(0.f, 0.f);
-    float best = -1.f;
+        if (i < ants.n) {
+            sum_abs += fabsf(x[i].x) + fabsf(x[i].y);
+            if (rf.l1) sum_l1 += rf.l1[(long)f * V + ants.idx[i]];
+        }
+    }
+    const float NEG = -__builtin_huge_valf();
+    float best = NEG, second = NEG;
     int best_idx = 0x7fffffff;
     for (int k = lane; k < A; k += 64) {
         float re = 0.f, im = 0.f;
@@ -293,20 +347,124 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
         }
         const float m = hypotf(re, im);
         const int kk = shift ? (k + A / 2) % A : k;
-        if (m > best || (m == best && kk < best_idx)) {
+        if (best_idx == 0x7fffffff || mag_better(m, kk, best, best_idx)) {
+            if (best_idx != 0x7fffffff) second = best;
+            best = m;
+            best_idx = kk;
+        } else if (mag_gt(m, second)) second = m;
+    }
+    // wave-wide first maximum, then the largest magnitude among everything else
+    float wb = best;
+    int wi = best_idx;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(wb, d, 64);
+        const int oi = __shfl_xor(wi, d, 64);
+        if (oi != 0x7fffffff && (wi == 0x7fffffff || mag_better(ob, oi, wb, wi))) {
+            wb = ob;
+            wi = oi;
+        }
+    }
+    float ws2 = (best_idx == wi) ? second : best;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float o = __shfl_xor(ws2, d, 64);
+        if (mag_gt(o, ws2)) ws2 = o;
+    }
+    if (lane == 0) {
+        out_idx[(long)f * cap + det] = wi;
+        if (rf.l1) {
+            const float B = rf.k_fft * sum_l1 + rf.k_ang * sum_abs;
+            if (!(wb - ws2 > 2.f * B)) {       // also taken for NaN / inf magnitudes
+                const int pos = atomicAdd(rf.n_flag, 1);
+                if (pos < rf.list_cap) rf.list[pos] = f * cap + det;
+            }
+        }
+    }
+}
+
+// float64 first-max argmax of the zero-padded A-point DFT of n_ant complex128 cells per row (np.fft.fft + np.abs +
+// np.argmax of the reference, point_cloud_generator.py:187-206).  One wave per row.
+__device__ __forceinline__ int argmax64_wave(const cplx<double> *X, int n_ant, int A, int shift, const cplx<double> *twA,
+                                             int lane) {
+    double best = 0.0;
+    int best_idx = 0x7fffffff;
+    for (int k = lane; k < A; k += 64) {
+        double re = 0.0, im = 0.0;
+        int t = 0;
+        for (int i = 0; i < n_ant; ++i) {
+            const cplx<double> w = twA[t], xi = X[i];
+            re += xi.x * w.x - xi.y * w.y;
+            im += xi.x * w.y + xi.y * w.x;
+            t += k;
+            if (t >= A) t -= A;
+        }
+        const double m = hypot(re, im);
+        const int kk = shift ? (k + A / 2) % A : k;
+        if (best_idx == 0x7fffffff || mag_better(m, kk, best, best_idx)) {
             best = m;
             best_idx = kk;
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {
-        const float ob = __shfl_xor(best, d, 64);
+        const double ob = __shfl_xor(best, d, 64);
         const int oi = __shfl_xor(best_idx, d, 64);
-        if (ob > best || (ob == best && oi < best_idx)) {
+        if (oi != 0x7fffffff && (best_idx == 0x7fffffff || mag_better(ob, oi, best, best_idx))) {
             best = ob;
             best_idx = oi;
         }
     }
-    if (lane == 0) out_idx[(long)f * cap + det] = best_idx;
+    return best_idx;
+}
+
+__global__ __launch_bounds__(256) void k_argmax64_cells(const cplx<double> *cells, int32_t *out_idx, int n_rows, int n_ant,
+                                                         int A, int shift, const cplx<double> *twA) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const int idx = argmax64_wave(cells + (long)row * n_ant, n_ant, A, shift, twA, lane);
+    if (lane == 0) out_idx[row] = idx;
+}
+
+// Flagged detections: the range-Doppler cell of every listed antenna as the float64 2-D DFT coefficient of the windowed
+// cube (direct S*C-term sum, table twiddles), then the float64 argmax.  One workgroup per flagged detection.
+__global__ __launch_bounds__(256) void k_argmax_refine(const float2 *__restrict__ cubes, const int32_t *dets, const int *n_flag,
+                                                        const int *list, int list_cap, int32_t *out_idx, int V, int S, int C,
+                                                        int cap, AntList ants, int A, int shift, const double *__restrict__ ws,
+                                                        const double *__restrict__ wc, const cplx<double> *__restrict__ twS,
+                                                        const cplx<double> *__restrict__ twC, const cplx<double> *twA) {
+    __shared__ cplx<double> red[4];
+    __shared__ cplx<double> X[MAX_ANT];
+    int n = *n_flag;
+    if (n > list_cap) n = list_cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const int id = list[e], f = id / cap, det = id - f * cap;
+        const int r = dets[((long)f * cap + det) * 2], v = dets[((long)f * cap + det) * 2 + 1];
+        int kd = v - C / 2;                 // FFT bin behind the fftshifted Doppler index
+        if (kd < 0) kd += C;
+        for (int i = 0; i < ants.n; ++i) {
+            const float2 *plane = cubes + ((long)f * V + ants.idx[i]) * S * C;
+            cplx<double> acc = cplx<double>{0.0, 0.0};
+            for (int cell = tid; cell < S * C; cell += 256) {
+                const int s = cell / C, c = cell - s * C;
+                const float2 xv = plane[cell];
+                const double w = ws[s] * wc[c];
+                const cplx<double> ph = cmul(twS[(int)(((long)r * s) % S)], twC[(int)(((long)kd * c) % C)]);
+                acc = acc + cmul(cplx<double>{w * (double)xv.x, w * (double)xv.y}, ph);
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                acc.x += __shfl_xor(acc.x, d, 64);
+                acc.y += __shfl_xor(acc.y, d, 64);
+            }
+            if (lane == 0) red[wave] = acc;
+            __syncthreads();
+            if (tid == 0) X[i] = (red[0] + red[1]) + (red[2] + red[3]);
+            __syncthreads();
+        }
+        if (wave == 0) {
+            const int idx = argmax64_wave(X, ants.n, A, shift, twA, lane);
+            if (lane == 0) out_idx[(long)f * cap + det] = idx;
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace mmw

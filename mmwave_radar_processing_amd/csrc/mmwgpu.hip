@@ -1109,29 +1109,115 @@ int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_ma
 }
 
 // ------------------------------------------------------------------ point cloud
+static int fill_ant_list(const int *h_ant, int n_ant, int V, int A, AntList *ants) {
+    MMW_REQUIRE(n_ant >= 1 && n_ant <= MAX_ANT && n_ant <= A && h_ant, "antenna list must have 1..%d entries (<= A)", MAX_ANT);
+    ants->n = n_ant;
+    for (int i = 0; i < n_ant; ++i) {
+        int a = h_ant[i];
+        if (a < 0) a += V;
+        MMW_REQUIRE(a >= 0 && a < V, "antenna index %d out of range", h_ant[i]);
+        ants->idx[i] = a;
+    }
+    return MMW_OK;
+}
+
 int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, const int32_t *d_counts,
                      int32_t *d_idx, int n_frames, int V, int S, int C, int cap, const int *h_ant, int n_ant,
                      int A, int shift) {
     MMW_REQUIRE(ctx && d_rd && d_dets && d_counts && d_idx, "null argument");
     MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && n_frames <= 65535 && V > 0 && S > 0 && C > 0 && cap >= 0 && A > 0, "bad shape");
-    MMW_REQUIRE(n_ant >= 1 && n_ant <= MAX_ANT && n_ant <= A && h_ant, "antenna list must have 1..%d entries (<= A)", MAX_ANT);
     AntList ants{};
-    ants.n = n_ant;
-    for (int i = 0; i < n_ant; ++i) {
-        int a = h_ant[i];
-        if (a < 0) a += V;
-        MMW_REQUIRE(a >= 0 && a < V, "antenna index %d out of range", h_ant[i]);
-        ants.idx[i] = a;
-    }
+    MMW_TRY(fill_ant_list(h_ant, n_ant, V, A, &ants));
     if (n_frames == 0 || cap == 0) return MMW_OK;
     const void *twA = nullptr;
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, A, &twA));
     ProfScope ps(ctx, "argmax");
     dim3 grid((cap + 3) / 4, n_frames);
     hipLaunchKernelGGL(k_angle_argmax, grid, dim3(256), 0, ctx->stream, (const float2 *)d_rd, d_dets, d_counts, d_idx,
-                       V, S, C, cap, ants, A, shift, (const float2 *)twA);
+                       V, S, C, cap, ants, A, shift, (const float2 *)twA, ArgmaxRefine{});
     return check_launch("angle_argmax");
+}
+
+int mmw_plane_l1(mmw_ctx *ctx, const void *d_cubes, float *d_l1, int n_frames, int V, int S, int C) {
+    MMW_REQUIRE(ctx && d_cubes && d_l1, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && (long)n_frames * V < (1L << 31), "bad shape");
+    if (n_frames == 0) return MMW_OK;
+    const void *ws, *wc;
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &ws));
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, C, &wc));
+    ProfScope ps(ctx, "plane_l1");
+    hipLaunchKernelGGL(k_plane_l1, dim3((unsigned)(n_frames * V)), dim3(256), 0, ctx->stream, (const float2 *)d_cubes, d_l1, S,
+                       C, (const float *)ws, (const float *)wc);
+    return check_launch("plane_l1");
+}
+
+int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1, const void *d_rd, const int32_t *d_dets,
+                           const int32_t *d_counts, int32_t *d_idx, int n_frames, int V, int S, int C, int cap,
+                           const int *h_ant, int n_ant, int A, int shift, int *h_n_refined) {
+    MMW_REQUIRE(ctx && d_cubes && d_l1 && d_rd && d_dets && d_counts && d_idx, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && n_frames <= 65535 && V > 0 && S > 0 && C > 0 && cap >= 0 && A > 0, "bad shape");
+    MMW_REQUIRE((long)n_frames * cap < (1L << 31), "too many detection slots for one call");
+    AntList ants{};
+    MMW_TRY(fill_ant_list(h_ant, n_ant, V, A, &ants));
+    if (h_n_refined) *h_n_refined = 0;
+    if (n_frames == 0 || cap == 0) return MMW_OK;
+    const void *twA = nullptr, *twA64, *twS64, *twC64, *ws64, *wc64;
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, A, &twA));
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, A, &twA64));
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, S, &twS64));
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, C, &twC64));
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &ws64));
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &wc64));
+    const int list_cap = n_frames * cap;
+    MMW_TRY(ensure_scratch(ctx, 256 + (size_t)list_cap * sizeof(int)));
+    int *d_nflag = (int *)ctx->scratch, *d_list = (int *)((char *)ctx->scratch + 256);
+    MMW_HIP(hipMemsetAsync(d_nflag, 0, 256, ctx->stream));
+    // Error-bound constants of k_angle_argmax, in units of eps = 2^-24, for whichever kernel mmw_range_doppler runs on
+    // this plane.  Radix-2 register FFTs: per level one add and one twiddled difference, <= 3.5 eps of the running
+    // sum of |terms| (FMA complex product + table twiddle), 2 levels' worth for the two window factors; levels that
+    // evaluate an R-point DFT directly (mixed-radix kernel, direct-DFT fallback) add an R-term FMA chain, <= R eps.
+    const float eps = 5.9604645e-8f;
+    int ulps = 4 * 2;
+    for (int n = 1; n < S; n <<= 1) ulps += 4;
+    for (int n = 1; n < C; n <<= 1) ulps += 4;
+    if (!fused_rd_ok(S, C) && !rd_lds_supported(S, C)) {
+        RdMixedPlan mp;
+        if (rd_mixed_plan(S, C, sizeof(cplx<float>), &mp) && !env_int("MMW_NO_MIXED_RD", 0))
+            ulps += mp.s1 + mp.s2 + mp.c1 + mp.c2 + 2 * (mp.rad_s[0] + mp.rad_s[1] + mp.rad_c[0] + mp.rad_c[1]);
+        else
+            ulps += (is_pow2(S) ? 0 : S) + (is_pow2(C) ? 0 : C);
+    }
+    ArgmaxRefine rf{d_l1, d_nflag, d_list, list_cap, (float)ulps * eps, 4.f * (float)(n_ant + 4) * eps};
+    ProfScope ps(ctx, "argmax");
+    dim3 grid((cap + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_angle_argmax, grid, dim3(256), 0, ctx->stream, (const float2 *)d_rd, d_dets, d_counts, d_idx,
+                       V, S, C, cap, ants, A, shift, (const float2 *)twA, rf);
+    MMW_TRY(check_launch("angle_argmax"));
+    const int grid2 = (int)std::min<long>(list_cap, 8L * ctx->num_cu);
+    hipLaunchKernelGGL(k_argmax_refine, dim3(grid2), dim3(256), 0, ctx->stream, (const float2 *)d_cubes, d_dets, d_nflag, d_list,
+                       list_cap, d_idx, V, S, C, cap, ants, A, shift, (const double *)ws64, (const double *)wc64,
+                       (const cplx<double> *)twS64, (const cplx<double> *)twC64, (const cplx<double> *)twA64);
+    MMW_TRY(check_launch("argmax_refine"));
+    if (h_n_refined) {
+        MMW_HIP(hipMemcpyAsync(h_n_refined, d_nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MMW_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MMW_OK;
+}
+
+int mmw_angle_argmax_cells64(mmw_ctx *ctx, const void *d_cells, int32_t *d_idx, int n_rows, int n_ant, int A, int shift) {
+    MMW_REQUIRE(ctx && d_cells && d_idx, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_rows >= 0 && n_ant >= 1 && A >= n_ant, "bad shape (need 1 <= n_ant <= A)");
+    if (n_rows == 0) return MMW_OK;
+    const void *twA64;
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, A, &twA64));
+    hipLaunchKernelGGL(k_argmax64_cells, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
+                       (const cplx<double> *)d_cells, d_idx, n_rows, n_ant, A, shift, (const cplx<double> *)twA64);
+    return check_launch("argmax64_cells");
 }
 
 int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
@@ -1174,7 +1260,7 @@ int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, 
     plan[2] = p.ring;
     plan[3] = p.rd_cus;
     plan[4] = p.vskip > 2 ? V - 2 : V;      // range-Doppler planes transformed per frame
-    plan[5] = tune_int("MMW_ANGLE_LEAN", 0);
+    plan[5] = 0;
     plan[6] = p.sync;
     plan[7] = p.sync ? p.ring_frames : 0;
     return MMW_OK;

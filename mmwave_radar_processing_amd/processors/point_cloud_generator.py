@@ -2,7 +2,8 @@
 (reference: mmwave_radar_processing/processors/point_cloud_generator.py:9-256).
 
 detector (RD + CFAR on the GPU) -> per-detection zero-padded angle FFT + first-max argmax on the GPU
-(``mmw_angle_argmax``, one wavefront per detection) -> host table lookups and the spherical->Cartesian map.
+(``mmw_angle_argmax_exact``, one wavefront per detection, float64 where float32 cannot decide) -> host table lookups
+and the spherical->Cartesian map.
 """
 from __future__ import annotations
 
@@ -38,6 +39,7 @@ class PointCloudGenerator(_Processor):
         self.num_angle_bins = num_angle_bins
         self.phase_shifts = None
         self.angle_bins = None
+        self.n_refined = 0      # detections of the last frame whose argmax was re-evaluated in float64
         registry = get_range_doppler_detector_registry()
         if detector_type not in registry:
             raise ValueError(f"Unknown detector type: {detector_type}. Available: {list(registry.keys())}")
@@ -58,46 +60,58 @@ class PointCloudGenerator(_Processor):
         return self._convert_to_cartesian(det_ranges, az, el, det_velocities)
 
     # ------------------------------------------------------------------ angles
-    def _argmax_bins(self, ctx, bufs, d_rd_ptr, shape, d_dets, d_cnt, cap, n, ant, shift):
-        V, S, C = shape
-        d_idx = bufs.get("angle_idx", max(cap, 1) * 4)
-        arr, n_ant = _lib.int_array(ant)
-        _lib.check(ctx.lib.mmw_angle_argmax(ctx.handle, d_rd_ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, 1, V, S, C, cap,
-                                            arr, n_ant, int(self.num_angle_bins), int(bool(shift))))
-        return d_idx.download((n,), np.int32).astype(int)
-
     def _compute_angle_estimation(self, rng_dop_resp_raw: np.ndarray, det_range_idxs: np.ndarray,
                                   det_velocity_idxs: np.ndarray):
-        """Azimuth / elevation angle of each detection; an empty antenna list gives zeros (reference :160-178)."""
+        """Azimuth / elevation angle of each detection; an empty antenna list gives zeros (reference :160-178).
+
+        The reference does the per-detection angle FFT in complex128 on a complex128 range-Doppler cube.  Two device
+        paths give the same argmax indices:
+          * the cube is the one the detector just computed (still resident in HBM, float32): ``mmw_angle_argmax_exact``
+            -- float32 pass with an error bound, detections whose two best bins are closer than the bound are
+            re-evaluated in float64 from the raw ADC cube;
+          * any other array (a caller's own complex128 cube): the cells at the detections are gathered on the host and
+            the float64 angle DFT + argmax runs on the device (``mmw_angle_argmax_cells64``)."""
         n = len(det_range_idxs)
         az_angles = np.zeros(n)
         el_angles = np.zeros(n)
         if n == 0 or (self.az_antenna_idxs.size == 0 and self.el_antenna_idxs.size == 0):
             return az_angles, el_angles
         ctx, bufs = self._device()
+        L, h = ctx.lib, ctx.handle
         raw = np.asarray(rng_dop_resp_raw)
+        r_idx = np.asarray(det_range_idxs).astype(np.int64)
+        v_idx = np.asarray(det_velocity_idxs).astype(np.int64)
+        A = int(self.num_angle_bins)
+        d_idx = bufs.get("angle_idx", n * 4)
         dev = getattr(self.detector, "_dev", None)
-        if dev is not None and raw is self.detector.rng_dop_resp_raw:
-            d_rd, shape = dev[0], dev[2]          # RD cube of this frame is still resident in HBM
-        else:
-            rd = np.ascontiguousarray(raw, dtype=np.complex64)
-            d_rd = bufs.get("rd_host", rd.nbytes)
-            d_rd.upload(rd)
-            shape = rd.shape
-        dets = np.ascontiguousarray(np.stack([np.asarray(det_range_idxs), np.asarray(det_velocity_idxs)], axis=1),
-                                    dtype=np.int32)
-        d_dets, d_cnt = bufs.get("pc_dets", dets.nbytes), bufs.get("pc_count", 4)
-        d_dets.upload(dets)
-        d_cnt.upload(np.array([n], dtype=np.int32))
-        if self.az_antenna_idxs.size > 0:
-            idx = self._argmax_bins(ctx, bufs, d_rd.ptr, shape, d_dets, d_cnt, n, n, self.az_antenna_idxs,
-                                    self.shift_az_resp)
-            az_angles = self.angle_bins[idx]
-        if self.el_antenna_idxs.size > 0:
-            idx = self._argmax_bins(ctx, bufs, d_rd.ptr, shape, d_dets, d_cnt, n, n, self.el_antenna_idxs,
-                                    self.shift_el_resp)
-            el_angles = self.angle_bins[idx]
-        return az_angles, el_angles
+        resident = dev is not None and raw is self.detector.rng_dop_resp_raw
+        if resident:
+            d_rd, (V, S, C), d_cube = dev[0], dev[2], dev[3]
+            dets = np.ascontiguousarray(np.stack([r_idx, v_idx], axis=1), dtype=np.int32)
+            d_dets, d_cnt = bufs.get("pc_dets", dets.nbytes), bufs.get("pc_count", 4)
+            d_dets.upload(dets)
+            d_cnt.upload(np.array([n], dtype=np.int32))
+            d_l1 = bufs.get("plane_l1", V * 4)
+            _lib.check(L.mmw_plane_l1(h, d_cube.ptr, d_l1.ptr, 1, V, S, C))
+        self.n_refined = 0
+        out = []
+        for ant, shift in ((self.az_antenna_idxs, self.shift_az_resp), (self.el_antenna_idxs, self.shift_el_resp)):
+            if ant.size == 0:
+                out.append(np.zeros(n))
+                continue
+            if resident:
+                arr, n_ant = _lib.int_array(ant)
+                n_ref = _lib.C.c_int(0)
+                _lib.check(L.mmw_angle_argmax_exact(h, d_cube.ptr, d_l1.ptr, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, 1,
+                                                    V, S, C, n, arr, n_ant, A, int(bool(shift)), _lib.C.byref(n_ref)))
+                self.n_refined += n_ref.value
+            else:
+                cells = np.ascontiguousarray(raw[ant][:, r_idx, v_idx].T, dtype=np.complex128)     # (N, n_ant), :168-175
+                d_cells = bufs.get("pc_cells", cells.nbytes)
+                d_cells.upload(cells)
+                _lib.check(L.mmw_angle_argmax_cells64(h, d_cells.ptr, d_idx.ptr, n, cells.shape[1], A, int(bool(shift))))
+            out.append(self.angle_bins[d_idx.download((n,), np.int32).astype(int)])
+        return out[0], out[1]
 
     def _convert_to_cartesian(self, ranges, az_angles, el_angles, velocities) -> np.ndarray:
         """FLU frame: x forward, y left, z up (reference :216-248).  O(N) host arithmetic on the detections."""

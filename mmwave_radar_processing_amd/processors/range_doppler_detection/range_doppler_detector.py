@@ -24,7 +24,7 @@ class RangeDopplerDetector(RangeDopplerProcessor):
         self.rng_dop_resp_raw: Optional[np.ndarray] = None
         self.rng_dop_resp: Optional[np.ndarray] = None
         self.dets: Optional[np.ndarray] = None
-        self._dev = None        # (d_rd, d_mag64, (V, S, C)) of the last frame
+        self._dev = None        # (d_rd, d_mag64, (V, S, C), d_cube) of the last frame
 
     def reset(self):
         super().reset()
@@ -42,7 +42,7 @@ class RangeDopplerDetector(RangeDopplerProcessor):
         ctx, bufs, d_cube, d_rd, _, (V, S, C) = self._range_doppler_device(adc_cube, want_mag=False)
         d_mag = bufs.get("mag64", S * C * 8)
         _lib.check(ctx.lib.mmw_range_doppler_mag64(ctx.handle, d_cube.ptr, d_mag.ptr, 1, V, S, C, 0))
-        self._dev = (d_rd, d_mag, (V, S, C))
+        self._dev = (d_rd, d_mag, (V, S, C), d_cube)
         self.rng_dop_resp_raw = d_rd.download((V, S, C), np.complex64).astype(np.complex128)
         self.rng_dop_resp = d_mag.download((S, C), np.float64)
         return self.rng_dop_resp_raw, self.rng_dop_resp

@@ -27,7 +27,7 @@ class RangeDopplerDetector2D(RangeDopplerDetector):
             dets = det.detect(rng_dop_resp)     # foreign map or 1-D detector: the detector's own path
             return np.array(dets, dtype=int) if dets else np.empty((0, 2), dtype=int)
         ctx, bufs = self._device()
-        _, d_mag, (_, S, C) = self._dev
+        _, d_mag, (_, S, C) = self._dev[:3]
         n = S * C
         d_thr, d_noise, d_mask = bufs.get("thr", n * 8), bufs.get("noise", n * 8), bufs.get("mask", n)
         det._launch_device(ctx, d_mag.ptr, d_thr.ptr, d_noise.ptr, d_mask.ptr, 1, S, C)

@@ -31,6 +31,14 @@ def rel_err(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
 
 
+CROSS_SCHEDULE_TOL = 1e-6      # max |a - b| / max |b| between two schedules of the same chain (float32 ulps)
+
+
+def cross_schedule_dev(a, b):
+    """Largest element-wise deviation between two schedules' outputs, relative to the frame's peak magnitude."""
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
 def make_cm(text):
     cm = ConfigManager()
     cm.load_cfg_text(text)
@@ -152,16 +160,16 @@ def test_detector_and_point_cloud_vs_oracle(seed):
     np.testing.assert_array_equal(pcg.detector.dets, dets_ref)
     raw = O.range_doppler(cube)
     got_az, got_el = pcg._compute_angle_estimation(pcg.detector.rng_dop_resp_raw, dets_ref[:, 0], dets_ref[:, 1])
-    # argmax indices identical, except where the oracle's two best bins tie to within fp32 resolution
-    for got, ant, shift, ref_i in ((got_az, az, True, az_i), (got_el, el, False, el_i)):
-        _, resp = O.angle_argmax(raw, dets_ref[:, 0], dets_ref[:, 1], ant, 64, shift)
+    # argmax indices identical to the float64 oracle's: the float32 pass re-evaluates every detection it cannot decide
+    # within its error bound in float64 from the raw cube (mmw_angle_argmax_exact)
+    for got, ref_i in ((got_az, az_i), (got_el, el_i)):
         gi = np.array([int(np.where(pcg.angle_bins == a)[0][0]) for a in got])
-        bad = np.where(gi != ref_i)[0]
-        for b in bad:
-            assert abs(resp[b, gi[b]] - resp[b, ref_i[b]]) <= 1e-5 * resp[b, ref_i[b]]
-        assert len(bad) <= 1
-    ok = np.all(np.isclose(pc, pc_ref, atol=1e-5 * sc["range_max_m"]), axis=1)
-    assert ok.sum() >= len(ok) - 1
+        np.testing.assert_array_equal(gi, ref_i)
+    # a caller-supplied complex128 cube takes the float64 cell path (mmw_angle_argmax_cells64): same indices again
+    got_az2, got_el2 = pcg._compute_angle_estimation(raw, dets_ref[:, 0], dets_ref[:, 1])
+    np.testing.assert_array_equal(got_az2, got_az)
+    np.testing.assert_array_equal(got_el2, got_el)
+    np.testing.assert_allclose(pc, pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
 
 
 def test_sample_cfg_non_pow2_pipeline(golden):
@@ -430,8 +438,7 @@ def test_frame_pipeline_matches_per_frame_processors_and_oracle():
         assert pipe.dets[f].dtype == np.int64
         single = pcg.process(cubes[f])
         np.testing.assert_array_equal(pcs[f], single)            # same kernels, same bits
-        ok = np.all(np.isclose(pcs[f], pc_ref, atol=1e-5 * sc["range_max_m"]), axis=1)
-        assert ok.sum() >= len(ok) - 1
+        np.testing.assert_allclose(pcs[f], pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
     pipe.chain3d()
     for f in (0, F - 1):
         assert rel_err(pipe.fetch_chain3d(f), O.fft3d_windowed(cubes[f])) <= SPEC_TOL
@@ -775,11 +782,79 @@ def test_full_batch_size_independent_properties():
         b = d_out2.download((step, A * S * C), np.float32, f0 * A * S * C * 4)
         sums1[f0:f0 + step] = a.sum(axis=1, dtype=np.float64)
         sums2[f0:f0 + step] = b.sum(axis=1, dtype=np.float64)
-        assert np.array_equal(a[::7], b[::7])           # same kernels, same bits
-    np.testing.assert_array_equal(sums1, sums2)
+        # same arithmetic in separately compiled kernels (the compiler contracts a few multiply-adds differently):
+        # a few units in the last place of float32, far inside the 1e-5 budget
+        assert cross_schedule_dev(a[::7], b[::7]) <= CROSS_SCHEDULE_TOL
+    np.testing.assert_allclose(sums1, sums2, rtol=1e-7)
     assert np.all(sums1 > 0)
     for b_ in (d_in, d_rd, d_out, d_mix, d_mix_out, d_out1, d_out2):
         b_.free()
+
+
+def test_chain_schedules_agree_and_hand_over(monkeypatch):
+    """mmw_chain3d has three schedules for the 256 x 128 plane: serial, overlapped with events per chunk of frames, and
+    device-synchronised (one range-Doppler and one angle launch per call, frames handed over through counters and a
+    ring in device memory).  They run the same arithmetic in separately compiled kernels: outputs agree to float32
+    rounding across schedules and are bit-identical within one schedule -- for batches shorter and longer than the ring,
+    back to back without a host sync, and across a change of the ring layout."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    S, C, A = 256, 128, 64
+    F = 130
+    d_in = ctx.alloc(F * 12 * S * C * 8)
+    d_out = ctx.alloc(F * A * S * C * 8)
+    d_out2 = ctx.alloc(F * A * S * C * 8)
+    _lib.check(L.mmw_synth_cubes(h, d_in.ptr, F, 12, S, C, 4242, 8, 30.0))
+
+    def run(mode, n_frames, V, out, flags=0):
+        monkeypatch.setenv("MMW_CHAIN_PIPELINE", "0" if mode == "serial" else "1")
+        monkeypatch.setenv("MMW_CHAIN_MODE", "events" if mode == "events" else "sync")
+        plan = (_lib.C.c_int * 8)()
+        _lib.check(L.mmw_diag_chain_plan(h, n_frames, V, S, C, A, flags, plan))
+        assert (bool(plan[0]), bool(plan[6])) == {"serial": (False, False), "events": (True, False),
+                                                  "sync": (True, True)}[mode]
+        _lib.check(L.mmw_chain3d(h, d_in.ptr, None, out.ptr, n_frames, V, S, C, A, flags))
+
+    def fetch(out, n_frames, esz=8):
+        return out.download((n_frames, A, S, C), np.complex64 if esz == 8 else np.float32)
+
+    run("serial", F, 12, d_out)
+    ref = fetch(d_out, F)
+    cube0 = d_in.download((12, S, C), np.complex64)
+    assert rel_err(ref[0], O.fft3d_windowed(cube0, A)) <= SPEC_TOL
+    for mode in ("events", "sync"):
+        d_out.zero()
+        run(mode, F, 12, d_out)
+        got = fetch(d_out, F)
+        print(f"schedule {mode} vs serial: max deviation {cross_schedule_dev(got, ref):.2e} of the peak, "
+              f"bit-identical: {np.array_equal(got, ref)}")
+        assert cross_schedule_dev(got, ref) <= CROSS_SCHEDULE_TOL, mode
+        if mode == "sync":
+            ref_sync = got
+    # device-synchronised: batches shorter than the ring, back to back into two buffers, no host sync in between
+    d_out.zero()
+    d_out2.zero()
+    run("sync", 5, 12, d_out)
+    run("sync", 77, 12, d_out2)
+    run("sync", 3, 12, d_out)           # overwrites the first three frames of the 5-frame result with the same values
+    assert np.array_equal(fetch(d_out, 5), ref_sync[:5])        # one schedule: bit-identical whatever the batch
+    assert np.array_equal(fetch(d_out2, 77), ref_sync[:77])
+    # change of layout with work in flight: the same bytes read as 8-antenna cubes (no end-plane skipping there: the
+    # Hann(8) end points are zero as well, so V = 8 skips too), magnitude output, then back to 12 antennas
+    F8 = F * 12 // 8
+    run("sync", F8, 8, d_out2, 1)
+    ref8 = fetch(d_out2, F8, 4)[:100].copy()
+    run("serial", 100, 8, d_out2, 1)
+    assert cross_schedule_dev(fetch(d_out2, 100, 4), ref8) <= CROSS_SCHEDULE_TOL
+    d_out2.zero()
+    run("sync", F, 12, d_out)
+    run("sync", 100, 8, d_out2, 1)
+    run("events", 40, 12, d_out)
+    run("sync", F, 12, d_out)
+    assert np.array_equal(fetch(d_out2, 100, 4), ref8)
+    assert np.array_equal(fetch(d_out, F), ref_sync)
+    for b in (d_in, d_out, d_out2):
+        b.free()
 
 
 def test_overlapped_chain_on_an_lds_resident_shape():

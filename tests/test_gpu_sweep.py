@@ -1,4 +1,5 @@
-"""Many-frame parity sweep: CFAR detection indices of the device-resident pipeline vs the oracle, bit-exact.
+"""Many-frame parity sweep: CFAR detection indices, argmax angle bins and point clouds of the device-resident pipeline
+vs the oracle, bit-exact on every index.
 
 Default 96 frames (about 6 s of oracle time on one core); set MMW_SWEEP_FRAMES / MMW_SWEEP_PROCS for the long
 run quoted in DESIGN.md (3000 frames, 16 processes).  Frames come from the device-side generator, so the
@@ -17,9 +18,14 @@ from mmwave_radar_processing_amd.detectors import CaCFAR2D, OsCFAR2D
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_dets(cube):
+AZ, EL = list(range(8)), [8, 9, 10, 11]
+
+
+def _oracle_point_cloud(args):
+    cube, cfg_text = args
     from oracle import oracle_np as O
-    return O.rd_detect_2d(cube)[2]
+    pc, dets, az_i, el_i = O.point_cloud(cube, O.cfg_scalars(cfg_text), AZ, EL)
+    return dets, az_i, el_i, pc
 
 
 # the headline cube (fused register-resident RD kernel) and the shape of the 6843 ods cfgs the reference ships
@@ -28,24 +34,36 @@ def _oracle_dets(cube):
 def test_detection_indices_bit_exact_over_many_frames(shape, scale):
     n_frames = int(os.environ.get("MMW_SWEEP_FRAMES", "96")) * scale
     procs = int(os.environ.get("MMW_SWEEP_PROCS", "4"))
+    cfg_text = synth.synth_cfg_text(num_samples=shape[1], num_loops=shape[2])
     cm = ConfigManager()
-    cm.load_cfg_text(synth.synth_cfg_text(num_samples=shape[1], num_loops=shape[2]))
+    cm.load_cfg_text(cfg_text)
     batch = min(n_frames, 256 * scale)
-    pipe = FramePipeline(cm, max_frames=batch, shape=shape, cfar=CaCFAR2D((4, 4), (2, 2), 1e-5))
-    total_dets = mismatched = 0
+    pipe = FramePipeline(cm, max_frames=batch, shape=shape, cfar=CaCFAR2D((4, 4), (2, 2), 1e-5), az_antenna_idxs=AZ,
+                         el_antenna_idxs=EL)
+    total_dets = bad_dets = bad_az = bad_el = bad_pc = refined = 0
     with get_context("spawn").Pool(procs) as pool:
         for f0 in range(0, n_frames, batch):
             nf = min(batch, n_frames - f0)
             pipe.synth(nf, seed0=900_000 + f0)
-            dets = pipe.detect()
+            pcs = pipe.point_clouds()
+            refined += pipe.n_refined
             cubes = pipe.cubes(0, nf)
-            ref = pool.map(_oracle_dets, [cubes[i] for i in range(nf)], chunksize=4)
+            ref = pool.map(_oracle_point_cloud, [(cubes[i], cfg_text) for i in range(nf)], chunksize=4)
             for f in range(nf):
-                total_dets += ref[f].shape[0]
-                if not np.array_equal(dets[f], ref[f]):
-                    mismatched += 1
-    print(f"sweep {shape}: {n_frames} frames, {total_dets} detections, {mismatched} frames with any index difference")
-    assert mismatched == 0
+                dets_ref, az_ref, el_ref, pc_ref = ref[f]
+                total_dets += dets_ref.shape[0]
+                if not np.array_equal(pipe.dets[f], dets_ref):
+                    bad_dets += 1
+                    continue
+                if dets_ref.shape[0] == 0:
+                    continue
+                bad_az += int(np.count_nonzero(pipe.az_idx[f] != az_ref))
+                bad_el += int(np.count_nonzero(pipe.el_idx[f] != el_ref))
+                bad_pc += int(np.count_nonzero(np.any(np.abs(pcs[f] - pc_ref) > 1e-9 * cm.range_max_m, axis=1)))
+    print(f"sweep {shape}: {n_frames} frames, {total_dets} detections, {bad_dets} frames with any detection index "
+          f"difference, {bad_az} azimuth / {bad_el} elevation argmax index differences, {bad_pc} point-cloud rows off, "
+          f"{refined} argmax evaluations refined in float64")
+    assert bad_dets == 0 and bad_az == 0 and bad_el == 0 and bad_pc == 0
     assert total_dets > 5 * n_frames
 
 
