@@ -154,18 +154,100 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+DET_CFAR = dict(kind=0, train=(4, 4), guard=(2, 2), pfa=1e-5)      # CaCFAR2D((4,4),(2,2),1e-5), SURVEY.md 8d
+AZ_ANT, EL_ANT = list(range(8)), [8, 9, 10, 11]
+DET_CAP = 2048
+DET_BYTES_PER_FRAME = 2 * CUBE_BYTES + S * C * 4    # RD cube in + out, antenna-0 magnitude (+ 8 B / detection)
+
+
+def ca_alpha(n_train: int, pfa: float) -> float:
+    return n_train * (pfa ** (-1.0 / n_train) - 1.0)       # detectors/base.py:293
+
+
+class DetectWorkload:
+    """BASELINE configs[2]: RD (all antennas) + float64 |RD| of antenna 0 + CA-CFAR + ordered compaction + exact
+    azimuth / elevation argmax for every frame of the resident batch (FramePipeline.point_clouds without the host
+    table look-ups)."""
+
+    def __init__(self, ctx, F):
+        from mmwave_radar_processing_amd import _lib
+        self.ctx, self.F, self._lib = ctx, F, _lib
+        n = S * C
+        self.d_rd, self.d_mag, self.d_mask = ctx.alloc(F * CUBE_BYTES), ctx.alloc(F * n * 8), ctx.alloc(F * n)
+        self.d_dets, self.d_cnt = ctx.alloc(F * DET_CAP * 8), ctx.alloc(F * 4)
+        self.d_l1, self.d_az, self.d_el = ctx.alloc(F * V * 4), ctx.alloc(F * DET_CAP * 4), ctx.alloc(F * DET_CAP * 4)
+        (tr, td), (gr, gd) = DET_CFAR["train"], DET_CFAR["guard"]
+        n_train = (2 * (tr + gr) + 1) * (2 * (td + gd) + 1) - (2 * gr + 1) * (2 * gd + 1)
+        self.scale = ca_alpha(n_train, DET_CFAR["pfa"])
+        self.az, self.n_az = _lib.int_array(AZ_ANT)
+        self.el, self.n_el = _lib.int_array(EL_ANT)
+
+    def step(self, d_in):
+        L, h, lib, F = self.ctx.lib, self.ctx.handle, self._lib, self.F
+        (tr, td), (gr, gd) = DET_CFAR["train"], DET_CFAR["guard"]
+        lib.check(L.mmw_detect_batch(h, d_in.ptr, self.d_rd.ptr, self.d_mag.ptr, self.d_mask.ptr, self.d_dets.ptr,
+                                     self.d_cnt.ptr, self.d_l1.ptr, F, V, S, C, DET_CFAR["kind"], tr, td, gr, gd, self.scale,
+                                     0, DET_CAP))
+        for ant, n_ant, d_idx, shift in ((self.az, self.n_az, self.d_az, 1), (self.el, self.n_el, self.d_el, 0)):
+            lib.check(L.mmw_angle_argmax_exact(h, d_in.ptr, self.d_l1.ptr, self.d_rd.ptr, self.d_dets.ptr, self.d_cnt.ptr,
+                                               d_idx.ptr, F, V, S, C, DET_CAP, ant, n_ant, A, shift, None))
+
+    def parity(self, d_in, frames):
+        """Detections (values and order) and argmax bins of the picked frames against the oracle: mismatch counts."""
+        from mmwave_radar_processing_amd import synth
+        from oracle import oracle_np as O
+        sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+        counts = self.d_cnt.download((self.F,), np.int32)
+        out = {}
+        for f in frames:
+            cube = d_in.download((V, S, C), np.complex64, f * CUBE_BYTES)
+            _, dets_ref, az_ref, el_ref = O.point_cloud(cube, sc, AZ_ANT, EL_ANT)
+            n = int(counts[f])
+            dets = self.d_dets.download((n, 2), np.int32, f * DET_CAP * 8).astype(np.int64)
+            ok = n == dets_ref.shape[0] and np.array_equal(dets, dets_ref)
+            bad_idx = -1
+            if ok and n:
+                az = self.d_az.download((n,), np.int32, f * DET_CAP * 4)
+                el = self.d_el.download((n,), np.int32, f * DET_CAP * 4)
+                bad_idx = int(np.count_nonzero(az != az_ref) + np.count_nonzero(el != el_ref))
+            out[f"frame{f}"] = {"detections": n, "detection_indices_identical": bool(ok),
+                                "argmax_index_differences": bad_idx if ok else None}
+        return out, int(counts.sum())
+
+
+def cpu_baseline_detect(seconds: float = 12.0):
+    from mmwave_radar_processing_amd import synth
+    from oracle import oracle_np as O
+    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    cubes = [synth.synth_cube(1000 + i) for i in range(4)]
+    O.point_cloud(cubes[0], sc, AZ_ANT, EL_ANT)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.point_cloud(cubes[n % len(cubes)], sc, AZ_ANT, EL_ANT)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 8:
+            break
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames of the same synthetic 12x256x128 workload through oracle_np.point_cloud (float64 NumPy "
+                      f"RD + CA-CFAR + angle argmax, single thread) in {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1250, help="frames resident per GPU (10k-frame batch / 8 GPUs)")
+    ap.add_argument("--workload", choices=("chain", "detect"), default="chain",
+                    help="chain: range+Doppler+angle FFT chain (BASELINE configs[1], the headline); detect: RD + CA-CFAR + "
+                         "point-cloud angle argmax (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--profile-every", type=int, default=7,
-                    help="record a HIP event pair around every n-th launch of each kernel inside the timed region "
-                         "(7 is coprime with the 32 launches of a 1250-frame step, so the short tail chunk is sampled "
-                         "in proportion and the average matches rocprofv3's all-launch average)")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="record a HIP event pair around every n-th launch of each kernel inside the timed region; 0 = "
+                         "auto: every launch when a step is one launch per stage, else every 7th (coprime with the "
+                         "launches per step, so a short tail chunk is sampled in proportion)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     args = ap.parse_args()
 
@@ -187,14 +269,21 @@ def main():
     ctx = _lib.Context(local_rank % ndev)
     info = _lib.device_info(ctx.device)
     F = args.frames
+    detect = args.workload == "detect"
     d_in = ctx.alloc(F * CUBE_BYTES)
-    d_out = ctx.alloc(F * OUT_BYTES)
+    d_out = None if detect else ctx.alloc(F * OUT_BYTES)
+    work = DetectWorkload(ctx, F) if detect else None
     # distinct frames per rank: seed0 offsets by the rank's first global frame index
     _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 7_000_000 + rank * F, 8, 30.0))
     ctx.sync()
+    plan = chain_plan(ctx, F)
+    n_launch = 1 if detect else -(-F // plan["frames_per_launch_max"])    # kernel launches of each stage per step
 
     def step():
-        _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+        if detect:
+            work.step(d_in)
+        else:
+            _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
 
     def barrier():
         ctx.sync()
@@ -206,7 +295,7 @@ def main():
     barrier()
     if not args.no_profile:
         ctx.profile_reset()
-        ctx.profile_enable(max(1, args.profile_every))
+        ctx.profile_enable(args.profile_every if args.profile_every > 0 else (1 if n_launch == 1 else 7))
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
@@ -226,27 +315,41 @@ def main():
     if rank == 0:
         total_frames = world * F * args.steps
         value = total_frames / elapsed
-        plan = chain_plan(ctx, F)
-        n_launch = -(-F // plan["frames_per_launch_max"])           # kernel launches of each stage per step
+        algo = DET_BYTES_PER_FRAME if detect else ALGO_BYTES_PER_FRAME
         out = {
             "metric": baseline_metric(),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "IWR1843 synthetic 256x128x(4Rx x 3Tx) cube: Hann range FFT + Doppler FFT + "
-                                   "64-bin angle FFT -> complex64 [64,256,128] (BASELINE configs[1])",
+            "config": {"workload": ("IWR1843 synthetic 256x128x(4Rx x 3Tx) cube: range-Doppler of all antennas (float32) + "
+                                    "float64 |RD| of antenna 0 + CA-CFAR((4,4),(2,2),1e-5) + ordered detections + exact "
+                                    "8-antenna azimuth / 4-antenna elevation argmax (BASELINE configs[2])") if detect else
+                                   ("IWR1843 synthetic 256x128x(4Rx x 3Tx) cube: Hann range FFT + Doppler FFT + "
+                                    "64-bin angle FFT -> complex64 [64,256,128] (BASELINE configs[1])"),
                        "frames_per_gpu": F, "cube": [V, S, C], "angle_bins": A,
                        "sharding": f"frame-sharded x{world}, no collective",
-                       "schedule": plan,
+                       "schedule": "stages back to back on one stream, whole batch per launch" if detect else plan,
                        "device": info["name"], "arch": info["arch"]},
             "hip_event_ms_per_step_rank0": ev_ms / args.steps,
-            "chain_hbm_frac_of_8TBs": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),
+            "chain_hbm_frac_of_8TBs": value / world * algo / (HBM_PEAK_GBS * 1e9),
         }
-        if not args.no_profile:
+        if not args.no_profile and detect:
+            fam = {k: ctx.profile_get(k) for k in ("rd", "rd64", "cfar", "compact", "plane_l1", "argmax")}
+            out["kernels_ms_per_step"] = {k: ms / max(n, 1) * (2 if k == "argmax" else 1) for k, (ms, n) in fam.items() if n}
+            rd_ms, rd_n = fam["rd"]
+            if rd_n:
+                avg_s = rd_ms * 1e-3 / rd_n
+                achieved = F * 2 * CUBE_BYTES / avg_s / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": "k_rd_fused_256x128_persist (range-Doppler of all 12 planes: the "
+                                   "largest stage of the pipeline)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                                   "launches": rd_n, "frames_per_launch": F,
+                                   "algorithmic_bytes_per_launch": F * 2 * CUBE_BYTES}
+        if not args.no_profile and not detect:
             ang_ms, ang_n = ctx.profile_get("angle")
             rd_ms, rd_n = ctx.profile_get("rd")
             if ang_n:
-                # sampled launches: full 40-frame chunks and the tail chunk are hit in proportion
+                # sampled launches: full chunks and the tail chunk are hit in proportion
                 frames_per_launch = F / n_launch
                 avg_s = ang_ms * 1e-3 / ang_n
                 achieved = frames_per_launch * ALGO_BYTES_PER_FRAME / avg_s / 1e9
@@ -258,7 +361,9 @@ def main():
                     traffic_src = ("static: PMC bytes per frame from " + os.path.relpath(args.traffic_json, ROOT) +
                                    " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, FETCH "
                                    "doubled per the gfx950 note) x frames per launch; not measured in this run")
-                out["roofline"] = {"bound": "hbm", "kernel": "k_angle64 (angle FFT, reads V planes / writes 64)",
+                out["roofline"] = {"bound": "hbm",
+                                   "kernel": ("k_angle64_sync" if plan["device_sync"] else "k_angle64") +
+                                             " (angle FFT: reads the live RD planes, writes 64 angle planes)",
                                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                    "avg_launch_us": avg_s * 1e6, "launches": ang_n,
@@ -273,18 +378,25 @@ def main():
                                     "algorithmic_bytes_per_launch": fpl * rd_bytes}
         # parity of this very run: first frame, a frame inside the last full launch and the batch's last frame (the
         # short tail launch), against the oracle on the SAME bytes -- not timed
-        picks = sorted({0, max(0, (n_launch - 1) * plan["frames_per_launch_max"] - 1), F - 1})
-        saved = [(f"frame{f}", d_in.download((V, S, C), np.complex64, f * CUBE_BYTES),
-                  d_out.download((A, S, C), np.complex64, f * OUT_BYTES)) for f in picks]
-        if "roofline" in out:
-            out["roofline"]["insitu_streaming_ceiling"] = insitu_ceiling(ctx, d_out, F * OUT_BYTES)
-        out["parity_max_rel_err"] = parity_check(saved)
+        picks = sorted({0, max(0, (n_launch - 1) * plan["frames_per_launch_max"] - 1) if not detect else F // 2, F - 1})
+        if detect:
+            out["parity"], total_dets = work.parity(d_in, picks)
+            out["detections_per_frame"] = total_dets / F
+            parity_ok = all(v["detection_indices_identical"] and not v["argmax_index_differences"] for v in out["parity"].values())
+        else:
+            saved = [(f"frame{f}", d_in.download((V, S, C), np.complex64, f * CUBE_BYTES),
+                      d_out.download((A, S, C), np.complex64, f * OUT_BYTES)) for f in picks]
+            if "roofline" in out:
+                out["roofline"]["insitu_streaming_ceiling"] = insitu_ceiling(ctx, d_out, F * OUT_BYTES)
+            out["parity_max_rel_err"] = parity_check(saved)
+            parity_ok = max(out["parity_max_rel_err"].values()) <= 1e-5
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["cpu_baseline_all_cores"] = cpu_baseline_pool()
+            out["cpu_baseline"] = cpu_baseline_detect() if detect else cpu_baseline()
+            if not detect:
+                out["cpu_baseline_all_cores"] = cpu_baseline_pool()
         print(json.dumps(out))
-        if not max(out["parity_max_rel_err"].values()) <= 1e-5:
-            sys.exit("bench.py: GPU chain output differs from the oracle beyond 1e-5 -- the figure above is invalid")
+        if not parity_ok:
+            sys.exit("bench.py: GPU output differs from the oracle (spectra beyond 1e-5 / any index) -- the figure above is invalid")
     if dist is not None:
         with stdout_to_stderr():
             dist.barrier()

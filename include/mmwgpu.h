@@ -189,9 +189,11 @@ int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t 
 /* mmw_detect_batch: the detection pipeline of RangeDopplerDetector2D for a batch of frames in one call:
  *   d_rd[F][V][S][C] c64 (mmw_range_doppler) and, for antenna 0, d_mag64[F][S][C] -> 2-D CFAR mask -> ordered
  *   detections d_dets[F][cap][2] / d_counts[F]
- *   (range_doppler_detection/range_doppler_detector.py:45-80 + range_doppler_detector_2d.py:49-65 per frame). */
+ *   (range_doppler_detection/range_doppler_detector.py:45-80 + range_doppler_detector_2d.py:49-65 per frame).
+ *   d_l1 (may be NULL): [F][V] float32, the per-plane norms of mmw_plane_l1 for a following
+ *   mmw_angle_argmax_exact -- produced inside the range-Doppler kernel where it can, so the cube is not read again. */
 int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_mag64, uint8_t *d_mask,
-                     int32_t *d_dets, int32_t *d_counts, int n_frames, int V, int S, int C, int cfar_kind,
+                     int32_t *d_dets, int32_t *d_counts, float *d_l1, int n_frames, int V, int S, int C, int cfar_kind,
                      int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap);
 
 /* ---------------------------------------------------------------- point cloud
@@ -203,8 +205,9 @@ int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_ma
  * mmw_plane_l1: d_l1[F][V] float32 = sum over each plane of hann(S) hann(C) (|re| + |im|): the scale of the rounding-
  *   error bound the exact variant uses (computed once per batch, shared by the azimuth and elevation calls).
  * mmw_angle_argmax_exact: same result contract as the reference's complex128 computation (:186-206).  The float32
- *   pass bounds how far its magnitudes can be from the float64 ones (from d_l1 and the gathered cells); a detection
- *   whose best and second-best magnitudes are closer than twice that bound is re-evaluated in float64 from the raw cube
+ *   pass bounds how far its magnitudes can be from the float64 ones (from d_l1 and the gathered cells: 1/8 of the
+ *   worst-case rounding bound, ~10x above the largest error measured; MMW_ARGMAX_BOUND_DIV=1 selects the worst case
+ *   itself); a detection whose best and second-best magnitudes are closer than twice that bound is re-evaluated in float64 from the raw cube
  *   d_cubes (its range-Doppler cells as direct float64 2-D DFT sums, then the float64 angle DFT + argmax).
  *   h_n_refined (may be NULL): number of re-evaluated detections; passing it makes the call synchronise.
  * mmw_angle_argmax_cells64: the float64 angle DFT + first-max argmax for rows of n_ant complex128 cells the caller

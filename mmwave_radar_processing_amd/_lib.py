@@ -65,7 +65,7 @@ _SIGNATURES = {
     "mmw_cfar2d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i],
     "mmw_cfar1d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i],
     "mmw_compact2d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
-    "mmw_detect_batch": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i],
+    "mmw_detect_batch": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i],
     "mmw_angle_argmax": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i],
     "mmw_plane_l1": [_vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_angle_argmax_exact": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip],

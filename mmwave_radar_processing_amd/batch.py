@@ -79,7 +79,7 @@ class FramePipeline:
         self.ctx = ctx if ctx is not None else _lib.default_context()
         self.bufs = _lib.BufferSet(self.ctx)
         self.n_frames = 0
-        self.n_refined, self._l1_valid = 0, False
+        self.n_refined = 0
         cm = config_manager
         self.vel_bins = np.arange(-cm.vel_max_m_s, cm.vel_max_m_s - cm.vel_res_m_s + 1e-3, cm.vel_res_m_s)
         self.range_bins = np.arange(0, cm.range_max_m - cm.range_res_m / 2 + 1e-3, cm.range_res_m)
@@ -158,12 +158,13 @@ class FramePipeline:
         d_mask = self.bufs.get("mask", max(F, 1) * n)
         self.d_dets = self.bufs.get("dets", max(F, 1) * cap * 8)
         self.d_cnt = self.bufs.get("counts", max(F, 1) * 4)
+        self.d_l1 = self.bufs.get("plane_l1", max(F, 1) * V * 4)     # error-bound scale for the exact argmax
         (tr, td), (gr, gd) = self.cfar.num_train, self.cfar.num_guard
         for f0 in range(0, F, 32768):       # grid limits of the per-frame launches
             nf = min(32768, F - f0)
             _lib.check(L.mmw_detect_batch(h, self.d_in.at(f0 * self.cube_bytes), self.d_rd.at(f0 * self.cube_bytes),
                                           d_mag.at(f0 * n * 8), d_mask.at(f0 * n), self.d_dets.at(f0 * cap * 8),
-                                          self.d_cnt.at(f0 * 4), nf, V, S, C, self.cfar.kind, int(tr), int(td), int(gr),
+                                          self.d_cnt.at(f0 * 4), self.d_l1.at(f0 * V * 4), nf, V, S, C, self.cfar.kind, int(tr), int(td), int(gr),
                                           int(gd), float(self.cfar._scale()), int(self.cfar._k_rank()), cap))
         self.counts = self.d_cnt.download((F,), np.int32)
         if np.any(self.counts > cap):
@@ -177,11 +178,8 @@ class FramePipeline:
         """Exact (float64-equivalent) argmax bins of every detection: ``mmw_angle_argmax_exact``."""
         F, cap = self.n_frames, self.cap
         d_idx = self.bufs.get("angle_idx", max(F, 1) * cap * 4)
-        d_l1 = self.bufs.get("plane_l1", max(F, 1) * self.V * 4)
+        d_l1 = self.d_l1                    # filled by detect()
         L, h = self.ctx.lib, self.ctx.handle
-        if not self._l1_valid:
-            _lib.check(L.mmw_plane_l1(h, self.d_in.ptr, d_l1.ptr, F, self.V, self.S, self.C))
-            self._l1_valid = True
         arr, n_ant = _lib.int_array(ant)
         n_ref = _lib.C.c_int(0)
         for f0 in range(0, F, 32768):
@@ -196,7 +194,7 @@ class FramePipeline:
     def point_clouds(self) -> List[np.ndarray]:
         """Per-frame float64 ``(N, 4)`` (x, y, z, velocity), FLU frame (point_cloud_generator.py:216-248)."""
         dets = self.detect()
-        self.n_refined, self._l1_valid = 0, False   # detections re-evaluated in float64 (near-ties of the float32 pass)
+        self.n_refined = 0      # detections re-evaluated in float64 (near-ties of the float32 pass)
         az_idx = self._argmax(self.az, self.shift_az) if self.az else None
         el_idx = self._argmax(self.el, self.shift_el) if self.el else None
         out = []
@@ -213,3 +211,145 @@ class FramePipeline:
         self.az_idx = None if az_idx is None else [az_idx[f, :len(d)].astype(np.int64) for f, d in enumerate(dets)]
         self.el_idx = None if el_idx is None else [el_idx[f, :len(d)].astype(np.int64) for f, d in enumerate(dets)]
         return out
+
+
+class MultiDeviceFramePipeline:
+    """One process, every visible device: the frame range is block-split (``shard_bounds``) over one ``FramePipeline``
+    per device, each driven by its own host thread (a context is only ever touched by its thread), results land in
+    disjoint slices of caller-owned arrays and per-frame lists come back concatenated in frame order.  No device
+    talks to another (no collective).  This is what the reference's single-process frame loops
+    (scripts/test_vel_estimation.py:145-151) turn into on a multi-GPU node; ``bench.py --gpus N`` keeps the
+    one-process-per-GPU form.
+
+    ``part_factory(device, max_frames)`` builds the per-device pipeline (default: ``FramePipeline`` on a new
+    ``Context(device)``); tests inject a host-only fake to exercise the split / join logic without a GPU."""
+
+    def __init__(self, config_manager, max_frames: int, shape: Tuple[int, int, int], devices: Optional[Sequence[int]] = None,
+                 part_factory: Optional[Callable[[int, int], object]] = None, **pipeline_kwargs):
+        from concurrent.futures import ThreadPoolExecutor
+        if devices is None:
+            devices = list(range(_lib.device_count()))
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise _lib.MmwGpuError("no HIP device visible: the MI355X HIP path is the only backend")
+        self.world = len(self.devices)
+        self.max_frames = int(max_frames)
+        self.shape = tuple(int(x) for x in shape)
+        per_dev = -(-self.max_frames // self.world)
+        if part_factory is None:
+            def part_factory(device, n):
+                return FramePipeline(config_manager, n, shape, ctx=_lib.Context(device), **pipeline_kwargs)
+        # one single-thread executor per device: every call on a device's context comes from the same host thread
+        self._pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"mmw-dev{d}") for d in self.devices]
+        self.parts = self._each(lambda r: part_factory(self.devices[r], per_dev), all_ranks=True)
+        self.n_frames = 0
+        self.bounds: List[Tuple[int, int]] = [(0, 0)] * self.world
+
+    # ------------------------------------------------------------------ plumbing
+    def _each(self, fn, all_ranks: bool = False) -> List:
+        """``fn(rank)`` on every device thread that holds frames (or on all); results in rank order; the first
+        exception is re-raised after all threads have finished."""
+        ranks = [r for r in range(self.world) if all_ranks or self.bounds[r][1] > self.bounds[r][0]]
+        futs = {r: self._pools[r].submit(fn, r) for r in ranks}
+        out, err = [], None
+        for r in ranks:
+            try:
+                out.append(futs[r].result())
+            except Exception as e:        # noqa: BLE001 -- collected, re-raised below
+                out.append(None)
+                err = err or e
+        if err is not None:
+            raise err
+        return out
+
+    def _set_frames(self, n_frames: int):
+        if n_frames > self.max_frames:
+            raise ValueError("n_frames exceeds max_frames")
+        self.n_frames = int(n_frames)
+        self.bounds = [shard_bounds(self.n_frames, r, self.world) for r in range(self.world)]
+
+    def _join(self, per_rank: List[List]) -> List:
+        out: List = []
+        for part in per_rank:
+            out.extend(part)
+        if len(out) != self.n_frames:
+            raise RuntimeError(f"joined {len(out)} per-frame results for {self.n_frames} frames")
+        return out
+
+    def owner(self, frame: int) -> Tuple[int, int]:
+        """(rank, local frame index) of a global frame index."""
+        if not 0 <= frame < self.n_frames:
+            raise IndexError(frame)
+        r = frame * self.world // self.n_frames
+        return r, frame - self.bounds[r][0]
+
+    # ------------------------------------------------------------------ input
+    def load(self, cubes: np.ndarray):
+        cubes = np.asarray(cubes)
+        if cubes.ndim != 4 or tuple(cubes.shape[1:]) != self.shape:
+            raise ValueError(f"expected [F, {self.shape[0]}, {self.shape[1]}, {self.shape[2]}] cubes, got {cubes.shape}")
+        self._set_frames(cubes.shape[0])
+        self._each(lambda r: self.parts[r].load(cubes[self.bounds[r][0]:self.bounds[r][1]]))
+
+    def synth(self, n_frames: int, seed0: int, **kw):
+        """Frame f of the batch is generated from seed0 + f whichever device it lands on."""
+        self._set_frames(n_frames)
+        self._each(lambda r: self.parts[r].synth(self.bounds[r][1] - self.bounds[r][0], seed0 + self.bounds[r][0], **kw))
+
+    def cubes(self) -> np.ndarray:
+        V, S, C = self.shape
+        out = np.empty((self.n_frames, V, S, C), dtype=np.complex64)
+
+        def fetch(r):
+            lo, hi = self.bounds[r]
+            out[lo:hi] = self.parts[r].cubes(0, hi - lo)
+        self._each(fetch)
+        return out
+
+    # ------------------------------------------------------------------ compute
+    def detect(self) -> List[np.ndarray]:
+        self.dets = self._join(self._each(lambda r: self.parts[r].detect()))
+        return self.dets
+
+    def point_clouds(self) -> List[np.ndarray]:
+        pcs = self._join(self._each(lambda r: self.parts[r].point_clouds()))
+        live = [p for r, p in enumerate(self.parts) if self.bounds[r][1] > self.bounds[r][0]]
+        self.dets = self._join([p.dets for p in live])
+        self.n_refined = sum(p.n_refined for p in live)
+        return pcs
+
+    def chain3d(self, magnitude: bool = False, out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        """3-D windowed FFT of every frame on its device.  ``out`` (optional, caller-owned ``[F, A, S, C]`` complex64 /
+        float32 array): every device thread copies its frames into its own slice of it."""
+        self._each(lambda r: self.parts[r].chain3d(magnitude))
+        if out is None:
+            return None
+        if out.shape[0] < self.n_frames:
+            raise ValueError("output array holds fewer frames than the batch")
+
+        def fetch(r):
+            lo, hi = self.bounds[r]
+            for f in range(lo, hi):
+                out[f] = self.parts[r].fetch_chain3d(f - lo)
+        self._each(fetch)
+        return out
+
+    def fetch_chain3d(self, frame: int) -> np.ndarray:
+        r, local = self.owner(frame)
+        return self._pools[r].submit(self.parts[r].fetch_chain3d, local).result()
+
+    def close(self):
+        for r, pool in enumerate(self._pools):
+            part = self.parts[r]
+
+            def shut(p=part):
+                if hasattr(p, "bufs"):
+                    p.bufs.free()
+                ctx = getattr(p, "ctx", None)
+                if ctx is not None and ctx is not _lib._default_ctx:
+                    ctx.close()
+            try:
+                pool.submit(shut).result()
+            finally:
+                pool.shutdown(wait=True)
+        self.parts = []

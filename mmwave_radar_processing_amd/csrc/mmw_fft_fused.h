@@ -409,7 +409,7 @@ __device__ __forceinline__ const cplx<float> *raw_plane(const cplx<float> *in, l
 // Range FFT = processors/range_doppler_resp.py:99-101 axis -2, Doppler = axis -1, shift = :98,103.
 constexpr int RD_S = 256, RD_C = 128, RD_PITCH = 152;
 constexpr int RD_LDS_MAIN = 128 * RD_PITCH;                       // complex elements (>= 8*16*128 for X1)
-constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8 + 16;      // + W128 table + ticket words
+constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8 + 16 + 64;      // + W128 table + ticket words + L1 partials
 
 // RAW: the input is the raw [F][num_rx][256][num_tx * 128] cube (two 8-B loads per lane and row instead of one 16-B)
 template <bool NTIN, int ABL = 0, bool RAW = false>   // ABL: timing-only ablations (1 no stores, 2 no loads, 3 neither)
@@ -524,16 +524,20 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
 // budget (126 VGPRs, no scratch) and is 12 % faster than one plane per workgroup; PF = 16 spilled and was slower.
 // SYNC: the chain's device-synchronised form (ChainSync above): planes come from a ticket counter, `out` is the ring of
 // RD frames, stores are sc1, and the workgroup waits for / signals the per-slot counters.
-template <bool NTIN, int PF, bool SYNC = false>
+// L1N: also write l1[plane] = sum of |re| + |im| of the windowed plane (the error-bound scale of mmw_angle_argmax_exact;
+// same quantity as k_plane_l1, here for free while the samples are in registers).
+template <bool NTIN, int PF, bool SYNC = false, bool L1N = false>
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
                                                             const cplx<float> *__restrict__ tw256,
-                                                            const cplx<float> *__restrict__ tw128, ChainSync cs) {
+                                                            const cplx<float> *__restrict__ tw128, ChainSync cs,
+                                                            float *__restrict__ l1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
     cplx<float> *tw128_l = lds + RD_LDS_MAIN;
     int *lds_ctl = reinterpret_cast<int *>(tw128_l + 128);      // SYNC: [0] / [1] tickets (double buffered), [2] abort
+    float *lds_l1 = reinterpret_cast<float *>(lds_ctl + 4);     // L1N: one partial sum per wave
     if (threadIdx.x < 128) tw128_l[threadIdx.x] = tw128[threadIdx.x];
     const int t0 = threadIdx.x;
     const int l0 = t0 & 63;
@@ -592,6 +596,7 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
         if constexpr (PF < 16) issue_loads(plane, std::integral_constant<int, PF>{}, std::integral_constant<int, 16>{});
         // ---- step 0: window, range pass 1 (n = 16*n1 + w)
         cplx<float> y0[16], y1[16];
+        [[maybe_unused]] float l1_acc = 0.f;
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int n = 16 * n1 + w;
@@ -599,6 +604,11 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
             const float hs = hann_s[n];
             y0[n1] = cplx<float>{v.x, v.y} * (hs * hc0);
             y1[n1] = cplx<float>{v.z, v.w} * (hs * hc1);
+            if constexpr (L1N) l1_acc += (fabsf(y0[n1].x) + fabsf(y0[n1].y)) + (fabsf(y1[n1].x) + fabsf(y1[n1].y));
+        }
+        if constexpr (L1N) {
+            for (int d = 32; d >= 1; d >>= 1) l1_acc += __shfl_xor(l1_acc, d, 64);
+            if (l == 0) lds_l1[w] = l1_acc;      // read by thread 0 after this plane's first barrier
         }
         RegFFT<16, float>::run(y0);
         RegFFT<16, float>::run(y1);
@@ -630,6 +640,14 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
                 }
             }
             __syncthreads();
+            if constexpr (L1N && h == 0) {
+                if (t == 0) {               // fixed summation order: the value does not depend on timing
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a += lds_l1[i];
+                    l1[plane] = a;
+                }
+            }
             if constexpr (SYNC) {
                 if constexpr (h == 0) {
                     dead = __builtin_amdgcn_readfirstlane(lds_ctl[2]) != 0;
@@ -875,7 +893,9 @@ inline bool rd_lds_supported(int S, int C) {
 // launch_rd_lds / launch_rd_fused instantiate ~15 large kernels; they are compiled once, in mmw_tu_rd.hip
 // (MMW_TU_RD), and only declared for the other translation units.
 int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv = RawView{1, 0});
-int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv = RawView{1, 0});
+// d_l1 != nullptr: also l1[plane] (see k_plane_l1); *l1_done tells whether this launch produced it
+int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv = RawView{1, 0},
+                    float *d_l1 = nullptr, bool *l1_done = nullptr);
 
 #ifdef MMW_TU_RD
 int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv) {
@@ -900,11 +920,13 @@ int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_ite
     auto kern = k_rd_fused_256x128_persist<true, 8, true>;
     MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in, (cplx<float> *)d_ring,
-                       n_items, (const float *)hs, (const float *)hc, (const cplx<float> *)t256, (const cplx<float> *)t128, cs);
+                       n_items, (const float *)hs, (const float *)hc, (const cplx<float> *)t256, (const cplx<float> *)t128, cs,
+                       (float *)nullptr);
     return check_launch("rd_fused_sync");
 }
 
-int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv) {
+int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv, float *d_l1, bool *l1_done) {
+    if (l1_done) *l1_done = false;
     if (!rd_fused_supported(S, C)) return set_error(MMW_ERR_UNSUPPORTED, "fused RD kernel is 256x128 only");
     const void *hs, *hc, *t256, *t128;
     MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_S, &hs));
@@ -937,9 +959,16 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
                                (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                               (const cplx<float> *)t256, (const cplx<float> *)t128, ChainSync{});
+                               (const cplx<float> *)t256, (const cplx<float> *)t128, ChainSync{}, (float *)nullptr);
         };
-        launch(k_rd_fused_256x128_persist<true, 8>);
+        if (d_l1) {
+            auto kern = k_rd_fused_256x128_persist<true, 4, false, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
+                               (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                               (const cplx<float> *)t256, (const cplx<float> *)t128, ChainSync{}, d_l1);
+            if (l1_done) *l1_done = true;
+        } else launch(k_rd_fused_256x128_persist<true, 8>);
         return check_launch("rd_fused_persist");
     }
 #ifdef MMW_ABLATE   // timing-only variants (no loads / no stores), build with EXTRA=-DMMW_ABLATE

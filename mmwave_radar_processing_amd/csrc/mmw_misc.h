@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void k_synth(float2 *cubes, long total, int V,
         re += amp * cs;
         im += amp * sn;
     }
-    const unsigned long long h = mix64(fs ^ mix64((unsigned long long)gid * 2 + 0x51ull));
+    // noise keyed by (frame seed, element index inside the frame): a frame's bytes do not depend on where in a batch
+    // (or on which device of a sharded batch) it is generated
+    const unsigned long long e = (unsigned long long)(gid - (long)f * ((long)C * S * V));
+    const unsigned long long h = mix64(fs ^ mix64(e * 2 + 0x51ull));
     const float u1 = u01(h), u2 = u01(mix64(h + 7));
     const float rad = sigma * sqrtf(-2.0f * logf(u1));
     float sn, cs;
@@ -273,19 +276,34 @@ template <typename T> __device__ __forceinline__ bool mag_better(T a, int ia, T 
 // bound of the float32 range-Doppler cell values (see k_angle_argmax).  One workgroup per plane.
 __global__ __launch_bounds__(256) void k_plane_l1(const float2 *__restrict__ in, float *__restrict__ l1, int S, int C,
                                                    const float *__restrict__ ws, const float *__restrict__ wc) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float2 *src = in + (long)blockIdx.x * S * C;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) {
-        float row = 0.f;
-        for (int c = threadIdx.x; c < C; c += 256) {
-            const float2 v = src[(long)s * C + c];
-            row += wc[c] * (fabsf(v.x) + fabsf(v.y));
+    if ((C & 1) == 0) {             // one wave per row, 16-B loads
+        const f4 *src4 = reinterpret_cast<const f4 *>(src);
+        const int C2 = C >> 1;
+        for (int s = wave; s < S; s += 4) {
+            float row = 0.f;
+            for (int p = lane; p < C2; p += 64) {
+                const f4 v = __builtin_nontemporal_load(src4 + (long)s * C2 + p);
+                row += wc[2 * p] * (fabsf(v.x) + fabsf(v.y)) + wc[2 * p + 1] * (fabsf(v.z) + fabsf(v.w));
+            }
+            acc += ws[s] * row;
         }
-        acc += ws[s] * row;
+    } else {
+        for (int s = wave; s < S; s += 4) {
+            float row = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                const float2 v = src[(long)s * C + c];
+                row += wc[c] * (fabsf(v.x) + fabsf(v.y));
+            }
+            acc += ws[s] * row;
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    if (lane == 0) part[wave] = acc;
     __syncthreads();
     if (threadIdx.x == 0) l1[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
@@ -424,44 +442,170 @@ __global__ __launch_bounds__(256) void k_argmax64_cells(const cplx<double> *cell
 }
 
 // Flagged detections: the range-Doppler cell of every listed antenna as the float64 2-D DFT coefficient of the windowed
-// cube (direct S*C-term sum, table twiddles), then the float64 argmax.  One workgroup per flagged detection.
-__global__ __launch_bounds__(256) void k_argmax_refine(const float2 *__restrict__ cubes, const int32_t *dets, const int *n_flag,
-                                                        const int *list, int list_cap, int32_t *out_idx, int V, int S, int C,
-                                                        int cap, AntList ants, int A, int shift, const double *__restrict__ ws,
-                                                        const double *__restrict__ wc, const cplx<double> *__restrict__ twS,
-                                                        const cplx<double> *__restrict__ twC, const cplx<double> *twA) {
-    __shared__ cplx<double> red[4];
-    __shared__ cplx<double> X[MAX_ANT];
-    int n = *n_flag;
-    if (n > list_cap) n = list_cap;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = blockIdx.x; e < n; e += gridDim.x) {
-        const int id = list[e], f = id / cap, det = id - f * cap;
-        const int r = dets[((long)f * cap + det) * 2], v = dets[((long)f * cap + det) * 2 + 1];
-        int kd = v - C / 2;                 // FFT bin behind the fftshifted Doppler index
-        if (kd < 0) kd += C;
-        for (int i = 0; i < ants.n; ++i) {
-            const float2 *plane = cubes + ((long)f * V + ants.idx[i]) * S * C;
-            cplx<double> acc = cplx<double>{0.0, 0.0};
-            for (int cell = tid; cell < S * C; cell += 256) {
-                const int s = cell / C, c = cell - s * C;
-                const float2 xv = plane[cell];
-                const double w = ws[s] * wc[c];
-                const cplx<double> ph = cmul(twS[(int)(((long)r * s) % S)], twC[(int)(((long)kd * c) % C)]);
-                acc = acc + cmul(cplx<double>{w * (double)xv.x, w * (double)xv.y}, ph);
+// cube (direct S*C-term sum, table twiddles), then the float64 argmax.  The sum over a plane is cut into REFINE_PARTS
+// slices, one workgroup each (a single workgroup per detection is latency-bound on its 32 trips to cold HBM lines):
+//   k_argmax_refine_part   partial[e][part][i] for the first `n_split` flagged detections; a thread walks cells
+//                          base + tid, + 256, ... keeping (s, c) and the two twiddle indices up to date incrementally and
+//                          uses each cell's window * phase factor for all antennas of the list;
+//   k_argmax_refine_finish adds the slices in a fixed order and runs the float64 argmax (one wave per detection);
+//   k_argmax_refine_whole  whole planes in one workgroup: the (never yet seen) overflow beyond n_split detections.
+constexpr int REFINE_PARTS = 8, REFINE_NA = 8;
+
+struct RefineArgs {
+    const float2 *cubes;
+    const int32_t *dets;
+    const int *n_flag, *list;
+    int list_cap;
+    int32_t *out_idx;
+    int V, S, C, cap;
+    AntList ants;
+    int A, shift;
+    const double *ws, *wc;
+    const cplx<double> *twS, *twC, *twA;
+    cplx<double> *partial;      // [n_split][REFINE_PARTS][ants.n]
+    int n_split;
+};
+
+// sum over cells [cell_lo, cell_hi) of plane (f, ant) * window * phase, for antennas a0 .. a0 + NA - 1 of the list
+template <int NA>
+__device__ __forceinline__ void refine_accumulate(const RefineArgs &a, int f, int r, int kd, int a0, long cell_lo, long cell_hi,
+                                                  int tid, cplx<double> (&acc)[NA]) {
+    const int S = a.S, C = a.C;
+    const long plane_cells = (long)S * C;
+    const int ds = 256 / C, dc = 256 - ds * C;         // advancing a cell index by 256: c += dc (carry into s), s += ds
+    const int is_ds = (int)(((long)r * ds) % S), is_1 = r % S, ic_dc = (int)(((long)kd * dc) % C);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = cplx<double>{0.0, 0.0};
+    const long first = cell_lo + tid;
+    int s = (int)(first / C), c = (int)(first - (long)s * C);
+    if (s >= S) s = 0;
+    int is = (int)(((long)r * s) % S), ic = (int)(((long)kd * c) % C);
+    constexpr int U = 4;        // four cells per trip: all of their (cold) samples are requested before any is used
+    for (long cell0 = first; cell0 < cell_hi; cell0 += 256 * U) {
+        float2 xv[U][NA];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const long cell = cell0 + 256 * u;
+                xv[u][i] = (a0 + i < a.ants.n && cell < cell_hi)
+                               ? a.cubes[((long)f * a.V + a.ants.idx[a0 + i]) * plane_cells + cell] : make_float2(0.f, 0.f);
             }
-            for (int d = 32; d >= 1; d >>= 1) {
-                acc.x += __shfl_xor(acc.x, d, 64);
-                acc.y += __shfl_xor(acc.y, d, 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (cell0 + 256 * u < cell_hi) {
+                const double w = a.ws[s] * a.wc[c];
+                const cplx<double> ph = cmul(a.twS[is], a.twC[ic]) * w;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) acc[i] = acc[i] + cmul(cplx<double>{(double)xv[u][i].x, (double)xv[u][i].y}, ph);
             }
-            if (lane == 0) red[wave] = acc;
-            __syncthreads();
-            if (tid == 0) X[i] = (red[0] + red[1]) + (red[2] + red[3]);
-            __syncthreads();
+            c += dc;
+            ic += ic_dc;
+            if (ic >= C) ic -= C;
+            if (c >= C) {               // kd * (c - C) == kd * c (mod C): ic unchanged
+                c -= C;
+                ++s;
+                is += is_1;
+                if (is >= S) is -= S;
+            }
+            s += ds;
+            is += is_ds;
+            if (is >= S) is -= S;
+            if (s >= S) s = is = 0;     // past the plane (guarded above): keep the table indices in range
         }
-        if (wave == 0) {
-            const int idx = argmax64_wave(X, ants.n, A, shift, twA, lane);
-            if (lane == 0) out_idx[(long)f * cap + det] = idx;
+    }
+}
+
+// block-wide sum of acc[i] in a fixed order -> out[i] (thread i writes), `red` = [4][NA] LDS words
+template <int NA>
+__device__ __forceinline__ void refine_reduce(cplx<double> (&acc)[NA], cplx<double> (*red)[NA], int tid, cplx<double> *out, int n_out) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            acc[i].x += __shfl_xor(acc[i].x, d, 64);
+            acc[i].y += __shfl_xor(acc[i].y, d, 64);
+        }
+        if (lane == 0) red[wave][i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < NA && tid < n_out) out[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __syncthreads();
+}
+
+__device__ __forceinline__ void refine_entry(const RefineArgs &a, int e, int *f, int *det, int *r, int *kd) {
+    const int id = a.list[e];
+    *f = id / a.cap;
+    *det = id - *f * a.cap;
+    *r = a.dets[((long)*f * a.cap + *det) * 2];
+    int k = a.dets[((long)*f * a.cap + *det) * 2 + 1] - a.C / 2;     // FFT bin behind the fftshifted Doppler index
+    if (k < 0) k += a.C;
+    *kd = k;
+}
+
+__global__ __launch_bounds__(256) void k_argmax_refine_part(RefineArgs a) {
+    __shared__ cplx<double> red[4][REFINE_NA];
+    int n = *a.n_flag;
+    if (n > a.list_cap) n = a.list_cap;
+    if (n > a.n_split) n = a.n_split;
+    const int part = blockIdx.x, tid = threadIdx.x;
+    const long plane_cells = (long)a.S * a.C;
+    const long per = ((plane_cells + REFINE_PARTS - 1) / REFINE_PARTS + 255) / 256 * 256;
+    const long lo = (long)part * per, hi = lo + per < plane_cells ? lo + per : plane_cells;
+    for (int e = blockIdx.y; e < n; e += gridDim.y) {
+        int f, det, r, kd;
+        refine_entry(a, e, &f, &det, &r, &kd);
+        for (int a0 = 0; a0 < a.ants.n; a0 += REFINE_NA) {
+            cplx<double> acc[REFINE_NA];
+            refine_accumulate<REFINE_NA>(a, f, r, kd, a0, lo < hi ? lo : hi, hi, tid, acc);
+            refine_reduce<REFINE_NA>(acc, red, tid, a.partial + ((long)e * REFINE_PARTS + part) * a.ants.n + a0, a.ants.n - a0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_argmax_refine_finish(RefineArgs a) {
+    __shared__ cplx<double> X[4][MAX_ANT];
+    int n = *a.n_flag;
+    if (n > a.list_cap) n = a.list_cap;
+    if (n > a.n_split) n = a.n_split;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e0 = blockIdx.x * 4; e0 < n; e0 += gridDim.x * 4) {
+        const int e = e0 + wave;
+        if (e < n) {
+            for (int i = lane; i < a.ants.n; i += 64) {
+                cplx<double> s = cplx<double>{0.0, 0.0};
+                for (int p = 0; p < REFINE_PARTS; ++p) s = s + a.partial[((long)e * REFINE_PARTS + p) * a.ants.n + i];
+                X[wave][i] = s;
+            }
+        }
+        __syncthreads();
+        if (e < n) {
+            int f, det, r, kd;
+            refine_entry(a, e, &f, &det, &r, &kd);
+            const int idx = argmax64_wave(X[wave], a.ants.n, a.A, a.shift, a.twA, lane);
+            if (lane == 0) a.out_idx[(long)f * a.cap + det] = idx;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_argmax_refine_whole(RefineArgs a) {
+    __shared__ cplx<double> red[4][REFINE_NA];
+    __shared__ cplx<double> X[MAX_ANT];
+    int n = *a.n_flag;
+    if (n > a.list_cap) n = a.list_cap;
+    const int tid = threadIdx.x;
+    for (int e = a.n_split + blockIdx.x; e < n; e += gridDim.x) {
+        int f, det, r, kd;
+        refine_entry(a, e, &f, &det, &r, &kd);
+        for (int a0 = 0; a0 < a.ants.n; a0 += REFINE_NA) {
+            cplx<double> acc[REFINE_NA];
+            refine_accumulate<REFINE_NA>(a, f, r, kd, a0, 0, (long)a.S * a.C, tid, acc);
+            refine_reduce<REFINE_NA>(acc, red, tid, X + a0, a.ants.n - a0);
+        }
+        if (tid < 64) {
+            const int idx = argmax64_wave(X, a.ants.n, a.A, a.shift, a.twA, tid);
+            if (tid == 0) a.out_idx[(long)f * a.cap + det] = idx;
         }
         __syncthreads();
     }

@@ -317,15 +317,20 @@ int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, in
 // ------------------------------------------------------------------ FFT chain
 // rv.ntx > 1: d_cubes is the raw [F][num_rx][S][num_tx * C] cube and the virtual-array de-interleave is folded into
 // the load of the single-pass kernels (V == rv.ntx * rv.nrx).
+static int plane_l1_impl(mmw_ctx *ctx, const void *d_cubes, float *d_l1, int n_frames, int V, int S, int C);
+
+// d_l1 != nullptr: also the per-plane L1 norms of the windowed input (mmw_plane_l1), from inside the RD kernel where it
+// can produce them, else by a pass of k_plane_l1.
 static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_mag_f32, int n_frames, int V,
-                             int S, int C, RawView rv = RawView{1, 0}) {
+                             int S, int C, RawView rv = RawView{1, 0}, float *d_l1 = nullptr) {
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0, "bad shape");
     if (n_frames == 0) return MMW_OK;
     {
         ProfScope ps(ctx, "rd");
+        bool l1_done = false;
         if (fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
-            MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
+            MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C, rv, rv.ntx > 1 ? nullptr : d_l1, &l1_done));
         else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
             MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
         else if (rd_mixed_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0))
@@ -339,6 +344,10 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
             MMW_TRY(range_doppler_generic(ctx, d_out, d_out, n_frames, V, S, C));
         } else
             MMW_TRY(range_doppler_generic(ctx, d_cubes, d_out, n_frames, V, S, C));
+        if (d_l1 && !l1_done) {
+            MMW_REQUIRE(rv.ntx <= 1, "plane L1 norms are defined on virtual-array cubes");
+            MMW_TRY(plane_l1_impl(ctx, d_cubes, d_l1, n_frames, V, S, C));
+        }
     }
     if (d_mag_f32) MMW_TRY(abs_c64(ctx, d_out, (float *)d_mag_f32, (size_t)n_frames * V * S * C));
     return MMW_OK;
@@ -1095,13 +1104,13 @@ int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t 
 // stream: running the RD kernel beside the detection kernels on CU-masked queues was measured 2x SLOWER, because the
 // float64 FFT and CFAR kernels are latency/ALU bound and scale with the CUs they get (unlike the angle kernel).
 int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_mag64, uint8_t *d_mask,
-                     int32_t *d_dets, int32_t *d_counts, int n_frames, int V, int S, int C, int cfar_kind,
+                     int32_t *d_dets, int32_t *d_counts, float *d_l1, int n_frames, int V, int S, int C, int cfar_kind,
                      int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap) {
     MMW_REQUIRE(ctx && d_cubes && d_rd && d_mag64 && d_mask && d_dets && d_counts, "null argument");
     MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && n_frames <= 65535 && V > 0 && S > 0 && C > 0 && cap >= 0, "bad shape");
     if (n_frames == 0) return MMW_OK;
-    MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C));
+    MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
     MMW_TRY(range_doppler_mag64_impl(ctx, d_cubes, d_mag64, n_frames, V, S, C, 0));
     MMW_TRY(cfar2d_impl(ctx, d_mag64, nullptr, nullptr, d_mask, n_frames, S, C, cfar_kind, train_r, train_d, guard_r,
                         guard_d, scale, k_rank));
@@ -1143,6 +1152,10 @@ int mmw_plane_l1(mmw_ctx *ctx, const void *d_cubes, float *d_l1, int n_frames, i
     MMW_REQUIRE(ctx && d_cubes && d_l1, "null argument");
     MMW_JOIN(ctx);
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && (long)n_frames * V < (1L << 31), "bad shape");
+    return plane_l1_impl(ctx, d_cubes, d_l1, n_frames, V, S, C);
+}
+
+static int plane_l1_impl(mmw_ctx *ctx, const void *d_cubes, float *d_l1, int n_frames, int V, int S, int C) {
     if (n_frames == 0) return MMW_OK;
     const void *ws, *wc;
     MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &ws));
@@ -1172,7 +1185,11 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &ws64));
     MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &wc64));
     const int list_cap = n_frames * cap;
-    MMW_TRY(ensure_scratch(ctx, 256 + (size_t)list_cap * sizeof(int)));
+    const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));   // flagged detections whose
+                                                                                          // plane sums are split over workgroups
+    const size_t list_bytes = (256 + (size_t)list_cap * sizeof(int) + 255) & ~(size_t)255;
+    const size_t part_bytes = (size_t)n_split * REFINE_PARTS * n_ant * sizeof(cplx<double>);
+    MMW_TRY(ensure_scratch(ctx, list_bytes + part_bytes));
     int *d_nflag = (int *)ctx->scratch, *d_list = (int *)((char *)ctx->scratch + 256);
     MMW_HIP(hipMemsetAsync(d_nflag, 0, 256, ctx->stream));
     // Error-bound constants of k_angle_argmax, in units of eps = 2^-24, for whichever kernel mmw_range_doppler runs on
@@ -1190,17 +1207,49 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
         else
             ulps += (is_pow2(S) ? 0 : S) + (is_pow2(C) ? 0 : C);
     }
-    ArgmaxRefine rf{d_l1, d_nflag, d_list, list_cap, (float)ulps * eps, 4.f * (float)(n_ant + 4) * eps};
+    // The worst-case bound assumes every rounding error of every partial sum lines up; measured float32 errors stay below
+    // 1.2 % of it (tools/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).  The kernel uses
+    // 1/8 of the worst case -- still ~10x above anything observed -- which cuts the float64 re-evaluations (each reads
+    // the antennas' whole planes) from 1.8 % to 0.2 % of the detections; MMW_ARGMAX_BOUND_DIV=1 restores the full bound.
+    const float div = (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 8));
+    ArgmaxRefine rf{d_l1, d_nflag, d_list, list_cap, (float)ulps * eps / div, 4.f * (float)(n_ant + 4) * eps / div};
     ProfScope ps(ctx, "argmax");
     dim3 grid((cap + 3) / 4, n_frames);
     hipLaunchKernelGGL(k_angle_argmax, grid, dim3(256), 0, ctx->stream, (const float2 *)d_rd, d_dets, d_counts, d_idx,
                        V, S, C, cap, ants, A, shift, (const float2 *)twA, rf);
     MMW_TRY(check_launch("angle_argmax"));
-    const int grid2 = (int)std::min<long>(list_cap, 8L * ctx->num_cu);
-    hipLaunchKernelGGL(k_argmax_refine, dim3(grid2), dim3(256), 0, ctx->stream, (const float2 *)d_cubes, d_dets, d_nflag, d_list,
-                       list_cap, d_idx, V, S, C, cap, ants, A, shift, (const double *)ws64, (const double *)wc64,
-                       (const cplx<double> *)twS64, (const cplx<double> *)twC64, (const cplx<double> *)twA64);
-    MMW_TRY(check_launch("argmax_refine"));
+    RefineArgs ra{};
+    ra.cubes = (const float2 *)d_cubes;
+    ra.dets = d_dets;
+    ra.n_flag = d_nflag;
+    ra.list = d_list;
+    ra.list_cap = list_cap;
+    ra.out_idx = d_idx;
+    ra.V = V;
+    ra.S = S;
+    ra.C = C;
+    ra.cap = cap;
+    ra.ants = ants;
+    ra.A = A;
+    ra.shift = shift;
+    ra.ws = (const double *)ws64;
+    ra.wc = (const double *)wc64;
+    ra.twS = (const cplx<double> *)twS64;
+    ra.twC = (const cplx<double> *)twC64;
+    ra.twA = (const cplx<double> *)twA64;
+    ra.partial = (cplx<double> *)((char *)ctx->scratch + list_bytes);
+    ra.n_split = n_split;
+    // grids are fixed (the flagged count stays on the device): workgroups beyond it leave at once
+    if (n_split > 0) {
+        hipLaunchKernelGGL(k_argmax_refine_part, dim3(REFINE_PARTS, std::min(n_split, 4 * ctx->num_cu)), dim3(256), 0, ctx->stream, ra);
+        MMW_TRY(check_launch("argmax_refine_part"));
+        hipLaunchKernelGGL(k_argmax_refine_finish, dim3(std::min((n_split + 3) / 4, 2 * ctx->num_cu)), dim3(256), 0, ctx->stream, ra);
+        MMW_TRY(check_launch("argmax_refine_finish"));
+    }
+    if (list_cap > n_split) {
+        hipLaunchKernelGGL(k_argmax_refine_whole, dim3(2 * ctx->num_cu), dim3(256), 0, ctx->stream, ra);
+        MMW_TRY(check_launch("argmax_refine_whole"));
+    }
     if (h_n_refined) {
         MMW_HIP(hipMemcpyAsync(h_n_refined, d_nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MMW_HIP(hipStreamSynchronize(ctx->stream));

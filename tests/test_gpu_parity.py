@@ -172,6 +172,53 @@ def test_detector_and_point_cloud_vs_oracle(seed):
     np.testing.assert_allclose(pc, pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
 
 
+def test_exact_argmax_refinement_paths(monkeypatch):
+    """mmw_angle_argmax_exact: with the worst-case bound (divisor 1) and with every detection forced through the float64
+    path (a huge bound), through the split-plane kernels and through the whole-plane overflow kernel, the indices are the
+    oracle's; a NaN cell yields the first NaN bin like np.argmax."""
+    from mmwave_radar_processing_amd.batch import FramePipeline
+    cm = make_cm(synth.SYNTH_CFG_256x128x12)
+    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    az, el = list(range(8)), [8, 9, 10, 11]
+    cubes = np.stack([synth.synth_cube(8800 + f) for f in range(3)])
+    refs = [O.point_cloud(c, sc, az, el) for c in cubes]
+    pipe = FramePipeline(cm, max_frames=3, shape=(12, 256, 128), az_antenna_idxs=az, el_antenna_idxs=el)
+    pipe.load(cubes)
+    n_dets = sum(r[1].shape[0] for r in refs)
+    for div, split, expect_all in (("1", None, False), ("8", None, False), ("1", "0", False), ("1", "3", False)):
+        monkeypatch.setenv("MMW_ARGMAX_BOUND_DIV", div)
+        if split is None:
+            monkeypatch.delenv("MMW_REFINE_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("MMW_REFINE_SPLIT", split)
+        pipe.point_clouds()
+        for f, (_, dets_ref, az_i, el_i) in enumerate(refs):
+            np.testing.assert_array_equal(pipe.dets[f], dets_ref)
+            np.testing.assert_array_equal(pipe.az_idx[f], az_i)
+            np.testing.assert_array_equal(pipe.el_idx[f], el_i)
+        print(f"bound divisor {div}, split {split}: {pipe.n_refined} of {2 * n_dets} evaluations refined")
+        assert 0 < pipe.n_refined < n_dets
+    monkeypatch.delenv("MMW_REFINE_SPLIT", raising=False)
+    monkeypatch.delenv("MMW_ARGMAX_BOUND_DIV", raising=False)
+    # float64 cell path: NaN wins and the first one is reported; +inf beats finite values
+    ctx = _lib.default_context()
+    cells = np.zeros((3, 4), dtype=np.complex128)
+    cells[0] = [1, 2, 3, 4]
+    cells[1] = [1, np.nan, 3, 4]
+    cells[2] = [np.inf, 0, 0, 0]
+    d_cells, d_idx = ctx.alloc(cells.nbytes), ctx.alloc(12)
+    d_cells.upload(cells)
+    for shift in (0, 1):
+        _lib.check(ctx.lib.mmw_angle_argmax_cells64(ctx.handle, d_cells.ptr, d_idx.ptr, 3, 4, 16, shift))
+        got = d_idx.download((3,), np.int32)
+        spec = np.abs(np.fft.fft(np.pad(cells, ((0, 0), (0, 12))), axis=1))
+        if shift:
+            spec = np.fft.fftshift(spec, axes=1)
+        np.testing.assert_array_equal(got, np.argmax(spec, axis=1))
+    d_cells.free()
+    d_idx.free()
+
+
 def test_sample_cfg_non_pow2_pipeline(golden):
     """BASELINE config 1 substitute: the shipped 6843 ODS 20 Hz cfg (12,63,70) end to end on the GPU."""
     g = golden("small_chain.npz")
@@ -468,6 +515,45 @@ def test_frame_pipeline_matches_per_frame_processors_and_oracle():
         small = FramePipeline(cm, max_frames=2, shape=(12, 256, 128), det_capacity=4)
         small.load(cubes[:1])
         small.detect()
+
+
+def test_multi_device_pipeline_matches_single_pipeline():
+    """One process, one host thread + context per device.  Runs on however many devices are visible and,
+    to exercise the split / join with a single GPU too, on three contexts of device 0."""
+    from mmwave_radar_processing_amd.batch import FramePipeline, MultiDeviceFramePipeline
+    cm = make_cm(synth.synth_cfg_text(num_samples=64, num_loops=32))
+    shape, F = (12, 64, 32), 11
+    cfar = CaCFAR2D((4, 4), (2, 2), 1e-4)
+    kw = dict(cfar=cfar, az_antenna_idxs=list(range(8)), el_antenna_idxs=[8, 9, 10, 11], det_capacity=512)
+    cubes = np.stack([synth.synth_cube(4000 + f, shape, num_targets=4) for f in range(F)])
+    single = FramePipeline(cm, max_frames=F, shape=shape, **kw)
+    single.load(cubes)
+    pcs_ref = single.point_clouds()
+    dets_ref = single.dets
+    single.chain3d()
+    for devices in (None, [0, 0, 0]):
+        mp = MultiDeviceFramePipeline(cm, max_frames=F, shape=shape, devices=devices, **kw)
+        assert mp.world == (_lib.device_count() if devices is None else 3)
+        mp.load(cubes)
+        pcs = mp.point_clouds()
+        assert len(pcs) == F
+        for f in range(F):
+            np.testing.assert_array_equal(mp.dets[f], dets_ref[f])
+            np.testing.assert_array_equal(pcs[f], pcs_ref[f])
+        out = np.zeros((F, 64) + shape[1:], dtype=np.complex64)
+        mp.chain3d(out=out)
+        for f in (0, F // 2, F - 1):
+            np.testing.assert_array_equal(out[f], single.fetch_chain3d(f))
+            np.testing.assert_array_equal(mp.fetch_chain3d(f), out[f])
+        # device-generated frames: frame f comes from seed0 + f wherever it lands
+        mp.synth(F, seed0=77000)
+        single.synth(F, seed0=77000)
+        np.testing.assert_array_equal(mp.cubes(), single.cubes())
+        a, b = mp.detect(), single.detect()
+        for f in range(F):
+            np.testing.assert_array_equal(a[f], b[f])
+        mp.close()
+        single.load(cubes)
 
 
 def test_overlapped_chain_schedule_full_batch():

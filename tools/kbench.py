@@ -107,11 +107,23 @@ def main():
     run("detect_pipeline_config3", detect_all, F * (2 * cube_b + S * C * 4))
 
     def detect_batch():
-        _lib.check(L.mmw_detect_batch(ctx.handle, d_in.ptr, d_rd.ptr, d_mag.ptr, d_mask.ptr, d_dets.ptr, d_cnt.ptr,
+        _lib.check(L.mmw_detect_batch(ctx.handle, d_in.ptr, d_rd.ptr, d_mag.ptr, d_mask.ptr, d_dets.ptr, d_cnt.ptr, None,
                                       min(F, 32768), V, S, C, 0, 4, 4, 2, 2, alpha, 0, cap))
         _lib.check(L.mmw_angle_argmax(ctx.handle, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, min(F, 65535), V, S, C, cap,
                                       ants, n_ant, A, 1))
     run("detect_batch_config3", detect_batch, F * (2 * cube_b + S * C * 4))
+    d_l1 = ctx.alloc(F * V * 4)
+
+    def detect_batch_exact():       # the product path of FramePipeline.point_clouds: exact azimuth argmax
+        _lib.check(L.mmw_detect_batch(ctx.handle, d_in.ptr, d_rd.ptr, d_mag.ptr, d_mask.ptr, d_dets.ptr, d_cnt.ptr, d_l1.ptr,
+                                      min(F, 32768), V, S, C, 0, 4, 4, 2, 2, alpha, 0, cap))
+        _lib.check(L.mmw_angle_argmax_exact(ctx.handle, d_in.ptr, d_l1.ptr, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr,
+                                            min(F, 32768), V, S, C, cap, ants, n_ant, A, 1, None))
+    run("detect_batch_config3_exact_argmax", detect_batch_exact, F * (2 * cube_b + S * C * 4))
+    run("plane_l1", lambda: _lib.check(L.mmw_plane_l1(ctx.handle, d_in.ptr, d_l1.ptr, F, V, S, C)), F * cube_b)
+    run("angle_argmax_exact_az8", lambda: _lib.check(L.mmw_angle_argmax_exact(
+        ctx.handle, d_in.ptr, d_l1.ptr, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, min(F, 32768), V, S, C, cap, ants, n_ant,
+        A, 1, None)), F * 76 * n_ant * 8)
     res["mean_detections_per_frame"] = float(d_cnt.download((F,), np.int32).mean())
     # ---- Doppler-azimuth: coarse (3-D chain + range mean) and precise (zoom transform, 2 x 128 bins) modes
     Fz = min(F, 256)
