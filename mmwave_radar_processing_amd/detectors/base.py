@@ -12,6 +12,7 @@ from __future__ import annotations
 from typing import List, Optional, Tuple
 
 import numpy as np
+from numpy.lib.stride_tricks import sliding_window_view
 
 from .. import _lib
 
@@ -90,9 +91,20 @@ class BaseCFAR1D(_DeviceCFAR):
         x = np.asarray(x)
         if x.ndim != 1:
             raise ValueError("Input x must be a 1D array.")
+        # _compute_thresholds is the hook subclasses override (reference base.py:56-65); the decision rule is applied
+        # here exactly as the reference does (strict >; +inf / NaN thresholds never fire), so a user subclass written
+        # against the reference -- its own NumPy _compute_thresholds -- keeps working unchanged
         self.thresholds, self.noise_estimates = self._compute_thresholds(x)
-        self.detections = self._mask[0]
+        self.detections = x > self.thresholds
         return np.where(self.detections)[0].tolist()
+
+    def _get_window_view(self, x: np.ndarray) -> np.ndarray:
+        """Sliding windows of 2 * (num_train + num_guard) + 1 cells (reference base.py:129-152): a helper for subclasses
+        that compute their own thresholds on the host; ValueError when the input is shorter than the window."""
+        window_size = 2 * (self.num_train + self.num_guard) + 1
+        if len(x) < window_size:
+            raise ValueError(f"Input length {len(x)} is smaller than window size {window_size}.")
+        return sliding_window_view(x, window_shape=window_size)
 
     def plot_detections(self, x, title="CFAR Detection", convert_to_dB=False):  # pragma: no cover
         raise NotImplementedError("plotting is outside the accelerated hot path (SURVEY.md section 2)")
@@ -143,10 +155,18 @@ class BaseCFAR2D(_DeviceCFAR):
         X = np.asarray(X)
         if X.ndim != 2:
             raise ValueError("Input X must be a 2D array.")
-        self.thresholds, self.noise_estimates = self._compute_thresholds(X)
-        self.detections = self._mask
+        self.thresholds, self.noise_estimates = self._compute_thresholds(X)      # the subclass hook (reference :222-226)
+        self.detections = X > self.thresholds
         rows, cols = np.where(self.detections)
         return list(zip(rows, cols))
+
+    def _get_window_view(self, X: np.ndarray) -> np.ndarray:
+        """2-D sliding windows (reference base.py:308-327), for subclasses with their own host-side thresholds."""
+        win_r = 2 * (self.num_train[0] + self.num_guard[0]) + 1
+        win_d = 2 * (self.num_train[1] + self.num_guard[1]) + 1
+        if X.shape[0] < win_r or X.shape[1] < win_d:
+            raise ValueError(f"Input shape {X.shape} is smaller than window size {(win_r, win_d)}.")
+        return sliding_window_view(X, window_shape=(win_r, win_d))
 
     def plot_detections(self, X, title="2D CFAR Detection"):  # pragma: no cover
         raise NotImplementedError("plotting is outside the accelerated hot path (SURVEY.md section 2)")

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import GOLDEN, ROOT
 from mmwave_radar_processing_amd import _lib, synth
 from mmwave_radar_processing_amd.config_managers import ConfigManager
 
@@ -156,3 +156,67 @@ def test_register_fft_network_host_build(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "test_regfft.cpp"), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert "N=64" in out
+
+
+def test_package_config_manager_on_every_shipped_cfg():
+    """The package's ConfigManager (the class a user of the reference instantiates) against the scalars the reference's own
+    ConfigManager produced for all 26 cfg files (tests/golden/cfg_scalars.json, written by make_golden.py): exact float64."""
+    import json
+    with open(os.path.join(GOLDEN, "cfg_scalars.json")) as f:
+        table = json.load(f)
+    assert len(table) == 26
+    attr = {"num_rx": "num_rx_antennas", "num_tx": "num_tx_antennas", "loops": "frameCfg_loops",
+            "frame_start": "frameCfg_start_index", "frame_end": "frameCfg_end_index", "range_res_m": "range_res_m",
+            "range_max_m": "range_max_m", "range_bin_size_m": "range_bin_size_m", "vel_res_m_s": "vel_res_m_s",
+            "vel_max_m_s": "vel_max_m_s", "virtual_antennas_enabled": "virtual_antennas_enabled"}
+    for name, ent in table.items():
+        cm = ConfigManager()
+        cm.load_cfg_text("\n".join(ent["lines"]) + "\n")
+        for k, v in ent["expect"].items():
+            got = cm.get_num_adc_samples() if k == "num_samples" else getattr(cm, attr[k])
+            assert got == v and isinstance(got, (bool, int, float)) == isinstance(v, (bool, int, float)), (name, k, got, v)
+
+
+def test_cfar_subclass_with_its_own_numpy_thresholds():
+    """A detector written against the reference's base classes overrides _compute_thresholds (the abstract hook,
+    reference detectors/base.py:121-127,295-306) and may call _get_window_view; detect() then applies X > thresholds.
+    Such a subclass never touches the device, so this runs on the CPU."""
+    from mmwave_radar_processing_amd.detectors.base import BaseCFAR1D, BaseCFAR2D
+
+    class Median1D(BaseCFAR1D):
+        def _compute_thresholds(self, x):
+            half = self.num_train + self.num_guard
+            thr = np.full(len(x), np.inf)
+            noise = np.zeros(len(x))
+            if len(x) < 2 * half + 1:
+                return thr, noise
+            win = self._get_window_view(x)
+            noise[half:len(x) - half] = np.median(win, axis=1)
+            thr[half:len(x) - half] = 3.0 * noise[half:len(x) - half]
+            return thr, noise
+
+    class Mean2D(BaseCFAR2D):
+        def _compute_thresholds(self, X):
+            hr, hd = (t + g for t, g in zip(self.num_train, self.num_guard))
+            thr = np.full(X.shape, np.inf)
+            win = self._get_window_view(X)
+            thr[hr:X.shape[0] - hr, hd:X.shape[1] - hd] = 8.0 * win.mean(axis=(2, 3))
+            return thr, np.zeros(X.shape)
+
+    rng = np.random.default_rng(1)
+    x = rng.exponential(1.0, 80)
+    x[40] = 25.0
+    det = Median1D(6, 2, 1e-3)
+    assert det.detect(x) == np.where(x > det.thresholds)[0].tolist() and 40 in det.detect(x)
+    assert det.detections.dtype == bool and det.noise_estimates.shape == x.shape
+    assert det.detect(x[:10]) == []                         # shorter than the window: all-inf thresholds, no error here
+    with pytest.raises(ValueError):
+        det._get_window_view(x[:10])
+    with pytest.raises(ValueError):
+        det.detect(x[None, :])
+    X = rng.exponential(1.0, (30, 20))
+    X[15, 10] = 40.0
+    d2 = Mean2D((3, 3), (1, 1), 1e-3)
+    assert d2.detect(X) == [(15, 10)]
+    with pytest.raises(ValueError):
+        d2._get_window_view(X[:5])
