@@ -248,7 +248,7 @@ def main():
                     help="record a HIP event pair around every n-th launch of each kernel inside the timed region; 0 = "
                          "auto: every launch when a step is one launch per stage, else every 7th (coprime with the "
                          "launches per step, so a short tail chunk is sampled in proportion)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

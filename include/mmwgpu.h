@@ -224,17 +224,20 @@ int mmw_angle_argmax_cells64(mmw_ctx *ctx, const void *d_cells, int32_t *d_idx, 
                              int shift);
 
 /* ---------------------------------------------------------------- beamformers
- * mmw_bartlett: delay-and-sum steering-matrix contraction on MFMA,
- *   Y[s][t] = FFT_S( hann(S) * sum_e X[s][e] hamming(E)[e] exp(j 2 pi d_t . p_e / lambda) )
- *   d_X [S][E] c64, d_P [3][E] float64, d_dirs [3][T] float64, d_out [S][T] c64.
+ * mmw_bartlett: delay-and-sum steering-matrix contraction on MFMA for a batch of frames,
+ *   Y[f][s][t] = FFT_S( hann(S) * sum_e X[f][s][e] hamming(E)[e] exp(j 2 pi d_t . p_{f,e} / lambda) )
+ *   d_X [F][S][E] c64, d_P [F][3][E] float64 (each frame's array geometry), d_dirs [3][T] float64,
+ *   d_out [F][S][T] c64.
  *   replaces compute_synthetic_response / compute_response_at_steering_angle
- *   (processors/simple_synthetic_array_beamformer_processor_multiFrame.py:499-585).
- * mmw_capon: MVDR spectrum on a V-element half-wavelength ULA; NO upstream implementation exists
- *    -- definition in DESIGN.md; d_X [V][R][K] c64, d_out [R][T] float32. */
+ *   (processors/simple_synthetic_array_beamformer_processor_multiFrame.py:499-585), whose Python loop over steering
+ *   angles (:543-585) becomes one complex GEMM per frame.
+ * mmw_capon: MVDR spectrum on a V-element half-wavelength ULA for a batch of frames; NO upstream implementation
+ *   exists -- definition in DESIGN.md; d_X [F][V][R][K] c64 (K snapshots per range bin),
+ *   d_out [F][R][T] float32. */
 int mmw_bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs,
-                 void *d_out, int S, int E, int T, double lambda_m);
+                 void *d_out, int n_frames, int S, int E, int T, double lambda_m);
 int mmw_capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out,
-              int V, int R, int K, int T, double delta);
+              int n_frames, int V, int R, int K, int T, double delta);
 
 /* ---------------------------------------------------------------- element-wise helpers */
 int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n);
@@ -244,6 +247,10 @@ int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n);
  * grid-stride over `blocks` workgroups of 256 (0 = 8 per CU).  Used by tools/kbench.py to state what
  * a known-good streaming kernel reaches next to the hot-path kernels. */
 int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks);
+/* Matrix-core peak of this device, measured: back-to-back MFMAs on independent accumulators with register operands,
+ * two waves per SIMD.  kind 0 = v_mfma_f32_32x32x2_f32 (the Bartlett GEMM's instruction), 1 = v_mfma_f64_16x16x4_f64
+ * (the Capon covariance).  The figure the beamformer kernels' TFLOP/s are divided by in tools/kbench.py. */
+int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops);
 /* Which range-Doppler kernel mmw_range_doppler picks for an S x C plane, without touching a device (host logic
  * only): plan[0] = 0 fused 256x128 | 1 LDS-resident power of two | 2 mixed radix | 3 generic two-kernel path;
  * for the mixed-radix kernel plan[1..7] = register class, has a run-time-radix level, S1, S2, C1, C2 (S = S1 S2,

@@ -70,10 +70,11 @@ _SIGNATURES = {
     "mmw_plane_l1": [_vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_angle_argmax_exact": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip],
     "mmw_angle_argmax_cells64": [_vp, _vp, _vp, _i, _i, _i, _i],
-    "mmw_bartlett": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d],
-    "mmw_capon": [_vp, _vp, C.POINTER(_d), _vp, _i, _i, _i, _i, _d],
+    "mmw_bartlett": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d],
+    "mmw_capon": [_vp, _vp, C.POINTER(_d), _vp, _i, _i, _i, _i, _i, _d],
     "mmw_abs_c64": [_vp, _vp, _vp, _sz],
     "mmw_diag_membw": [_vp, _vp, _vp, _sz, _i, _i],
+    "mmw_diag_mfma_peak": [_vp, _i, C.POINTER(_d)],
     "mmw_diag_rd_plan": [_i, _i, _i, _ip],
     "mmw_diag_chain_plan": [_vp, _i, _i, _i, _i, _i, _i, _ip],
     "mmw_profile_enable": [_vp, _i],

@@ -18,78 +18,114 @@ namespace mmw {
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// W[e][t] (complex64, row-major [E][Tp]); phase reduced mod 1 turn in float64 before the sincos.
+// W[f][e][t] (complex64, row-major [E][Tp] per frame); phase reduced mod 1 turn in float64 before the sincos.
+// P [F][3][E] element positions of each frame's (synthetic) array, dirs [3][T] steering directions.
 __global__ __launch_bounds__(256) void k_steer(cplx<float> *W, const double *P, const double *dirs,
                                                 const float *hamming, int E, int T, int Tp, double inv_lambda) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)E * Tp) return;
     const int t = (int)(gid % Tp), e = (int)(gid / Tp);
+    const double *Pf = P + (long)blockIdx.y * 3 * E;
     cplx<float> w = cplx<float>{0.f, 0.f};
     if (t < T) {
-        double turns = (dirs[t] * P[e] + dirs[T + t] * P[E + e] + dirs[2 * T + t] * P[2 * E + e]) * inv_lambda;
+        double turns = (dirs[t] * Pf[e] + dirs[T + t] * Pf[E + e] + dirs[2 * T + t] * Pf[2 * E + e]) * inv_lambda;
         turns -= rint(turns);
         double sn, cs;
         sincospi(2.0 * turns, &sn, &cs);
         w = cplx<float>{(float)(cs * hamming[e]), (float)(sn * hamming[e])};
     }
-    W[gid] = w;
+    W[(long)blockIdx.y * E * Tp + gid] = w;
 }
 
-// C[M][N] = A[M][K] x B[K][N], complex64, row-major, leading dimensions lda / ldb / ldc (elements).
-// Workgroup = 4 waves = 64x64 tile (2x2 waves of 32x32); K advanced 16 at a time through LDS.
-constexpr int CG_TM = 64, CG_TN = 64, CG_TK = 16;
+// C[b][M][N] = A[b][M][K] x B[b][K][N], complex64, row-major, leading dimensions lda / ldb / ldc and batch strides
+// sa / sb / sc (elements); blockIdx.z = b.
+// Workgroup = 4 waves = 128 x 64 tile, each wave 64 x 32 (two 32 x 32 MFMA blocks, real and imaginary accumulators);
+// K advances 16 at a time through a DOUBLE-BUFFERED planar LDS tile: the global loads of step k + 1 are issued before
+// the MFMAs of step k and land in the other buffer afterwards -- one barrier per step.  v_mfma_f32_32x32x2_f32 is
+// exact float32 (an fmaf chain in k order), so the 1e-5 spectrum tolerance holds; 4 real MFMAs per complex k pair.
+constexpr int CG_TM = 128, CG_TN = 64, CG_TK = 16, CG_PA = CG_TM + 1, CG_PB = CG_TN + 1;
+constexpr int CG_LDS_FLOATS = 2 * CG_TK * CG_PA + 2 * CG_TK * CG_PB;       // one buffer: Ar, Ai, Br, Bi
 __global__ __launch_bounds__(256) void k_cgemm_mfma(const cplx<float> *__restrict__ A, const cplx<float> *__restrict__ B,
                                                      cplx<float> *__restrict__ Cm, int M, int N, int K, int lda,
-                                                     int ldb, int ldc) {
-    // planar tiles so each MFMA operand is one conflict-free 4-byte LDS read
-    __shared__ float sAr[CG_TK][CG_TM + 1], sAi[CG_TK][CG_TM + 1];
-    __shared__ float sBr[CG_TK][CG_TN + 1], sBi[CG_TK][CG_TN + 1];
+                                                     int ldb, int ldc, long sa, long sb, long sc) {
+    __shared__ float lds[2 * CG_LDS_FLOATS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    A += (long)blockIdx.z * sa;
+    B += (long)blockIdx.z * sb;
+    Cm += (long)blockIdx.z * sc;
     const int m0 = blockIdx.y * CG_TM, n0 = blockIdx.x * CG_TN;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    v16f acc_r = {0}, acc_i = {0};
-    for (int k0 = 0; k0 < K; k0 += CG_TK) {
-        // A tile: 64 rows x 16 k (1024 elements, 4 per thread), lanes along k for 128-B row segments
-        for (int q = t; q < CG_TM * CG_TK; q += 256) {
-            const int kk = q % CG_TK, mm = q / CG_TK;
-            const int gm = m0 + mm, gk = k0 + kk;
-            const cplx<float> v = (gm < M && gk < K) ? A[(long)gm * lda + gk] : cplx<float>{0.f, 0.f};
-            sAr[kk][mm] = v.x;
-            sAi[kk][mm] = v.y;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
+    // global -> register staging: A rows (thread = row, 8 consecutive k), B rows (thread = k, 4 consecutive n)
+    const int a_row = t >> 1, a_k = (t & 1) * 8, b_k = t >> 4, b_n = (t & 15) * 4;
+    cplx<float> ra[8], rb[4];
+    auto fetch = [&](int k0) {
+        const int gm = m0 + a_row;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gk = k0 + a_k + j;
+            ra[j] = (gm < M && gk < K) ? A[(long)gm * lda + gk] : cplx<float>{0.f, 0.f};
         }
-        for (int q = t; q < CG_TK * CG_TN; q += 256) {
-            const int nn = q % CG_TN, kk = q / CG_TN;
-            const int gn = n0 + nn, gk = k0 + kk;
-            const cplx<float> v = (gn < N && gk < K) ? B[(long)gk * ldb + gn] : cplx<float>{0.f, 0.f};
-            sBr[kk][nn] = v.x;
-            sBi[kk][nn] = v.y;
+        const int gk = k0 + b_k;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + b_n + j;
+            rb[j] = (gk < K && gn < N) ? B[(long)gk * ldb + gn] : cplx<float>{0.f, 0.f};
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+        float *Ar = lds + buf * CG_LDS_FLOATS, *Ai = Ar + CG_TK * CG_PA, *Br = Ai + CG_TK * CG_PA, *Bi = Br + CG_TK * CG_PB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            Ar[(a_k + j) * CG_PA + a_row] = ra[j].x;
+            Ai[(a_k + j) * CG_PA + a_row] = ra[j].y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Br[b_k * CG_PB + b_n + j] = rb[j].x;
+            Bi[b_k * CG_PB + b_n + j] = rb[j].y;
+        }
+    };
+    v16f acc_r[2] = {{0}, {0}}, acc_i[2] = {{0}, {0}};
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += CG_TK, buf ^= 1) {
+        const bool more = k0 + CG_TK < K;
+        if (more) fetch(k0 + CG_TK);                    // in flight while this step's MFMAs run
+        const float *Ar = lds + buf * CG_LDS_FLOATS, *Ai = Ar + CG_TK * CG_PA, *Br = Ai + CG_TK * CG_PA, *Bi = Br + CG_TK * CG_PB;
 #pragma unroll
         for (int ks = 0; ks < CG_TK; ks += 2) {
             // 32x32x2 operand maps: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
             const int kk = ks + (lane >> 5), ij = lane & 31;
-            const float ar = sAr[kk][wm + ij], ai = sAi[kk][wm + ij];
-            const float br = sBr[kk][wn + ij], bi = sBi[kk][wn + ij];
-            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, acc_r, 0, 0, 0);
-            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai, bi, acc_r, 0, 0, 0);
-            acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, acc_i, 0, 0, 0);
-            acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, acc_i, 0, 0, 0);
+            const float br = Br[kk * CG_PB + wn + ij], bi = Bi[kk * CG_PB + wn + ij];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const float ar = Ar[kk * CG_PA + wm + 32 * mb + ij], ai = Ai[kk * CG_PA + wm + 32 * mb + ij];
+                acc_r[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, acc_r[mb], 0, 0, 0);
+                acc_r[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai, bi, acc_r[mb], 0, 0, 0);
+                acc_i[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, acc_i[mb], 0, 0, 0);
+                acc_i[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, acc_i[mb], 0, 0, 0);
+            }
         }
+        if (more) stash(buf ^ 1);                       // the other buffer: nobody reads it during this step
         __syncthreads();
     }
     // C/D map of the 32x32 shapes: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = n0 + wn + (lane & 31);
-        if (row < M && col < N) Cm[(long)row * ldc + col] = cplx<float>{acc_r[r], acc_i[r]};
-    }
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = n0 + wn + (lane & 31);
+            if (row < M && col < N) Cm[(long)row * ldc + col] = cplx<float>{acc_r[mb][r], acc_i[mb][r]};
+        }
 }
 
-inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int S,
+// d_X [F][S][E] c64, d_P [F][3][E] f64, d_dirs [3][T] f64 -> d_out [F][S][T] c64
+inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int n_frames, int S,
                     int E, int T, double lambda_m) {
     const int Tp = (T + 3) & ~3;
-    const size_t w_bytes = (size_t)E * Tp * sizeof(cplx<float>), c_bytes = (size_t)S * T * sizeof(cplx<float>);
+    const size_t w_bytes = (size_t)n_frames * E * Tp * sizeof(cplx<float>), c_bytes = (size_t)n_frames * S * T * sizeof(cplx<float>);
     MMW_TRY(ensure_scratch(ctx, w_bytes + c_bytes));
     cplx<float> *W = (cplx<float> *)ctx->scratch;
     cplx<float> *Cm = (cplx<float> *)((char *)ctx->scratch + w_bytes);
@@ -98,19 +134,24 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
     MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &hann));
     ProfScope ps(ctx, "bartlett");
     const long nW = (long)E * Tp;
-    hipLaunchKernelGGL(k_steer, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, ctx->stream, W, d_P, d_dirs,
+    hipLaunchKernelGGL(k_steer, dim3((unsigned)((nW + 255) / 256), (unsigned)n_frames), dim3(256), 0, ctx->stream, W, d_P, d_dirs,
                        (const float *)ham, E, T, Tp, 1.0 / lambda_m);
     MMW_TRY(check_launch("steer"));
-    dim3 grid((T + CG_TN - 1) / CG_TN, (S + CG_TM - 1) / CG_TM);
-    hipLaunchKernelGGL(k_cgemm_mfma, grid, dim3(256), 0, ctx->stream, (const cplx<float> *)d_X, W, Cm, S, T, E, E, Tp, T);
-    MMW_TRY(check_launch("cgemm_mfma"));
-    // hann(S) window and FFT along S for every steering column (:537-540)
+    {
+        ProfScope pg(ctx, "cgemm");
+        dim3 grid((T + CG_TN - 1) / CG_TN, (S + CG_TM - 1) / CG_TM, (unsigned)n_frames);
+        hipLaunchKernelGGL(k_cgemm_mfma, grid, dim3(256), 0, ctx->stream, (const cplx<float> *)d_X, W, Cm, S, T, E, E, Tp, T,
+                           (long)S * E, (long)E * Tp, (long)S * T);
+        MMW_TRY(check_launch("cgemm_mfma"));
+    }
+    // hann(S) window and FFT along S for every steering column of every frame (:537-540)
     FftArgs a{};
     a.in = Cm;
     a.out = d_out;
-    a.outer = 1;
+    a.outer = n_frames;
     a.inner = T;
     a.n_in = S;
+    a.in_outer_stride = a.out_outer_stride = (long)S * T;
     a.in_axis_stride = a.out_axis_stride = T;
     a.in_inner_stride = a.out_inner_stride = 1;
     a.win_axis = hann;
@@ -118,123 +159,174 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
     return launch_fft_axis<float, float>(ctx, a, S, false);
 }
 
-// ------------------------------------------------------------------ Capon / MVDR (float64)
-// One wave per range bin.  X [V][R][K] complex64, steering table Ast [16][Tp] complex128 (rows >= V zero),
-// out [R][T] float32:  P = 1 / Re( a^H (Rxx + delta tr(Rxx)/V I)^-1 a ),  Rxx = X_r X_r^H / K.
-__global__ __launch_bounds__(64) void k_capon(const cplx<float> *__restrict__ X, const cplx<double> *__restrict__ Ast,
-                                               float *__restrict__ out, int V, int R, int K, int T, int Tp,
-                                               double delta) {
-    __shared__ cplx<double> Mx[16][17], Li[16][17], Ri[16][17];
-    const int l = threadIdx.x, r = blockIdx.x;
-    const int li = l & 15, lk = l >> 4;
-    // ---- covariance on the f64 matrix cores: operand maps A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]
-    v4d cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + lk;
-        double xr = 0.0, xi = 0.0;
-        if (li < V && k < K) {
-            const cplx<float> x = X[((long)li * R + r) * K + k];
-            xr = x.x;
-            xi = x.y;
+// ------------------------------------------------------------------ matrix-core peak probe (diagnostics)
+// Back-to-back MFMAs on four independent accumulators per wave, operands in registers: the rate the matrix pipe itself
+// sustains on this device, used as the `peak` the beamformer kernels are priced against (the guide lists 157.3 TF for
+// f32 MFMA and no figure for f64).  kind 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f64_16x16x4_f64.
+__global__ __launch_bounds__(256) void k_diag_mfma(float *sink, int iters, int kind) {
+    const float seed = (float)(threadIdx.x & 7) * 0.25f + 0.5f;
+    if (kind == 0) {
+        v16f a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+        for (int i = 0; i < iters; ++i) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 1.0f, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 0.5f, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 0.25f, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 0.125f, a3, 0, 0, 0);
         }
-        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, cr, 0, 0, 0);
-        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, cr, 0, 0, 0);
-        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xr, ci, 0, 0, 0);
-        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr, xi, ci, 0, 0, 0);
-    }
-    // f64 C/D map: col = lane&15, row = (lane>>4) + 4*reg
-    const double invK = 1.0 / (double)K;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Mx[lk + 4 * q][li] = cplx<double>{cr[q] * invK, ci[q] * invK};
-    __syncthreads();
-    if (l == 0) {
-        double tr = 0.0;
-        for (int i = 0; i < V; ++i) tr += Mx[i][i].x;
-        const double load = delta * tr / (double)V;
-        for (int i = 0; i < 16; ++i) Mx[i][i] = cplx<double>{i < V ? Mx[i][i].x + load : 1.0, 0.0};
-    }
-    __syncthreads();
-    // ---- Cholesky Mx = L L^H (lower triangle in place)
-    for (int j = 0; j < 16; ++j) {
-        const double d = sqrt(Mx[j][j].x);
-        __syncthreads();
-        if (l == j) Mx[j][j] = cplx<double>{d, 0.0};
-        if (l > j && l < 16) Mx[l][j] = Mx[l][j] * (1.0 / d);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = l + 64 * q, i = idx >> 4, c = idx & 15;
-            if (c > j && c <= i) {
-                const cplx<double> a = Mx[i][j], b = Mx[c][j];
-                Mx[i][c] = Mx[i][c] - cplx<double>{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};   // a * conj(b)
-            }
+        const float v = a0[0] + a1[1] + a2[2] + a3[3];
+        if (v == 12345.678f) sink[0] = v;
+    } else {
+        v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+        const double sd = seed;
+        for (int i = 0; i < iters; ++i) {
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sd, 1.0, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sd, 0.5, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(sd, 0.25, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(sd, 0.125, a3, 0, 0, 0);
         }
-        __syncthreads();
-    }
-    // ---- Li = L^-1 by forward substitution, one column per lane
-    if (l < 16) {
-        for (int i = 0; i < 16; ++i) {
-            cplx<double> s = cplx<double>{i == l ? 1.0 : 0.0, 0.0};
-            for (int k = l; k < i; ++k) s = s - cmul(Mx[i][k], Li[k][l]);
-            Li[i][l] = (i < l) ? cplx<double>{0.0, 0.0} : s * (1.0 / Mx[i][i].x);
-        }
-    }
-    __syncthreads();
-    // ---- Ri = Li^H Li
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = l + 64 * q, i = idx >> 4, j = idx & 15;
-        cplx<double> s = cplx<double>{0.0, 0.0};
-        for (int k = (i > j ? i : j); k < 16; ++k) {
-            const cplx<double> a = Li[k][i], b = Li[k][j];
-            s = s + cplx<double>{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};                      // conj(a) * b
-        }
-        Ri[i][j] = s;
-    }
-    __syncthreads();
-    // ---- Z = Ri x A(theta) on the matrix cores, 16 angles per pass; P = 1 / Re(sum_v conj(a_v) Z_v)
-    for (int t0 = 0; t0 < T; t0 += 16) {
-        v4d zr = {0, 0, 0, 0}, zi = {0, 0, 0, 0};
-#pragma unroll
-        for (int k0 = 0; k0 < 16; k0 += 4) {
-            const cplx<double> a = Ri[li][k0 + lk];
-            const int tc = t0 + li;
-            const cplx<double> b = tc < Tp ? Ast[(long)(k0 + lk) * Tp + tc] : cplx<double>{0.0, 0.0};
-            zr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, zr, 0, 0, 0);
-            zr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, zr, 0, 0, 0);
-            zi = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, zi, 0, 0, 0);
-            zi = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, zi, 0, 0, 0);
-        }
-        double acc = 0.0;
-        const int tc = t0 + li;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = lk + 4 * q;
-            const cplx<double> a = tc < Tp ? Ast[(long)row * Tp + tc] : cplx<double>{0.0, 0.0};
-            acc += a.x * zr[q] + a.y * zi[q];
-        }
-        acc += __shfl_xor(acc, 16, 64);
-        acc += __shfl_xor(acc, 32, 64);
-        if (l < 16 && tc < T) out[(long)r * T + tc] = (float)(1.0 / acc);
+        const double v = a0[0] + a1[1] + a2[2] + a3[3];
+        if (v == 12345.678) sink[0] = (float)v;
     }
 }
 
-inline int capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out, int V, int R, int K, int T,
-                 double delta) {
-    const int Tp = (T + 15) & ~15;
-    std::vector<double> ast((size_t)16 * Tp * 2, 0.0);
+// ------------------------------------------------------------------ Capon / MVDR (float64)
+// X [F][V][R][K] complex64 (K snapshots per range bin), steering table Ast [V][T] complex128, out [F][R][T] float32:
+//   P = 1 / Re( a^H (Rxx + delta tr(Rxx)/V I)^-1 a ),  Rxx = X_r X_r^H / K,  a_v = exp(-j pi v sin(theta)).
+// One WAVE per (frame, range bin), four waves per workgroup walking the bins of a batch (the single-frame kernel of
+// round 1 -- one 64-thread workgroup per bin, serial Cholesky / inverse on one to sixteen lanes, a workgroup barrier
+// per step -- was latency bound at 160 ns per bin).  Per bin:
+//   1. the V snapshot rows (K x 8 B, contiguous) arrive by coalesced 16-B loads into a wave-private LDS tile
+//      (pitch KT + 2: the MFMA operand reads that follow are bank-conflict free);
+//   2. Rxx on v_mfma_f64_16x16x4_f64: 4 real MFMAs per 4 snapshots (Re = xr xr^T + xi xi^T, Im = xi xr^T - xr xi^T);
+//   3. trace + diagonal loading by a 16-lane shuffle sum; right-looking Cholesky Rxx = L L^H in LDS with all 64 lanes on
+//      the trailing update, V steps, wave-synchronous (no workgroup barriers: each wave owns its matrix);
+//   4. a^H Rxx^-1 a = |L^-1 a|^2: every lane forward-substitutes L y = a for its steering angles with L broadcast from
+//      LDS -- V (V + 1) / 2 complex MACs per angle instead of the 16 x 16 of an explicit inverse and a second GEMM.
+constexpr int CAPON_KT = 64;                        // snapshots staged per pass
+constexpr int CAPON_XP = CAPON_KT + 2;              // LDS row pitch of the snapshot tile (complex64 elements)
+constexpr int CAPON_WAVE_LDS = 16 * CAPON_XP * 8 + 16 * 17 * 16 + 16 * 8;   // tile + matrix + 1 / diag
+
+// LDS traffic inside one wave needs no hardware barrier (DS instructions of a wave execute in order); the compiler
+// must not move accesses across the hand-over
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void k_capon_batch(const cplx<float> *__restrict__ X, const cplx<double> *__restrict__ Ast,
+                                                      float *__restrict__ out, int V, int R, int K, int T, long n_bins,
+                                                      double delta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    char *base = smem + (size_t)w * CAPON_WAVE_LDS;
+    cplx<float> *Xs = reinterpret_cast<cplx<float> *>(base);                              // [16][CAPON_XP]
+    cplx<double>(*Mx)[17] = reinterpret_cast<cplx<double>(*)[17]>(base + 16 * CAPON_XP * 8);
+    double *inv_d = reinterpret_cast<double *>(base + 16 * CAPON_XP * 8 + 16 * 17 * 16);
+    const int li = l & 15, lk = l >> 4;
+    // rows >= V of the tile stay zero
+    for (int e = l; e < 16 * CAPON_XP; e += 64) Xs[e] = cplx<float>{0.f, 0.f};
+    wave_lds_sync();
+    for (long bin = (long)blockIdx.x * 4 + w; bin < n_bins; bin += (long)gridDim.x * 4) {
+        const long f = bin / R;
+        const int r = (int)(bin - f * R);
+        const cplx<float> *xb = X + ((f * V) * R + r) * (long)K;        // antenna v at xb + v * R * K
+        // ---- 1 + 2: covariance
+        v4d cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += CAPON_KT) {
+            // half a wave per antenna row: lane h = l & 31 brings snapshots k0 + 2h, 2h + 1
+            for (int v = l >> 5; v < V; v += 2) {
+                const int k = k0 + 2 * (l & 31);
+                const cplx<float> *src = xb + (long)v * R * K + k;
+                f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                if (k + 1 < K && ((K & 1) == 0)) q = *reinterpret_cast<const f32x4 *>(src);     // 16-B aligned when K is even
+                else {
+                    if (k < K) { q.x = src[0].x; q.y = src[0].y; }
+                    if (k + 1 < K) { q.z = src[1].x; q.w = src[1].y; }
+                }
+                *reinterpret_cast<f32x4 *>(&Xs[v * CAPON_XP + 2 * (l & 31)]) = q;
+            }
+            wave_lds_sync();
+#pragma unroll 4
+            for (int kk = 0; kk < CAPON_KT; kk += 4) {
+                const cplx<float> x = Xs[li * CAPON_XP + kk + lk];       // operand maps: A[i = l&15][k = l>>4], B[k][j = l&15]
+                const double xr = x.x, xi = x.y;
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, cr, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xr, ci, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr, xi, ci, 0, 0, 0);
+            }
+            wave_lds_sync();
+        }
+        // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+        const double invK = 1.0 / (double)K;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Mx[lk + 4 * q][li] = cplx<double>{cr[q] * invK, ci[q] * invK};
+        wave_lds_sync();
+        // ---- 3: diagonal loading, Cholesky (lower triangle of Mx becomes L, diagonal real)
+        double tr = (l < V) ? Mx[l][l].x : 0.0;
+        for (int d = 8; d >= 1; d >>= 1) tr += __shfl_xor(tr, d, 64);      // lanes 0..15 hold the 16 diagonal terms
+        tr = __shfl(tr, 0, 64);
+        if (l < V) Mx[l][l] = cplx<double>{Mx[l][l].x + delta * tr / (double)V, 0.0};
+        wave_lds_sync();
+        for (int j = 0; j < V; ++j) {
+            const double d = sqrt(Mx[j][j].x), inv = 1.0 / d;
+            wave_lds_sync();
+            if (l == j) {
+                Mx[j][j] = cplx<double>{d, 0.0};
+                inv_d[j] = inv;
+            } else if (l > j && l < V) Mx[l][j] = Mx[l][j] * inv;
+            wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = l + 64 * q, i = idx >> 4, c = idx & 15;
+                if (c > j && c <= i && i < V) {
+                    const cplx<double> a = Mx[i][j], b = Mx[c][j];
+                    Mx[i][c] = Mx[i][c] - cplx<double>{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};   // a * conj(b)
+                }
+            }
+            wave_lds_sync();
+        }
+        // ---- 4: P(theta) = 1 / |L^-1 a(theta)|^2
+        for (int t = l; t < T; t += 64) {
+            cplx<double> y[16];
+            double p = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < V) {
+                    cplx<double> s = Ast[(long)i * T + t];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) s = s - cmul(Mx[i][k], y[k]);      // Mx[i][k]: same address in every lane
+                    y[i] = s * inv_d[i];
+                    p += y[i].x * y[i].x + y[i].y * y[i].y;
+                }
+            }
+            out[bin * T + t] = (float)(1.0 / p);
+        }
+        wave_lds_sync();
+    }
+}
+
+inline int capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out, int n_frames, int V, int R, int K,
+                 int T, double delta) {
+    std::vector<double> ast((size_t)V * T * 2, 0.0);
     for (int v = 0; v < V; ++v)
         for (int t = 0; t < T; ++t) {
             const double ph = -M_PI * (double)v * std::sin(h_thetas[t]);     // a_v = exp(-j pi v sin(theta))
-            ast[((size_t)v * Tp + t) * 2] = std::cos(ph);
-            ast[((size_t)v * Tp + t) * 2 + 1] = std::sin(ph);
+            ast[((size_t)v * T + t) * 2] = std::cos(ph);
+            ast[((size_t)v * T + t) * 2 + 1] = std::sin(ph);
         }
     MMW_TRY(ensure_scratch(ctx, ast.size() * sizeof(double)));
     MMW_HIP(hipMemcpyAsync(ctx->scratch, ast.data(), ast.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MMW_HIP(hipStreamSynchronize(ctx->stream));   // ast is a host temporary
     ProfScope ps(ctx, "capon");
-    hipLaunchKernelGGL(k_capon, dim3(R), dim3(64), 0, ctx->stream, (const cplx<float> *)d_X,
-                       (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, Tp, delta);
+    const long n_bins = (long)n_frames * R;
+    const int lds = 4 * CAPON_WAVE_LDS;
+    // three workgroups (12 waves) fit a CU's LDS; a few per CU, each wave walking its share of the bins
+    const long want = (n_bins + 3) / 4;
+    const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 3 * std::max(1, tune_int("MMW_CAPON_WG_ROUNDS", 2)));
+    hipLaunchKernelGGL(k_capon_batch, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
+                       (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, n_bins, delta);
     return check_launch("capon");
 }
 

@@ -193,7 +193,9 @@ int mmw_sync(mmw_ctx *ctx) {
         ctx->chain_dirty = false;
         if (aborted) {
             ctx->chain_layout[0] = 0;       // counters are inconsistent: the next call starts a fresh layout
-            return set_error(MMW_ERR_HIP, "chain hand-off timed out on the device (output incomplete)");
+            return set_error(MMW_ERR_HIP, "chain hand-off timed out on the device (output incomplete): the range-Doppler and angle "
+                             "launches of the device-synchronised chain must run concurrently -- a tool that serialises kernel "
+                             "dispatches (e.g. rocprofv3 --pmc) needs MMW_CHAIN_MODE=events");
         }
     }
     return MMW_OK;
@@ -1315,6 +1317,24 @@ int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, 
     return MMW_OK;
 }
 
+int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops) {
+    MMW_REQUIRE(ctx && tflops && (kind == 0 || kind == 1), "bad argument");
+    MMW_JOIN(ctx);
+    MMW_TRY(ensure_scratch(ctx, 256));
+    const int iters = 1 << 15, wgs = ctx->num_cu * 2;            // 8 waves per CU = 2 per SIMD
+    hipLaunchKernelGGL(k_diag_mfma, dim3(wgs), dim3(256), 0, ctx->stream, (float *)ctx->scratch, 256, kind);    // warm-up
+    MMW_HIP(hipEventRecord(ctx->t0, ctx->stream));
+    hipLaunchKernelGGL(k_diag_mfma, dim3(wgs), dim3(256), 0, ctx->stream, (float *)ctx->scratch, iters, kind);
+    MMW_TRY(check_launch("diag_mfma"));
+    MMW_HIP(hipEventRecord(ctx->t1, ctx->stream));
+    MMW_HIP(hipEventSynchronize(ctx->t1));
+    float ms = 0.f;
+    MMW_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    const double flops_per_mfma = kind == 0 ? 2.0 * 32 * 32 * 2 : 2.0 * 16 * 16 * 4;
+    *tflops = (double)wgs * 4 * iters * 4 * flops_per_mfma / (ms * 1e-3) / 1e12;
+    return MMW_OK;
+}
+
 int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks) {
     MMW_REQUIRE(ctx && d_src && d_dst && bytes % 16 == 0 && mode >= 0 && mode <= 7, "bad argument");
     MMW_JOIN(ctx);
@@ -1325,20 +1345,22 @@ int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, i
 }
 
 // ------------------------------------------------------------------ beamformers
-int mmw_bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int S,
+int mmw_bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int n_frames, int S,
                  int E, int T, double lambda_m) {
     MMW_REQUIRE(ctx && d_X && d_P && d_dirs && d_out, "null argument");
     MMW_JOIN(ctx);
-    MMW_REQUIRE(S > 0 && E > 0 && T > 0 && lambda_m > 0, "bad shape");
-    return bartlett(ctx, d_X, d_P, d_dirs, d_out, S, E, T, lambda_m);
+    MMW_REQUIRE(n_frames >= 0 && n_frames <= 65535 && S > 0 && E > 0 && T > 0 && lambda_m > 0, "bad shape");
+    if (n_frames == 0) return MMW_OK;
+    return bartlett(ctx, d_X, d_P, d_dirs, d_out, n_frames, S, E, T, lambda_m);
 }
 
-int mmw_capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out, int V, int R, int K, int T,
-              double delta) {
+int mmw_capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out, int n_frames, int V, int R, int K,
+              int T, double delta) {
     MMW_REQUIRE(ctx && d_X && h_thetas && d_out, "null argument");
     MMW_JOIN(ctx);
-    MMW_REQUIRE(V > 0 && V <= 16 && R > 0 && K > 0 && T > 0, "bad shape (V <= 16)");
-    return capon(ctx, d_X, h_thetas, d_out, V, R, K, T, delta);
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && V <= 16 && R > 0 && K > 0 && T > 0, "bad shape (V <= 16)");
+    if (n_frames == 0) return MMW_OK;
+    return capon(ctx, d_X, h_thetas, d_out, n_frames, V, R, K, T, delta);
 }
 
 }  // extern "C"

@@ -53,22 +53,29 @@ class SyntheticArrayBeamformerCore:
         return self.contract(X, P)
 
     def contract(self, X_se: np.ndarray, P_3e: np.ndarray) -> np.ndarray:
+        """``X [S, E]`` with geometry ``P [3, E]`` -> ``[S, n_az, n_el]``; a batch ``X [F, S, E]``, ``P [F, 3, E]`` (every
+        frame its own synthetic-array geometry) -> ``[F, S, n_az, n_el]`` in one launch group."""
         ctx, bufs = self._device()
         X = np.ascontiguousarray(X_se, dtype=np.complex64)
         P = np.ascontiguousarray(P_3e, dtype=np.float64)
-        S, E = X.shape
-        if P.shape != (3, E):
-            raise ValueError(f"array geometry {P.shape} does not match {E} elements")
+        single = X.ndim == 2
+        if single:
+            X, P = X[None], P[None]
+        if X.ndim != 3 or P.ndim != 3:
+            raise ValueError("expected X [S, E] / P [3, E] or X [F, S, E] / P [F, 3, E]")
+        F, S, E = X.shape
+        if P.shape != (F, 3, E):
+            raise ValueError(f"array geometry {P.shape} does not match {F} frames x {E} elements")
         dirs = np.ascontiguousarray(self.d.reshape(3, -1), dtype=np.float64)
         T = dirs.shape[1]
         d_X, d_P, d_D = bufs.get("bf_x", X.nbytes), bufs.get("bf_p", P.nbytes), bufs.get("bf_d", dirs.nbytes)
-        d_Y = bufs.get("bf_y", S * T * 8)
+        d_Y = bufs.get("bf_y", F * S * T * 8)
         d_X.upload(X)
         d_P.upload(P)
         d_D.upload(dirs)
-        _lib.check(ctx.lib.mmw_bartlett(ctx.handle, d_X.ptr, d_P.ptr, d_D.ptr, d_Y.ptr, S, E, T, self.lambda_m))
-        out = d_Y.download((S, T), np.complex64).astype(np.complex128)
-        self.beamformed_resp = out.reshape(S, self.d.shape[1], self.d.shape[2])
+        _lib.check(ctx.lib.mmw_bartlett(ctx.handle, d_X.ptr, d_P.ptr, d_D.ptr, d_Y.ptr, F, S, E, T, self.lambda_m))
+        out = d_Y.download((F, S, T), np.complex64).astype(np.complex128).reshape(F, S, self.d.shape[1], self.d.shape[2])
+        self.beamformed_resp = out[0] if single else out
         return self.beamformed_resp
 
 
@@ -85,17 +92,24 @@ class CaponBeamformer:
         self._bufs = None
 
     def process(self, X_vrk: np.ndarray) -> np.ndarray:
-        """X ``[V, R, K]`` complex snapshots (e.g. range-FFT output per chirp) -> float64 ``[R, T]``."""
+        """X ``[V, R, K]`` complex snapshots (e.g. range-FFT output per chirp) -> float64 ``[R, T]``;
+        a batch ``[F, V, R, K]`` -> ``[F, R, T]`` in one launch."""
         if self._ctx is None:
             self._ctx = _lib.default_context()
         if self._bufs is None:
             self._bufs = _lib.BufferSet(self._ctx)
         ctx, bufs = self._ctx, self._bufs
         X = np.ascontiguousarray(X_vrk, dtype=np.complex64)
-        V, R, K = X.shape
+        single = X.ndim == 3
+        if single:
+            X = X[None]
+        if X.ndim != 4:
+            raise ValueError("expected [V, R, K] or [F, V, R, K] snapshots")
+        F, V, R, K = X.shape
         T = len(self.thetas_rad)
-        d_X, d_out = bufs.get("cap_x", X.nbytes), bufs.get("cap_p", R * T * 4)
+        d_X, d_out = bufs.get("cap_x", X.nbytes), bufs.get("cap_p", F * R * T * 4)
         d_X.upload(X)
         th = self.thetas_rad.ctypes.data_as(C.POINTER(C.c_double))
-        _lib.check(ctx.lib.mmw_capon(ctx.handle, d_X.ptr, th, d_out.ptr, V, R, K, T, self.delta))
-        return d_out.download((R, T), np.float32).astype(np.float64)
+        _lib.check(ctx.lib.mmw_capon(ctx.handle, d_X.ptr, th, d_out.ptr, F, V, R, K, T, self.delta))
+        out = d_out.download((F, R, T), np.float32).astype(np.float64)
+        return out[0] if single else out

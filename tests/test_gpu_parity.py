@@ -443,11 +443,20 @@ def test_bartlett_mfma_vs_oracle_shapes(S, E, naz, nel):
     out = bf.contract(X, P)
     ref = O.bartlett_response(X.astype(complex), P, O.steering_dirs(az, el), lam)
     assert rel_err(out, ref) <= SPEC_TOL
+    # a batch of frames, each with its own array geometry, in one launch group == frame by frame
+    Xb = np.stack([X, X[::-1], 2.0 * X])
+    Pb = np.stack([P, rng.uniform(-0.05, 0.05, (3, E)), P])
+    outb = bf.contract(Xb, Pb)
+    assert outb.shape == (3,) + out.shape
+    np.testing.assert_array_equal(outb[0], out)
+    assert rel_err(outb[1], O.bartlett_response(Xb[1].astype(complex), Pb[1], O.steering_dirs(az, el), lam)) <= SPEC_TOL
+    assert rel_err(outb[2], 2.0 * ref) <= SPEC_TOL
 
 
 def test_capon_mfma_vs_own_oracle():
-    """BASELINE config 4 shape: 12-element array x 512 range bins.  No upstream oracle: parity unpinned,
-    checked against this build's float64 definition (oracle_np.capon_spectrum) and a single-source peak."""
+    """BASELINE config 4 shape: 12-element array x 512 range bins.  NO UPSTREAM ORACLE (the reference has no Capon code,
+    SURVEY.md F2): parity unpinned -- checked against this build's own float64 definition (oracle_np.capon_spectrum),
+    a single-source peak, the batch entry point, odd sizes, and an analytic two-source resolution case."""
     from mmwave_radar_processing_amd.processors.steering_beamformers import CaponBeamformer
     rng = np.random.default_rng(8)
     V, R, K = 12, 512, 128
@@ -457,11 +466,49 @@ def test_capon_mfma_vs_own_oracle():
     s = rng.standard_normal((R, K)) + 1j * rng.standard_normal((R, K))
     X = (a[:, :, None] * s[None] * 8 + rng.standard_normal((V, R, K)) + 1j * rng.standard_normal((V, R, K)))
     X = X.astype(np.complex64)
-    P = CaponBeamformer(th, delta=1e-3).process(X)
+    cap = CaponBeamformer(th, delta=1e-3)
+    P = cap.process(X)
     ref = O.capon_spectrum(X, th, delta=1e-3)
     assert P.shape == (R, len(th))
     np.testing.assert_allclose(P, ref, rtol=2e-5)
     assert np.all(np.abs(th[np.argmax(P, axis=1)] - th0) <= 0.03)
+    # batch of frames in one launch == frame by frame
+    Xb = np.stack([X, X[:, ::-1, :], 0.5 * X])
+    Pb = cap.process(Xb)
+    assert Pb.shape == (3, R, len(th))
+    np.testing.assert_array_equal(Pb[0], P)
+    np.testing.assert_array_equal(Pb[1], P[::-1])
+    np.testing.assert_allclose(Pb[2], 0.25 * P, rtol=1e-6)       # P scales with the signal power (float32 output)
+    # odd sizes: 7 antennas, 5 range bins, 37 snapshots (partial staging tile, odd K), 70 angles
+    X2 = (rng.standard_normal((2, 7, 5, 37)) + 1j * rng.standard_normal((2, 7, 5, 37))).astype(np.complex64)
+    th2 = np.linspace(-1.0, 1.0, 70)
+    P2 = CaponBeamformer(th2, delta=1e-2).process(X2)
+    for f in range(2):
+        np.testing.assert_allclose(P2[f], O.capon_spectrum(X2[f], th2, delta=1e-2), rtol=2e-5)
+    # two uncorrelated sources 0.12 rad apart: closer than the Rayleigh width of a 12-element half-wavelength array
+    # (2 / V = 0.17 in sin(theta)), so the delay-and-sum (Bartlett) spectrum shows ONE lobe while the MVDR spectrum,
+    # whose peak width shrinks with SNR, shows two peaks at the source angles with a dip between them.  With exact
+    # covariance R = sigma_s^2 (a1 a1^H + a2 a2^H) + sigma_n^2 I the MVDR spectrum has the closed form below.
+    t1, t2 = -0.06, 0.06
+    a1 = np.exp(-1j * np.pi * np.arange(V) * np.sin(t1))
+    a2 = np.exp(-1j * np.pi * np.arange(V) * np.sin(t2))
+    Kb = 4096
+    s1 = (rng.standard_normal(Kb) + 1j * rng.standard_normal(Kb)) * np.sqrt(50.0)
+    s2 = (rng.standard_normal(Kb) + 1j * rng.standard_normal(Kb)) * np.sqrt(50.0)
+    Xt = a1[:, None] * s1 + a2[:, None] * s2 + (rng.standard_normal((V, Kb)) + 1j * rng.standard_normal((V, Kb))) * np.sqrt(0.5)
+    tht = np.linspace(-0.4, 0.4, 321)
+    Pt = CaponBeamformer(tht, delta=0.0).process(Xt[:, None, :].astype(np.complex64))[0]
+    At = np.exp(-1j * np.pi * np.arange(V)[:, None] * np.sin(tht)[None, :])
+    Rth = 100.0 * (np.outer(a1, a1.conj()) + np.outer(a2, a2.conj())) + 1.0 * np.eye(V)
+    Pth = 1.0 / np.real(np.sum(At.conj() * np.linalg.solve(Rth, At), axis=0))
+    i1, i2, im = np.argmin(np.abs(tht - t1)), np.argmin(np.abs(tht - t2)), np.argmin(np.abs(tht))
+    peaks = [i for i in range(1, len(tht) - 1) if Pt[i] > Pt[i - 1] and Pt[i] > Pt[i + 1] and Pt[i] > 0.2 * Pt.max()]
+    assert len(peaks) == 2 and abs(peaks[0] - i1) <= 2 and abs(peaks[1] - i2) <= 2          # resolved, at the sources
+    assert Pt[im] < 0.5 * min(Pt[i1], Pt[i2])                                                  # a real dip between them
+    np.testing.assert_allclose(Pt[[i1, i2, im]], Pth[[i1, i2, im]], rtol=0.15)                 # finite-sample covariance
+    bart = np.abs(At.conj().T @ Xt.astype(np.complex64)).mean(axis=1)
+    bpk = [i for i in range(1, len(tht) - 1) if bart[i] > bart[i - 1] and bart[i] > bart[i + 1] and bart[i] > 0.5 * bart.max()]
+    assert len(bpk) == 1                                                                       # delay-and-sum does not resolve them
 
 
 def test_frame_pipeline_matches_per_frame_processors_and_oracle():

@@ -6,6 +6,7 @@ CA-CFAR + compaction, next to the in-situ copy / write / read ceilings of the sa
 Prints one JSON object; `GB/s` figures use ALGORITHMIC bytes: a kernel's compulsory read + write.
 """
 import argparse
+import ctypes as ct
 import json
 import os
 import sys
@@ -139,32 +140,64 @@ def main():
     for key in ("dopaz_coarse_two_pass", "dopaz_coarse"):
         if key in res:
             res[key]["us_per_frame"] = round(1e3 * res[key]["ms"] / Fz, 3)
-    import ctypes as ct
     zf = np.concatenate((np.linspace(0.974, 1.0, C, endpoint=False), np.linspace(0.0, 0.026, C, endpoint=False)))
     run("dopaz_zoom_256bins", lambda: _lib.check(L.mmw_doppler_azimuth_zoom(
         ctx.handle, d_in.ptr, d_da.ptr, Fz, V, S, C, A, 0, S, C, zf.ctypes.data_as(ct.POINTER(ct.c_double)), 2 * C, 0)),
         8.0 * Fz * V * S * C * 2 * C)                          # zoom-transform flops -> GFLOP/s
     if "dopaz_zoom_256bins" in res:
         res["dopaz_zoom_256bins"]["us_per_frame"] = round(1e3 * res["dopaz_zoom_256bins"]["ms"] / Fz, 3)
-    # ---- beamformers (BASELINE config 4 shapes): complex GEMM on f32 MFMA, MVDR on f64 MFMA
-    Sb, Eb, Tb = 256, 256, 64
+    # ---- beamformers (BASELINE config 4 shapes): complex GEMM on f32 MFMA, MVDR covariance on f64 MFMA.
+    # "GBs" of these entries is GFLOP/s of USEFUL flops (8 per complex multiply-add); "frac_of_mfma_peak" divides by the
+    # matrix-core peak measured on this device by mmw_diag_mfma_peak (the guide lists 157.3 TF f32 MFMA, nothing for f64).
+    peak = {}
+    for kind, name in ((0, "f32"), (1, "f64")):
+        v = ct.c_double(0)
+        _lib.check(L.mmw_diag_mfma_peak(ctx.handle, kind, ct.byref(v)))
+        peak[name] = v.value
+    res["mfma_peak_measured_TFLOPs"] = {k: round(v, 1) for k, v in peak.items()}
     rng = np.random.default_rng(1)
-    d_X = ctx.alloc(Sb * Eb * 8); d_X.upload((rng.standard_normal((Sb, Eb)) + 1j * rng.standard_normal((Sb, Eb))).astype(np.complex64))
-    d_P = ctx.alloc(3 * Eb * 8); d_P.upload(rng.uniform(-0.05, 0.05, (3, Eb)))
-    az = np.linspace(-1.2, 1.2, Tb)
-    dirs = np.ascontiguousarray(np.stack([np.cos(az), np.sin(az), np.zeros(Tb)]))
-    d_D = ctx.alloc(dirs.nbytes); d_D.upload(dirs)
-    d_Y = ctx.alloc(Sb * Tb * 8)
-    run("bartlett_256x256x64", lambda: _lib.check(L.mmw_bartlett(ctx.handle, d_X.ptr, d_P.ptr, d_D.ptr, d_Y.ptr, Sb, Eb, Tb,
-                                                                 299792458.0 / 77e9)), 8.0 * Sb * Eb * Tb)   # "GBs" = GFLOP/s here
+    lam = 299792458.0 / 77e9
+    for Fb, Sb, Eb, Tb in ((1, 256, 256, 64), (16, 256, 256, 64), (16, 256, 256, 900)):
+        X = (rng.standard_normal((Fb, Sb, Eb)) + 1j * rng.standard_normal((Fb, Sb, Eb))).astype(np.complex64)
+        d_X = ctx.alloc(X.nbytes); d_X.upload(X)
+        d_P = ctx.alloc(Fb * 3 * Eb * 8); d_P.upload(rng.uniform(-0.05, 0.05, (Fb, 3, Eb)))
+        az = np.linspace(-1.2, 1.2, Tb)
+        dirs = np.ascontiguousarray(np.stack([np.cos(az), np.sin(az), np.zeros(Tb)]))
+        d_D = ctx.alloc(dirs.nbytes); d_D.upload(dirs)
+        d_Y = ctx.alloc(Fb * Sb * Tb * 8)
+        key = f"bartlett_F{Fb}_{Sb}x{Eb}x{Tb}"
+        ctx.profile_reset(); ctx.profile_enable(1)
+        run(key, lambda: _lib.check(L.mmw_bartlett(ctx.handle, d_X.ptr, d_P.ptr, d_D.ptr, d_Y.ptr, Fb, Sb, Eb, Tb, lam)),
+            8.0 * Fb * Sb * Eb * Tb)
+        ctx.profile_enable(False)
+        if key in res:
+            ms, n = ctx.profile_get("cgemm")
+            res[key]["us_per_frame"] = round(1e3 * res[key]["ms"] / Fb, 3)
+            if n:
+                tf = 8.0 * Fb * Sb * Eb * Tb / (ms / n * 1e-3) / 1e12
+                res[key]["cgemm_ms"] = round(ms / n, 4)
+                res[key]["cgemm_TFLOPs"] = round(tf, 2)
+                res[key]["cgemm_frac_of_mfma_peak"] = round(tf / peak["f32"], 3)
+        for b_ in (d_X, d_P, d_D, d_Y):
+            b_.free()
     Vc, Rc, Kc, Tc = 12, 512, 128, 181
-    d_Xc = ctx.alloc(Vc * Rc * Kc * 8)
-    d_Xc.upload((rng.standard_normal((Vc, Rc, Kc)) + 1j * rng.standard_normal((Vc, Rc, Kc))).astype(np.complex64))
     th = np.linspace(-1.3, 1.3, Tc)
-    d_Pc = ctx.alloc(Rc * Tc * 4)
-    run("capon_12x512x128_T181", lambda: _lib.check(L.mmw_capon(ctx.handle, d_Xc.ptr, th.ctypes.data_as(ct.POINTER(ct.c_double)),
-                                                                d_Pc.ptr, Vc, Rc, Kc, Tc, 1e-3)),
-        8.0 * Vc * Vc * Kc * Rc + 8.0 * Tc * Vc * Vc * Rc)     # covariance + R^-1 A flops -> GFLOP/s
+    for Fc in (1, 32):
+        d_Xc = ctx.alloc(Fc * Vc * Rc * Kc * 8)
+        d_Xc.upload((rng.standard_normal((Fc, Vc, Rc, Kc)) + 1j * rng.standard_normal((Fc, Vc, Rc, Kc))).astype(np.complex64))
+        d_Pc = ctx.alloc(Fc * Rc * Tc * 4)
+        key = f"capon_F{Fc}_12x512x128_T181"
+        # useful flops: covariance 8 V^2 K per bin, forward substitution 8 T V (V + 1) / 2 per bin (no upstream oracle)
+        flops = Fc * Rc * (8.0 * Vc * Vc * Kc + 8.0 * Tc * Vc * (Vc + 1) / 2)
+        run(key, lambda: _lib.check(L.mmw_capon(ctx.handle, d_Xc.ptr, th.ctypes.data_as(ct.POINTER(ct.c_double)), d_Pc.ptr, Fc,
+                                                Vc, Rc, Kc, Tc, 1e-3)), flops)
+        if key in res:
+            res[key]["us_per_frame"] = round(1e3 * res[key]["ms"] / Fc, 3)
+            res[key]["TFLOPs_useful"] = round(flops / (res[key]["ms"] * 1e-3) / 1e12, 2)
+            res[key]["frac_of_f64_mfma_peak"] = round(res[key]["TFLOPs_useful"] / peak["f64"], 3)
+            res[key]["covariance_mfma_flops_issued"] = Fc * Rc * (Kc // 4) * 4 * 2.0 * 16 * 16 * 4
+            res[key]["input_GBs"] = round(Fc * Vc * Rc * Kc * 8 / res[key]["ms"] / 1e6, 1)
+        d_Xc.free(); d_Pc.free()
     print(json.dumps(res))
 
 
