@@ -13,7 +13,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmmwgpu.so")
+# MMWGPU_LIB: load another build of the same library (A/B timing of kernel variants; never a different backend)
+LIB_PATH = os.environ.get("MMWGPU_LIB") or os.path.join(_HERE, "csrc", "libmmwgpu.so")
 
 MMW_OK = 0
 MMW_ERR_INVALID = -1

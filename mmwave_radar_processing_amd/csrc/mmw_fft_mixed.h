@@ -21,6 +21,7 @@
 #include <algorithm>
 #include "mmw_fft_generic.h"
 #include "mmw_fft_fused.h"
+#include "mmw_dft_small.h"
 
 namespace mmw {
 
@@ -62,10 +63,14 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 
 // One level: groups (o, i), i fastest over the lanes; element j of a group sits at lds[i*inner_stride +
 // o*outer_stride + j*estride].  Output k replaces element k, times tw[(o * k) mod N] when tw != nullptr.
+// The R points go through RegDFT<R> (mmw_dft_small.h): radix-2 networks, real-symmetric prime DFTs, prime-factor /
+// Cooley-Tukey splits -- all at compile time, 3-4x fewer multiply-adds than the R x R matrix product of round 1
+// (Wm, the DFT matrix, is only used by the run-time-radix levels now).
 template <int R, int NT, typename T>
 __device__ __forceinline__ void dft_level(cplx<T> *lds, int tid, int n_inner, unsigned mg_inner, int inner_stride, int n_outer,
                                           int outer_stride, int estride, const cplx<T> *__restrict__ Wm,
                                           const cplx<T> *__restrict__ tw, int N) {
+    (void)Wm;
     const int n_groups = n_inner * n_outer;
     for (int g = tid; g < n_groups; g += NT) {
         const int o = fast_div(g, mg_inner, n_inner), i = g - o * n_inner;
@@ -73,33 +78,18 @@ __device__ __forceinline__ void dft_level(cplx<T> *lds, int tid, int n_inner, un
         cplx<T> x[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) x[j] = p[j * estride];
-        int idx = 0;
-#pragma unroll 1
-        for (int k = 0; k < R; ++k) {
-            const cplx<T> *w = Wm + k * R;      // uniform address: scalar loads
-            // acc += x * w as two packed FMAs: (x.re, x.re) * (w.re, w.im) + (-x.im, x.im) * (w.im, w.re);
-            // two independent chains (even / odd j); W^0 = 1 for j = 0
-            cplx<T> a0 = x[0], a1 = cplx<T>{(T)0, (T)0};
+        RegDFT<R, T>::run(x);
+        if (tw) {
+            int idx = o;                            // (o * k) mod N, k = 1 .. R-1 (o < N)
 #pragma unroll
-            for (int j = 1; j < R; ++j) {
-                const cplx<T> wj = w[j];
-                const cplx<T> xr = cplx<T>{x[j].x, x[j].x}, xi = cplx<T>{-x[j].y, x[j].y}, ws = cplx<T>{wj.y, wj.x};
-                if (j & 1) {
-                    a1 = __builtin_elementwise_fma(xr, wj, a1);
-                    a1 = __builtin_elementwise_fma(xi, ws, a1);
-                } else {
-                    a0 = __builtin_elementwise_fma(xr, wj, a0);
-                    a0 = __builtin_elementwise_fma(xi, ws, a0);
-                }
-            }
-            cplx<T> acc = a0 + a1;
-            if (tw) {
-                acc = cmul(acc, tw[idx]);
+            for (int k = 1; k < R; ++k) {
+                x[k] = cmul(x[k], tw[idx]);
                 idx += o;
                 if (idx >= N) idx -= N;
             }
-            p[k * estride] = acc;
         }
+#pragma unroll
+        for (int k = 0; k < R; ++k) p[k * estride] = x[k];
     }
 }
 
@@ -510,11 +500,18 @@ int get_rader_tables(mmw_ctx *ctx, int P, int r1, int r2, RaderTab *rt) {
     return MMW_OK;
 }
 
+// compile-time specialised kernels for the shipped cfg shapes (mmw_fft_mixed_ct.h, own translation units)
+bool rd_mixed_ct_supported(int S, int C);
+int launch_rd_mixed_ct(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv);
+
 // planes x [S][C] complex64 at d_in (plane pitch in_plane_stride elements) -> d_out planes, contiguous:
 // T = float: complex64 spectrum; T = double, MAG: float64 magnitude (the CFAR plane).
 template <typename T, bool MAG>
 int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C,
                     RawView rv = RawView{1, 0}) {
+    if constexpr (sizeof(T) == 4 && !MAG)
+        if (rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0))
+            return launch_rd_mixed_ct(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv);
     RdMixedPlan pl;
     if (!rd_mixed_plan(S, C, sizeof(cplx<T>), &pl))
         return set_error(MMW_ERR_UNSUPPORTED, "no mixed-radix RD plan for %dx%d", S, C);

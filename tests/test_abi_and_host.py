@@ -158,6 +158,16 @@ def test_register_fft_network_host_build(tmp_path):
     assert "N=64" in out
 
 
+def test_any_length_register_dft_host_build(tmp_path):
+    """RegDFT<R> (mmw_dft_small.h: radix-2 networks, real-symmetric primes, prime-factor and Cooley-Tukey splits, all at
+    compile time) against a direct DFT for R = 1..32, 35, 45, 49, 63, and its compile-time cos / sin against libm."""
+    exe = tmp_path / "test_regdft"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "mmwave_radar_processing_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "cpp", "test_regdft.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "R=31 " in out and "R=63 " in out
+
+
 def test_package_config_manager_on_every_shipped_cfg():
     """The package's ConfigManager (the class a user of the reference instantiates) against the scalars the reference's own
     ConfigManager produced for all 26 cfg files (tests/golden/cfg_scalars.json, written by make_golden.py): exact float64."""
