@@ -1038,6 +1038,19 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
     const int hr = train_r + guard_r, hd = train_d + guard_d;
     const long ntrain = (long)(2 * hr + 1) * (2 * hd + 1) - (long)(2 * guard_r + 1) * (2 * guard_d + 1);
     if (kind == MMW_CFAR_OS) MMW_REQUIRE(k_rank >= 1 && k_rank <= ntrain, "k_rank must be between 1 and %ld, got %d", ntrain, k_rank);
+    if (kind == MMW_CFAR_OS && !d_thr && !d_noise && d_mask && scale > 0.0 && !env_int("MMW_OS_SELECT", 0)) {
+        // mask only: one count per cell under test instead of an order-statistic selection (k_cfar2d_os_mask)
+        const int TW = OSM_TC + 2 * hd, TH = OSM_TR + 2 * hr, TWp = ((TW + 15) / 32) * 32 + 16;
+        const size_t lds_m = (size_t)TH * TWp * sizeof(double);
+        if (lds_m <= 64 * 1024) {
+            if (n_frames == 0) return MMW_OK;
+            ProfScope ps(ctx, "cfar");
+            Cfar2dArgs a{d_X, nullptr, nullptr, d_mask, R, D, kind, train_r, train_d, guard_r, guard_d, scale, k_rank, 0};
+            dim3 grid((D + OSM_TC - 1) / OSM_TC, (R + OSM_TR - 1) / OSM_TR, n_frames);
+            hipLaunchKernelGGL(k_cfar2d_os_mask, grid, dim3(OSM_TR * OSM_TC), lds_m, ctx->stream, a);
+            return check_launch("cfar2d_os_mask");
+        }
+    }
     MMW_REQUIRE(2 * hd + 1 <= 512, "Doppler window too wide for the exact summation order");
     const size_t n_tile = (size_t)(CFAR_TR + 2 * hr) * (CFAR_TC + 2 * hd);
     size_t npad = 1;

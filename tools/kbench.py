@@ -91,6 +91,9 @@ def main():
     k_os = max(1, min(int(0.7 * 200), 200))
     run("cfar2d_os_5x5_g3x2", lambda: _lib.check(L.mmw_cfar2d(ctx.handle, d_mag.ptr, None, None, d_mask.ptr, F, S, C,
                                                                1, 5, 5, 3, 2, 2.0, 122)), F * S * C * (8 + 1))
+    # the same detector when thresholds and noise estimates are wanted too: exact order-statistic selection (k_cfar2d)
+    run("cfar2d_os_5x5_g3x2_with_thresholds", lambda: _lib.check(L.mmw_cfar2d(
+        ctx.handle, d_mag.ptr, d_thr.ptr, d_noise.ptr, d_mask.ptr, F, S, C, 1, 5, 5, 3, 2, 2.0, 122)), F * S * C * (8 + 8 + 8 + 1))
     _lib.check(L.mmw_cfar2d(ctx.handle, d_mag.ptr, None, None, d_mask.ptr, F, S, C, 0, 4, 4, 2, 2, alpha, 0))
     _lib.check(L.mmw_compact2d(ctx.handle, d_mask.ptr, d_dets.ptr, d_cnt.ptr, F, S, C, cap))
     d_idx = ctx.alloc(F * cap * 4)

@@ -16,7 +16,7 @@ SHAPES = ((12, 64, 64), (12, 128, 128), (12, 256, 128), (12, 512, 64), (12, 256,
           (4, 127, 32), (12, 130, 50), (12, 63, 115), (12, 70, 40), (12, 120, 126), (12, 512, 32), (12, 512, 8))
 for (V, S, C) in SHAPES:
     A = 64
-    frames = max(8, min(2048, (1 << 30) // (V * S * C * 8 * 8)))
+    frames = max(8, min(2048, (4 << 30) // (V * S * C * 8 * 8)))      # <= 4 GiB of 3-D output, >= ~20 waves of workgroups
     n = V * S * C * 8
     d_in, d_rd, d_out = ctx.alloc(frames * n), ctx.alloc(frames * n), ctx.alloc(frames * A * S * C * 8)
     _lib.check(L.mmw_synth_cubes(ctx.handle, d_in.ptr, frames, V, S, C, 5, 8, 30.0))
