@@ -327,20 +327,23 @@ struct ArgmaxRefine {
 //                                          256 x 128; k_fft = 32 eps leaves a factor ~2)
 //   |m32[k] - m64[k]| <= B = sum_i k_fft l1_i + k_ang sum_i |x_i|   (n_ant-term float32 sum + hypotf)
 // and flags the detection unless best - second > 2 B: the float64 argmax of an unflagged detection is the one found.
+// NA: antennas held in registers (the list is padded to it): 4 / 8 / 16 / 32 -- the gathers are cold, strided 8-byte
+// loads, so the kernel lives on the number of waves in flight, i.e. on a small register footprint.
+template <int NA>
 __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const int32_t *dets, const int32_t *counts,
                                                        int32_t *out_idx, int V, int S, int C, int cap,
                                                        AntList ants, int A, int shift, const float2 *twA, ArgmaxRefine rf) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int det = blockIdx.x * 4 + wave;
     const int f = blockIdx.y;
     int n_det = counts[f];
     if (n_det > cap) n_det = cap;
-    if (det >= n_det) return;
+    // grid.x covers the usual detection counts in one pass; a wave walks on for frames with more
+    for (int det = blockIdx.x * 4 + wave; det < n_det; det += gridDim.x * 4) {
     const int r = dets[((long)f * cap + det) * 2], v = dets[((long)f * cap + det) * 2 + 1];
-    float2 x[MAX_ANT];
+    float2 x[NA];
     float sum_abs = 0.f, sum_l1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_ANT; ++i) {
+    for (int i = 0; i < NA; ++i) {
         x[i] = (i < ants.n) ? rd[(((long)f * V + ants.idx[i]) * S + r) * C + v] : make_float2(0.f, 0.f);
         if (i < ants.n) {
             sum_abs += fabsf(x[i].x) + fabsf(x[i].y);
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
         float re = 0.f, im = 0.f;
         int t = 0;
 #pragma unroll
-        for (int i = 0; i < MAX_ANT; ++i) {
+        for (int i = 0; i < NA; ++i) {
             if (i < ants.n) {
                 const float2 w = twA[t];
                 re += x[i].x * w.x - x[i].y * w.y;
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
                 if (pos < rf.list_cap) rf.list[pos] = f * cap + det;
             }
         }
+    }
     }
 }
 

@@ -1145,6 +1145,18 @@ static int fill_ant_list(const int *h_ant, int n_ant, int V, int A, AntList *ant
     return MMW_OK;
 }
 
+static void launch_angle_argmax(mmw_ctx *ctx, dim3 grid, const float2 *rd, const int32_t *dets, const int32_t *counts,
+                                int32_t *idx, int V, int S, int C, int cap, const AntList &ants, int A, int shift,
+                                const float2 *twA, const ArgmaxRefine &rf) {
+#define MMW_ARGMAX(NA) \
+    hipLaunchKernelGGL(k_angle_argmax<NA>, grid, dim3(256), 0, ctx->stream, rd, dets, counts, idx, V, S, C, cap, ants, A, shift, twA, rf)
+    if (ants.n <= 4) MMW_ARGMAX(4);
+    else if (ants.n <= 8) MMW_ARGMAX(8);
+    else if (ants.n <= 16) MMW_ARGMAX(16);
+    else MMW_ARGMAX(32);
+#undef MMW_ARGMAX
+}
+
 int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, const int32_t *d_counts,
                      int32_t *d_idx, int n_frames, int V, int S, int C, int cap, const int *h_ant, int n_ant,
                      int A, int shift) {
@@ -1157,9 +1169,9 @@ int mmw_angle_argmax(mmw_ctx *ctx, const void *d_rd, const int32_t *d_dets, cons
     const void *twA = nullptr;
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, A, &twA));
     ProfScope ps(ctx, "argmax");
-    dim3 grid((cap + 3) / 4, n_frames);
-    hipLaunchKernelGGL(k_angle_argmax, grid, dim3(256), 0, ctx->stream, (const float2 *)d_rd, d_dets, d_counts, d_idx,
-                       V, S, C, cap, ants, A, shift, (const float2 *)twA, ArgmaxRefine{});
+    dim3 grid(std::min((cap + 3) / 4, 32), n_frames);      // 128 detections per frame in one pass, more by looping
+    launch_angle_argmax(ctx, grid, (const float2 *)d_rd, d_dets, d_counts, d_idx, V, S, C, cap, ants, A, shift,
+                        (const float2 *)twA, ArgmaxRefine{});
     return check_launch("angle_argmax");
 }
 
@@ -1229,9 +1241,9 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     const float div = (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 8));
     ArgmaxRefine rf{d_l1, d_nflag, d_list, list_cap, (float)ulps * eps / div, 4.f * (float)(n_ant + 4) * eps / div};
     ProfScope ps(ctx, "argmax");
-    dim3 grid((cap + 3) / 4, n_frames);
-    hipLaunchKernelGGL(k_angle_argmax, grid, dim3(256), 0, ctx->stream, (const float2 *)d_rd, d_dets, d_counts, d_idx,
-                       V, S, C, cap, ants, A, shift, (const float2 *)twA, rf);
+    dim3 grid(std::min((cap + 3) / 4, 32), n_frames);      // 128 detections per frame in one pass, more by looping
+    launch_angle_argmax(ctx, grid, (const float2 *)d_rd, d_dets, d_counts, d_idx, V, S, C, cap, ants, A, shift,
+                        (const float2 *)twA, rf);
     MMW_TRY(check_launch("angle_argmax"));
     RefineArgs ra{};
     ra.cubes = (const float2 *)d_cubes;
