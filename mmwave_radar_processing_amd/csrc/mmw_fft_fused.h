@@ -49,7 +49,9 @@ struct ChainSync {
     int n_frames;
     unsigned long long timeout; // s_memrealtime ticks (100 MHz) a spin may last
     int naps_rd, naps_ang;      // s_sleep(32) calls between two polls of a counter (RD runs a ring ahead: long naps are free)
-    int exp_flags;              // timing experiments only: 1 = RD stores not sc1, 2 = angle loads not sc1 (results may be stale)
+    unsigned long long vmap;    // 16 x 4 bits: live-plane index within a frame -> virtual antenna (order of the RD work items);
+                                // a packed word, not an array: indexing an array in the argument block spills it to scratch
+    int ntx, nrx;               // ntx > 1: the RD input is the raw [F][nrx][S][ntx * C] cube
 };
 #define MMW_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 // one lane: wait until (int)(*cnt - target) >= 0; false on timeout / abort (and the abort flag is raised).
@@ -103,7 +105,9 @@ __device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<floa
             const C va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
             const long o = (f * 64 + a) * pairs_per_frame + pair;
             if constexpr (MAG) {
-                const f32x2 m = {hypotf(va.x, va.y), hypotf(vb.x, vb.y)};
+                // |.| as sqrt(x^2 + y^2): spectrum values are far from the float32 range limits, so hypotf's rescaling
+                // (and its register appetite, which spilled the persistent kernel) buys nothing; error <= 1.5 ulp
+                const f32x2 m = {__builtin_sqrtf(va.x * va.x + va.y * va.y), __builtin_sqrtf(vb.x * vb.x + vb.y * vb.y)};
                 if constexpr (NT) __builtin_nontemporal_store(m, reinterpret_cast<f32x2 *>(out) + o);
                 else reinterpret_cast<f32x2 *>(out)[o] = m;
             } else {
@@ -143,8 +147,10 @@ __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, v
 // k_angle64_sync: the chain's device-synchronised angle stage (ChainSync above).  Persistent workgroups take
 // (frame, tile of 512 bins) items from a ticket counter, wait until the frame's RD planes are published, read them
 // from the ring with sc1 loads, release the slot and run the same passes + streaming stores as k_angle64.
+// Register budget: 3 waves per SIMD (168 VGPRs) for the shapes that fit it -- the headline 12-antenna windowed case
+// among them -- and 2 where the unrolled passes need more (a spill costs more than the lost wave).
 template <int VIN, bool MAG, bool ZE>
-__global__ __launch_bounds__(256, 3) void k_angle64_sync(const void *__restrict__ ring, void *__restrict__ out, long pairs_per_frame,
+__global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG) || VIN <= 4 ? 3 : 2) void k_angle64_sync(const void *__restrict__ ring, void *__restrict__ out, long pairs_per_frame,
                                                        AngleWin win, int shift_off, ChainSync cs) {
     typedef cplx<float> C;
     __shared__ int sh[4];       // [0] ticket, [1] abort
@@ -183,8 +189,7 @@ __global__ __launch_bounds__(256, 3) void k_angle64_sync(const void *__restrict_
                     continue;
                 }
                 const unsigned off = (unsigned)((((long)slot * VIN + v) * pairs_per_frame + pair) * 16);
-                const f32x4 t = (cs.exp_flags & 2) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0))
-                                                   : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+                const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
                 const float h = win.h[v];
                 xa[v] = C{t.x * h, t.y * h};
                 xb[v] = C{t.z * h, t.w * h};
@@ -526,7 +531,8 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
 // RD frames, stores are sc1, and the workgroup waits for / signals the per-slot counters.
 // L1N: also write l1[plane] = sum of |re| + |im| of the windowed plane (the error-bound scale of mmw_angle_argmax_exact;
 // same quantity as k_plane_l1, here for free while the samples are in registers).
-template <bool NTIN, int PF, bool SYNC = false, bool L1N = false>
+// RAWIN (SYNC only): the input is the raw cube; the de-interleave is folded into the row loads (two 8-B loads per lane).
+template <bool NTIN, int PF, bool SYNC = false, bool L1N = false, bool RAWIN = false>
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
@@ -545,19 +551,41 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
 
     f32x4 nx[16];
     // work item -> input plane (SYNC: item = frame * v_live + live antenna)
-    auto in_plane = [&](int item) {
-        if constexpr (!SYNC) return item;
-        else {
-            const int f = item / cs.v_live, vi = item - f * cs.v_live;
-            return f * cs.V + (cs.vskip > 2 ? vi + 1 : vi);
-        }
+    // live-plane index within a frame -> virtual antenna
+    auto live_antenna = [&](int vi) {
+        if constexpr (RAWIN) return (int)((cs.vmap >> (4 * vi)) & 15);
+        else return cs.vskip > 2 ? vi + 1 : vi;
     };
     auto issue_loads = [&](int item, auto FIRST, auto LAST) {
-        const f32x4 *src = in + (long)in_plane(item) * (RD_S * RD_C / 2);
+        if constexpr (RAWIN) {
+            // item -> (frame, virtual antenna v = tx * nrx + rx): every ntx-th chirp of raw row (frame, rx), starting at tx
+            const int f = item / cs.v_live, v = live_antenna(item - f * cs.v_live);
+            const int tx = v / cs.nrx, rx = v - tx * cs.nrx;
+            // buffer loads: the (uniform) row base lives in the descriptor and the scalar offset, the lane part is one
+            // 32-bit register for the whole plane -- 64-bit per-lane pointers for 32 loads do not fit the register budget
+            const cplx<float> *rowbase = reinterpret_cast<const cplx<float> *>(in) + (((long)f * cs.nrx + rx) * RD_S) * (long)RD_C * cs.ntx + tx;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx<float> *>(rowbase), 0,
+                                                              (int)((unsigned)(RD_S * RD_C) * (unsigned)cs.ntx * 8u), 0x00020000);
+            const unsigned voff = (unsigned)(2 * l0 * cs.ntx) * 8u, step = (unsigned)cs.ntx * 8u;
 #pragma unroll
-        for (int n1 = decltype(FIRST)::value; n1 < decltype(LAST)::value; ++n1) {
-            const int n = 16 * n1 + w0;
-            nx[n1] = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l0) : src[n * (RD_C / 2) + l0];
+            for (int n1 = decltype(FIRST)::value; n1 < decltype(LAST)::value; ++n1) {
+                const unsigned soff = (unsigned)((16 * n1 + w0) * RD_C * cs.ntx) * 8u;
+                const cplx<float> a = __builtin_bit_cast(cplx<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+                const cplx<float> b = __builtin_bit_cast(cplx<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + step, soff, 0));
+                nx[n1] = f32x4{a.x, a.y, b.x, b.y};
+            }
+        } else {
+            long plane_in = item;
+            if constexpr (SYNC) {
+                const int f = item / cs.v_live;
+                plane_in = (long)f * cs.V + live_antenna(item - f * cs.v_live);
+            }
+            const f32x4 *src = in + plane_in * (RD_S * RD_C / 2);
+#pragma unroll
+            for (int n1 = decltype(FIRST)::value; n1 < decltype(LAST)::value; ++n1) {
+                const int n = 16 * n1 + w0;
+                nx[n1] = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l0) : src[n * (RD_C / 2) + l0];
+            }
         }
     };
     int first = blockIdx.x, iter = 0;
@@ -580,7 +608,7 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
             const unsigned g = cs.s0 + (unsigned)f;
             slot = (int)(g % (unsigned)cs.ring);
             free_target = (cs.u0 + g / (unsigned)cs.ring) * (unsigned)cs.tiles;
-            dst = out + ((long)slot * cs.V + (cs.vskip > 2 ? vi + 1 : vi)) * (RD_S * RD_C);
+            dst = out + ((long)slot * cs.V + live_antenna(vi)) * (RD_S * RD_C);
             if (t0 == 0) {
                 free_seen = __hip_atomic_load(cs.ctl + CTL_CNT + CTL_RING_MAX + slot, MMW_RLX_AGENT);
                 next_ticket = __hip_atomic_fetch_add(cs.ctl + CTL_RD_TICKET, 1u, MMW_RLX_AGENT) - cs.rd_base;
@@ -699,12 +727,8 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
                         // in soffset (scalar), lane part in voffset, the Doppler bin's constant in the immediate;
                         // after an abort the descriptor has zero records and the store is dropped.
                         constexpr int kc = ((16 * k2d) ^ 64) * 8;
-                        if (cs.exp_flags & 1)
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e[bitrev<8>(k2d)]), ring_rs,
-                                                                  (unsigned)((kr * RD_C + k1d) * 8 + kc), ring_soff, 0);
-                        else
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e[bitrev<8>(k2d)]), ring_rs,
-                                                                  (unsigned)((kr * RD_C + k1d) * 8 + kc), ring_soff, 16);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e[bitrev<8>(k2d)]), ring_rs,
+                                                              (unsigned)((kr * RD_C + k1d) * 8 + kc), ring_soff, 16);
                     } else dst[kr * RD_C + kk] = e[bitrev<8>(k2d)];
                 });
             }
@@ -908,7 +932,7 @@ int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S
 
 inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
 // the chain's device-synchronised RD stage: `grid` persistent workgroups, n_items = frames * live planes
-int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid);
+int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid);   // cs.ntx > 1: raw input
 
 #ifdef MMW_TU_RD
 int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid) {
@@ -917,11 +941,15 @@ int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_ite
     MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_C, &hc));
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 256, &t256));
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 128, &t128));
-    auto kern = k_rd_fused_256x128_persist<true, 8, true>;
-    MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in, (cplx<float> *)d_ring,
-                       n_items, (const float *)hs, (const float *)hc, (const cplx<float> *)t256, (const cplx<float> *)t128, cs,
-                       (float *)nullptr);
+    auto go = [&](auto kern) -> int {
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in, (cplx<float> *)d_ring,
+                           n_items, (const float *)hs, (const float *)hc, (const cplx<float> *)t256, (const cplx<float> *)t128, cs,
+                           (float *)nullptr);
+        return MMW_OK;
+    };
+    if (cs.ntx > 1) MMW_TRY(go(k_rd_fused_256x128_persist<false, 4, true, false, true>));
+    else MMW_TRY(go(k_rd_fused_256x128_persist<true, 6, true>));
     return check_launch("rd_fused_sync");
 }
 
@@ -968,7 +996,7 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
                                (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
                                (const cplx<float> *)t256, (const cplx<float> *)t128, ChainSync{}, d_l1);
             if (l1_done) *l1_done = true;
-        } else launch(k_rd_fused_256x128_persist<true, 8>);
+        } else launch(k_rd_fused_256x128_persist<true, 6>);     // 6 rows prefetched: 8 no longer fit the register budget (spills)
         return check_launch("rd_fused_persist");
     }
 #ifdef MMW_ABLATE   // timing-only variants (no loads / no stores), build with EXTRA=-DMMW_ABLATE

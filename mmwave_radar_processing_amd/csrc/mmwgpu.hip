@@ -684,7 +684,9 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // (Non-finite samples in an end antenna: the reference's 0 * inf gives NaN everywhere, this path stays finite.)
     p.vskip = (!keep_rd && angle_skips_end_planes(V, (long)S * C, A, flags) && tune_int("MMW_CHAIN_SKIP_ENDS", 1)) ? V : 0;
     const int v_live = p.vskip > 2 ? V - 2 : V;
-    p.rd_cus = env_int("MMW_RD_CUS", ctx->num_cu * 5 / 8);
+    // CU split: half the chip each.  The angle stage is bound by HBM writes and needs ~128 CUs to saturate them (a CU
+    // sustains ~44 GB/s of stores); the range-Doppler stage keeps up from 112 CUs on (sweep in DESIGN.md)
+    p.rd_cus = env_int("MMW_RD_CUS", ctx->num_cu / 2);
     if (p.rd_cus < 0 || p.rd_cus >= ctx->num_cu) p.rd_cus = ctx->num_cu / 2;     // 0: unmasked queues
     p.ring = std::max(2, std::min(env_int("MMW_CHAIN_RING", 3), (int)PIPE_RING_MAX));
     // chunk: whole RD waves (rd_cus planes each) and `ring` chunks of live RD planes within ~250 MB of cache
@@ -706,7 +708,9 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // Device-synchronised form (256 x 128 planes): needs the two disjoint CU sets, because persistent angle workgroups
     // that filled every CU would keep the range-Doppler workgroups they wait for from ever becoming resident.
     const char *mode = std::getenv("MMW_CHAIN_MODE");
-    p.sync = p.pipelined && !raw && fused_rd_ok(S, C) && p.rd_cus > 0 && !(mode && !std::strcmp(mode, "events"));
+    (void)raw;
+    // (windowed chains only: the un-windowed angle variants of the persistent kernel exceed its register budget)
+    p.sync = p.pipelined && fused_rd_ok(S, C) && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
     // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
     p.ring_frames = env_int("MMW_CHAIN_RING_FRAMES", (int)((120u << 20) / live_bytes));
@@ -717,8 +721,8 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
 }
 
 // One RD launch + one angle launch for the whole call, synchronised through device counters (ChainSync).
-static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes, void *d_out, int n_frames, int V, int S,
-                        int C, int flags) {
+static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes, RawView rv, void *d_out, int n_frames, int V,
+                        int S, int C, int flags) {
     const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
     const long bins = (long)S * C;
     const int tiles = (int)((bins / 2 + 255) / 256), v_live = plan.vskip > 2 ? V - 2 : V;
@@ -757,9 +761,21 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     cs.tiles = tiles;
     cs.n_frames = n_frames;
     cs.timeout = (unsigned long long)tune_int("MMW_CHAIN_TIMEOUT_MS", 2000) * 100000ull;      // 100 MHz ticks
+    // order of the RD work items inside a frame: plain cubes by antenna; raw cubes rx-major, so that the ntx planes that
+    // de-interleave the same raw rows are handed out back to back (their second and third read come from cache)
+    {
+        int n = 0;
+        const bool raw = rv.ntx > 1;
+        for (int i = 0; i < V && n < 16; ++i) {
+            const int v = raw ? (i % rv.ntx) * rv.nrx + i / rv.ntx : i;       // i = rx * ntx + tx when raw
+            if (plan.vskip > 2 && (v == 0 || v == V - 1)) continue;
+            cs.vmap |= (unsigned long long)v << (4 * n++);
+        }
+    }
+    cs.ntx = rv.ntx > 1 ? rv.ntx : 1;
+    cs.nrx = rv.nrx;
     cs.naps_rd = std::max(0, env_int("MMW_SYNC_NAPS_RD", 32));
     cs.naps_ang = std::max(0, env_int("MMW_SYNC_NAPS_ANG", 4));
-    cs.exp_flags = env_int("MMW_SYNC_EXP", 0);
     const int n_rd_items = n_frames * v_live, n_ang_items = n_frames * tiles;
     const int rd_grid = std::min(plan.rd_cus, n_rd_items);
     const int ang_grid = std::min((ctx->num_cu - plan.rd_cus) * std::max(1, tune_int("MMW_ANGLE_WGS_PER_CU", 3)), n_ang_items);
@@ -824,7 +840,7 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
     const int ring = plan.ring, rd_cus = plan.rd_cus;
     int chunk = plan.chunk;
     if (plan.sync) {
-        const int rc = chain3d_sync(ctx, plan, d_cubes, d_out, n_frames, V, S, C, flags);
+        const int rc = chain3d_sync(ctx, plan, d_cubes, rv, d_out, n_frames, V, S, C, flags);
         if (rc != MMW_ERR_UNSUPPORTED) return rc;          // queues unavailable: the serial schedule below
         chunk = std::min(n_frames, 1024);
     }
