@@ -17,3 +17,13 @@ r=json.load(open("gpurun_out/r02/bench_line.json")); print("bench", r["value"], 
 r=json.load(open("gpurun_out/r02/bench_detect_line.json")); print("detect", r["value"], r["kernels_ms_per_step"], r["parity"], r.get("cpu_baseline",{}).get("value"))
 print(open("gpurun_out/r02/api_latency.json").read())
 PY
+
+# ---- copy what is kept into profiles/ (tracked)
+cp gpurun_out/r02/bench_line.json profiles/r02_bench_line.json
+cp gpurun_out/r02/bench_detect_line.json profiles/r02_bench_detect_line.json
+cp gpurun_out/r02/kbench.json profiles/r02_kbench.json
+cp gpurun_out/r02/kbench_63x100.json profiles/r02_kbench_63x100.json
+cp gpurun_out/r02/shapes.json profiles/r02_shapes.json
+cp gpurun_out/r02/membw.json profiles/r02_membw.json
+cp gpurun_out/r02/gpu_tests.log profiles/r02_gpu_tests.log
+cp gpurun_out/r02/os_sweep.log profiles/r02_os_sweep.log
