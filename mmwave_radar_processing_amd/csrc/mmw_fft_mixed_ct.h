@@ -44,8 +44,11 @@ constexpr int best_n1(int N) {
 constexpr bool supported(int S, int C) { return best_n1(S) > 0 && best_n1(C) > 0; }
 constexpr int threads_for(int S, int C) {
     // as launch_rd_mixed: fill ~24 waves per CU given how many planes share its LDS
-    const long lds = ((long)S * (C | 1) + S + C) * 8;
+    const long lds = ((long)S * (C | 1) + S + C + (S + C + 1) / 2) * 8;
     const int wgs = (int)(160 * 1024 / lds);
+    // 90 x 80 and 200 x 40 need ~100 VGPRs: 1024 threads would leave ONE workgroup per CU although two planes fit its
+    // LDS; two 512-thread workgroups overlap each other's load and store phases (measured +12 % on both)
+    if ((S == 90 && C == 80) || (S == 200 && C == 40)) return 512;
     return wgs < 3 ? 1024 : (wgs < 6 ? 512 : 256);
 }
 }  // namespace mixct
@@ -59,7 +62,12 @@ struct RdMixedCtArgs {
     const float *cs_big;        // coefficient table of the big-prime level (nullptr when no axis has one)
     RawView raw;
     long planes;
+    long long *clk;             // diagnostics (MMW_PHASE_CLOCKS=1): s_memtime at the phase boundaries of workgroup 0
 };
+
+__device__ __forceinline__ void phase_mark(long long *clk, int i, int tid) {
+    if (clk && blockIdx.x == 0 && tid == 0) clk[i] = (long long)__builtin_amdgcn_s_memtime();
+}
 
 // One level over the LDS plane: N_GROUPS groups g = o * N_INNER + i (i fastest over the lanes); element j of a group sits
 // at base + i * INNER_STRIDE + o * OUTER_STRIDE + j * ESTRIDE.  tw2 (when TW): output k of outer index o times tw2[o * R + k].
@@ -87,82 +95,74 @@ __device__ __forceinline__ void dft_level_ct(cplx<float> *lds, const cplx<float>
     }
 }
 
-// A level whose radix is a prime P too large for registers (the 127 of three shipped cfgs), same contract as dft_level_ct.
-// Real-symmetric direct form, in place without scratch:
-//   1. every group's x_j, x_{P-j} (j = 1 .. H = (P-1)/2) become s_j = x_j + x_{P-j} (stored at j) and d_j = x_j - x_{P-j}
-//      (stored at P-j);
-//   2. a work item = (block of 4 output indices k, group): t_k = x_0 + sum_j cos(2 pi jk/P) s_j, u_k = sum_j sin(..) d_j kept
-//      in registers -- lanes of a wave share the block, so the 8 coefficients of every j arrive by ONE scalar load and
-//      the inner loop is 8 packed FMAs per two LDS reads (H complex-by-real MACs per output, against 2 (r1 + r2) + 3
-//      complex ones plus six LDS passes for the Rader form this replaces, whose few groups per pass left most lanes idle);
-//   3. after a barrier X_k = t_k - j u_k and X_{P-k} = t_k + j u_k overwrite the group (times the inter-level twiddle).
-// cs: [H][(H + 1) / 4 blocks][8] floats = cos(2 pi j k / P) for the block's four k, then the four sines; k = 0 .. H.
-// A work item takes 4 or 8 consecutive k.
+// A level whose radix is a prime P = 127 too large for registers (three shipped cfgs), same contract as dft_level_ct.
+// Real-symmetric direct form as two real matrix products on the matrix cores, in place:
+//   with s_j = x_j + x_{P-j}, d_j = x_j - x_{P-j} (j = 1 .. H = 63), s_0 = x_0, d_0 = 0 and the columns n = (group, re | im)
+//     Dc[k][n] = sum_{j=0..63} cos(2 pi jk/P) s_j[n],   Ds[k][n] = sum_j sin(2 pi jk/P) d_j[n]      (k = 0 .. 63)
+//     X_k = Dc - i Ds,   X_{P-k} = Dc + i Ds
+//   -- a [64 x 64] x [64 x 2 N_GROUPS] real GEMM each, run as v_mfma_f32_32x32x2_f32 tiles (exact float32 FMA chains):
+//   a wave owns one 32 (k) x 32 (n) output tile; the B operand (s_j, d_j) is formed from two LDS reads of the plane, the A
+//   operand is cos / sin((j k mod P) 2 pi / P) out of a 2 P-float LDS table, its index advanced by 2k mod P per step.
+// Round 2's first version kept the outputs in VALU registers and fetched 8..16 coefficients per j by wave-uniform scalar
+// loads: phase clocks showed that loop at 65 k of the 93 k clocks of a 254 x 50 plane (the 32 KB table overflows the
+// 16 KB scalar cache; ~500 clocks per load) against ~16 k for its FMAs.  The MFMA form needs no coefficient traffic.
+// cst (LDS): cos(2 pi m / P), m = 0 .. P-1, then the P sines.
+typedef float mixct_v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float lane_xor1(float v) {      // the value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
 template <int P, int NT, int N_INNER, int INNER_STRIDE, int N_OUTER, int OUTER_STRIDE, int ESTRIDE, bool TW>
-__device__ __forceinline__ void dft_level_bigprime_ct(cplx<float> *lds, const cplx<float> *tw2, const float *__restrict__ cs, int tid) {
-    constexpr int H = (P - 1) / 2, N_GROUPS = N_INNER * N_OUTER, G64 = (N_GROUPS + 63) / 64 * 64;
-    // outputs per work item: 8 when that still gives every thread an item (half the LDS reads per output), else 4
-    constexpr int KB = ((H + 1) / 8) * G64 >= NT ? 8 : 4, NBLK = (H + 1) / KB;
-    static_assert((H + 1) % 8 == 0, "output blocks of four or eight");
-    constexpr int ITEMS = NBLK * G64, ROUNDS = (ITEMS + NT - 1) / NT;
-    // 1. s / d in place
-    for (int e = tid; e < N_GROUPS * H; e += NT) {
-        const int j = e / N_GROUPS + 1, g = e - (j - 1) * N_GROUPS;
-        const int o = g / N_INNER, i = g - o * N_INNER;
-        cplx<float> *p = lds + i * INNER_STRIDE + o * OUTER_STRIDE;
-        const cplx<float> a = p[j * ESTRIDE], b = p[(P - j) * ESTRIDE];
-        p[j * ESTRIDE] = a + b;
-        p[(P - j) * ESTRIDE] = a - b;
-    }
-    __syncthreads();
-    // 2. outputs in registers
-    cplx<float> t[ROUNDS][KB], u[ROUNDS][KB];
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int w = tid + r * NT;
-        const int blk = __builtin_amdgcn_readfirstlane(w / G64), g = w - (w / G64) * G64;    // the whole wave shares blk
-        const bool live = w < ITEMS && g < N_GROUPS;
-        const int gg = live ? g : 0, o = gg / N_INNER, i = gg - o * N_INNER;
-        const cplx<float> *p = lds + i * INNER_STRIDE + o * OUTER_STRIDE;
-        const cplx<float> x0 = p[0];
-#pragma unroll
-        for (int q = 0; q < KB; ++q) {
-            t[r][q] = x0;
-            u[r][q] = cplx<float>{0.f, 0.f};
+__device__ __forceinline__ void dft_level_bigprime_ct(cplx<float> *lds, const cplx<float> *tw2, const float *cst, int tid,
+                                                      long long *clk = nullptr) {
+    constexpr int H = (P - 1) / 2, N_GROUPS = N_INNER * N_OUTER, NCOL = 2 * N_GROUPS, NTILES = (NCOL + 31) / 32;
+    constexpr int JOBS = 2 * NTILES, NW = NT / 64;
+    static_assert(H + 1 == 64, "two 32-row output tiles");
+    static_assert(JOBS <= NW, "one output tile per wave");
+    float *lf = reinterpret_cast<float *>(lds);
+    const int lane = tid & 63, job = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kt = job / NTILES, nt = job - kt * NTILES, kk = lane >> 5;
+    const int n = nt * 32 + (lane & 31);
+    const bool valid = n < NCOL;
+    const int g = valid ? n >> 1 : 0, comp = n & 1, o = g / N_INNER, i = g - o * N_INNER;
+    const int boff = 2 * (i * INNER_STRIDE + o * OUTER_STRIDE) + comp;      // float index of element 0, this component
+    mixct_v16f dc = {0}, ds = {0};
+    if (job < JOBS) {
+        const int k = kt * 32 + (lane & 31);                // this lane's row of the A operand
+        int idx = kk ? k : 0;                               // (j k) mod P, j = 2 t + kk
+        const int step = 2 * k >= P ? 2 * k - P : 2 * k;
+        const float *pa = lf + boff + 2 * ESTRIDE * kk;             // x_j
+        const float *pb = lf + boff + 2 * ESTRIDE * (P - kk);       // x_{P-j}
+#pragma unroll 8
+        for (int t = 0; t < 32; ++t) {
+            const float xa = pa[4 * ESTRIDE * t];
+            const float xb = (t == 0 && kk == 0) ? xa : pb[-4 * ESTRIDE * t];
+            const float sj = (t == 0 && kk == 0) ? xa : xa + xb, dj = xa - xb;
+            const float c = cst[idx], sn = cst[P + idx];
+            dc = __builtin_amdgcn_mfma_f32_32x32x2f32(c, sj, dc, 0, 0, 0);
+            ds = __builtin_amdgcn_mfma_f32_32x32x2f32(sn, dj, ds, 0, 0, 0);
+            idx += step;
+            if (idx >= P) idx -= P;
         }
-        // table rows are [j][block of 4][cos x4, sin x4]; a block of 8 outputs uses two consecutive 4-blocks
-        const float *row = cs + (size_t)(blk < NBLK ? blk : 0) * (2 * KB);
-#pragma unroll 3
-        for (int j = 1; j <= H; ++j) {
-            const cplx<float> sj = p[j * ESTRIDE], dj = p[(P - j) * ESTRIDE];
-            const float *c = row + (size_t)(j - 1) * ((H + 1) / 4) * 8;     // wave-uniform address: scalar loads
+    }
+    __syncthreads();            // every wave has read the x it needs: the groups may be overwritten
+    phase_mark(clk, 9, tid);
+    if (job < JOBS) {
+        const float sgn = comp ? -1.f : 1.f;
+        // C/D map of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-            for (int q = 0; q < KB; ++q) {
-                t[r][q] = t[r][q] + sj * c[(q >> 2) * 8 + (q & 3)];
-                u[r][q] = u[r][q] + dj * c[(q >> 2) * 8 + 4 + (q & 3)];
+        for (int r = 0; r < 16; ++r) {
+            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const float pr = lane_xor1(ds[r]);              // Ds of the other component
+            float lo = dc[r] + sgn * pr, hi = dc[r] - sgn * pr;     // re: Dc.re + Ds.im | im: Dc.im - Ds.re, and mirrored
+            if constexpr (TW) {
+                const float lo_o = lane_xor1(lo), hi_o = lane_xor1(hi);
+                const cplx<float> wl = tw2[o * P + k], wh = tw2[o * P + (k ? P - k : 0)];
+                lo = lo * wl.x - sgn * lo_o * wl.y;          // re: a.x b.x - a.y b.y | im: a.y b.x + a.x b.y
+                hi = hi * wh.x - sgn * hi_o * wh.y;
             }
-        }
-    }
-    __syncthreads();
-    // 3. write X_k, X_{P-k}
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const int w = tid + r * NT;
-        const int blk = w / G64, g = w - blk * G64;
-        if (w < ITEMS && g < N_GROUPS) {
-            const int o = g / N_INNER, i = g - o * N_INNER;
-            cplx<float> *p = lds + i * INNER_STRIDE + o * OUTER_STRIDE;
-#pragma unroll
-            for (int q = 0; q < KB; ++q) {
-                const int k = blk * KB + q;
-                cplx<float> lo = cplx<float>{t[r][q].x + u[r][q].y, t[r][q].y - u[r][q].x};      // t - j u
-                cplx<float> hi = cplx<float>{t[r][q].x - u[r][q].y, t[r][q].y + u[r][q].x};      // t + j u
-                if constexpr (TW) {
-                    lo = cmul(lo, tw2[o * P + k]);
-                    if (k > 0) hi = cmul(hi, tw2[o * P + P - k]);
-                }
-                p[k * ESTRIDE] = lo;
-                if (k > 0) p[(P - k) * ESTRIDE] = hi;
+            if (valid) {
+                lf[boff + 2 * ESTRIDE * k] = lo;
+                if (k > 0) lf[boff + 2 * ESTRIDE * (P - k)] = hi;
             }
         }
     }
@@ -170,14 +170,19 @@ __device__ __forceinline__ void dft_level_bigprime_ct(cplx<float> *lds, const cp
 
 // level dispatch: register-resident radix or the big prime
 template <int R, int NT, int N_INNER, int INNER_STRIDE, int N_OUTER, int OUTER_STRIDE, int ESTRIDE, bool TW>
-__device__ __forceinline__ void dft_level_any_ct(cplx<float> *lds, const cplx<float> *tw2, const float *cs, int tid) {
+__device__ __forceinline__ void dft_level_any_ct(cplx<float> *lds, const cplx<float> *tw2, const float *cs, int tid,
+                                                 long long *clk = nullptr) {
     if constexpr (R == mixct::BIG_PRIME)
-        dft_level_bigprime_ct<R, NT, N_INNER, INNER_STRIDE, N_OUTER, OUTER_STRIDE, ESTRIDE, TW>(lds, tw2, cs, tid);
+        dft_level_bigprime_ct<R, NT, N_INNER, INNER_STRIDE, N_OUTER, OUTER_STRIDE, ESTRIDE, TW>(lds, tw2, cs, tid, clk);
     else
         dft_level_ct<R, NT, N_INNER, INNER_STRIDE, N_OUTER, OUTER_STRIDE, ESTRIDE, TW>(lds, tw2, tid);
 }
 
-template <int S, int C, int NT>
+// PERSIST (virtual-array cubes only): the grid is one residency of workgroups, each walks planes item, item + grid, ...
+// and the NEXT plane's global loads are issued into registers before this plane's levels run, so the HBM latency of the
+// load phase (~10 k of the 20..50 k clocks of a plane when the LDS holds only one or two planes per CU, phase clocks
+// above) hides behind the arithmetic instead of serialising with it.
+template <int S, int C, int NT, bool PERSIST>
 __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     constexpr int S1 = mixct::best_n1(S), S2 = S / S1, C1 = mixct::best_n1(C), C2 = C / C1;
     constexpr int Cp = C | 1, CELLS = S * C;
@@ -185,76 +190,140 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);          // [S][Cp]
     cplx<float> *tw_s = lds + S * Cp, *tw_c = tw_s + S;
+    float *cst = reinterpret_cast<float *>(tw_c + C);                  // big-prime cos / sin table (2 P floats)
+    constexpr bool BIG = S1 == mixct::BIG_PRIME || C1 == mixct::BIG_PRIME;
+    // Hann tables in the LDS: a global load in the plane loop would wait (in-order vmcnt) for the previous plane's stores
+    float *win_s = cst + (BIG ? 2 * mixct::BIG_PRIME : 0), *win_c = win_s + S;
     const int tid = threadIdx.x;
-    long plane = blockIdx.x;
-    const bool raw = a.raw.ntx > 1;
+    const bool raw = !PERSIST && a.raw.ntx > 1;
+    const int ntx = raw ? a.raw.ntx : 1;
+    constexpr bool PAIRED = C % 2 == 0;         // two adjacent chirps per 16-B load (virtual-array cubes)
+    constexpr int PAIRS = CELLS / 2, PROUNDS = PAIRED ? (PAIRS + NT - 1) / NT : 1, EROUNDS = (CELLS + NT - 1) / NT;
+    f32x4 pre4[PROUNDS];
+    cplx<float> pre1[EROUNDS];
+    auto fetch = [&](const cplx<float> *in) {
+        if constexpr (PAIRED) {
+            const f32x4 *in4 = reinterpret_cast<const f32x4 *>(in);
+#pragma unroll
+            for (int q = 0; q < PROUNDS; ++q) {
+                const int e = tid + q * NT;
+                if (PAIRS % NT == 0 || q + 1 < PROUNDS || e < PAIRS) pre4[q] = __builtin_nontemporal_load(in4 + e);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EROUNDS; ++q) {
+                const int e = tid + q * NT;
+                if (CELLS % NT == 0 || q + 1 < EROUNDS || e < CELLS) pre1[q] = __builtin_nontemporal_load(in + e);
+            }
+        }
+    };
+    auto stash = [&](int t) {                   // registers x Hann(S) x Hann(C) -> LDS
+        if constexpr (PAIRED) {
+#pragma unroll
+            for (int q = 0; q < PROUNDS; ++q) {
+                const int e = t + q * NT;
+                if (PAIRS % NT == 0 || q + 1 < PROUNDS || e < PAIRS) {
+                    const int s = (2 * e) / C, c = (2 * e) - s * C;
+                    const f32x4 v = pre4[q];
+                    const float ws = win_s[s], w0 = ws * win_c[c], w1 = ws * win_c[c + 1];
+                    lds[s * Cp + c] = cplx<float>{v.x * w0, v.y * w0};
+                    lds[s * Cp + c + 1] = cplx<float>{v.z * w1, v.w * w1};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EROUNDS; ++q) {
+                const int e = t + q * NT;
+                if (CELLS % NT == 0 || q + 1 < EROUNDS || e < CELLS) {
+                    const int s = e / C, c = e - s * C;
+                    lds[s * Cp + c] = pre1[q] * (win_s[s] * win_c[c]);
+                }
+            }
+        }
+    };
+    const cplx<float> *in_base = reinterpret_cast<const cplx<float> *>(a.in);
+    long item = blockIdx.x;
+    const long n_items = PERSIST ? skip_planes(a.planes, a.raw) : 0;
+    long plane;
     if (raw) {
         plane = raw_block_plane(blockIdx.x, a.planes, a.raw);
         if (plane < 0 || skip_raw_plane(plane, a.raw)) return;
-    } else plane = skip_block_plane(blockIdx.x, a.raw);
-    const int ntx = raw ? a.raw.ntx : 1;
-    const cplx<float> *in = raw ? raw_plane(reinterpret_cast<const cplx<float> *>(a.in), plane, S, C, a.raw)
-                                : reinterpret_cast<const cplx<float> *>(a.in) + plane * a.in_plane_stride;
-    // ---- load + windows
-    if ((C % 2 == 0) && !raw) {                 // two adjacent chirps per 16-B load
-        const f32x4 *in4 = reinterpret_cast<const f32x4 *>(in);
-        constexpr int PAIRS = CELLS / 2, ROUNDS = (PAIRS + NT - 1) / NT;
-#pragma unroll
-        for (int q = 0; q < ROUNDS; ++q) {
-            const int e = tid + q * NT;
-            if (PAIRS % NT == 0 || q + 1 < ROUNDS || e < PAIRS) {
-                const int s = (2 * e) / C, c = (2 * e) - s * C;
-                const f32x4 v = __builtin_nontemporal_load(in4 + e);
-                const float ws = a.win_s[s], w0 = ws * a.win_c[c], w1 = ws * a.win_c[c + 1];
-                lds[s * Cp + c] = cplx<float>{v.x * w0, v.y * w0};
-                lds[s * Cp + c + 1] = cplx<float>{v.z * w1, v.w * w1};
-            }
-        }
-    } else {
-        constexpr int ROUNDS = (CELLS + NT - 1) / NT;
-#pragma unroll 4
-        for (int q = 0; q < ROUNDS; ++q) {
-            const int e = tid + q * NT;
-            if (CELLS % NT == 0 || q + 1 < ROUNDS || e < CELLS) {
-                const int s = e / C, c = e - s * C;
-                const cplx<float> v = __builtin_nontemporal_load(in + (long)e * ntx);
-                lds[s * Cp + c] = v * (a.win_s[s] * a.win_c[c]);
-            }
-        }
-    }
+    } else plane = skip_block_plane(item, a.raw);
+    if (PERSIST || (PAIRED && !raw)) fetch(in_base + plane * a.in_plane_stride);
     if constexpr (S2 > 1)
         for (int i = tid; i < S; i += NT) tw_s[i] = a.tw2_s[i];
     if constexpr (C2 > 1)
         for (int i = tid; i < C; i += NT) tw_c[i] = a.tw2_c[i];
+    if constexpr (BIG)
+        for (int i = tid; i < 2 * mixct::BIG_PRIME; i += NT) cst[i] = a.cs_big[i];
+    for (int i = tid; i < S; i += NT) win_s[i] = a.win_s[i];
+    for (int i = tid; i < C; i += NT) win_c[i] = a.win_c[i];
     __syncthreads();
-    // ---- range axis: sample s = S2 n1 + n2 lives in row s.  A: groups (column, n2), radix S1; B: groups (column, k1), radix S2
-    dft_level_any_ct<S1, NT, C, 1, S2, Cp, S2 * Cp, (S2 > 1)>(lds, tw_s, a.cs_big, tid);
-    __syncthreads();
-    if constexpr (S2 > 1) {
-        dft_level_ct<S2, NT, C, 1, S1, S2 * Cp, Cp, false>(lds, nullptr, tid);
-        __syncthreads();
-    }
-    // ---- Doppler axis: chirp c = C2 m1 + m2 lives in column c; lanes walk the rows (odd pitch: conflict free)
-    dft_level_any_ct<C1, NT, S, Cp, C2, 1, C2, (C2 > 1)>(lds, tw_c, a.cs_big, tid);
-    __syncthreads();
-    if constexpr (C2 > 1) {
-        dft_level_ct<C2, NT, S, Cp, C1, C2, 1, false>(lds, nullptr, tid);
-        __syncthreads();
-    }
-    // ---- store: range bin k = k1 + S1 k2 sits in row S2 k1 + k2, Doppler bin d = d1 + C1 d2 in column C2 d1 + d2;
-    //      fftshift: out[(d + C/2) % C] = X[d]
-    cplx<float> *out = reinterpret_cast<cplx<float> *>(a.out) + plane * CELLS;
-    constexpr int HALF = C / 2, ROUNDS = (CELLS + NT - 1) / NT;
+    while (true) {
+        // PERSIST: hide the thread index from loop-invariant code motion -- hoisting every plane-invariant index and window
+        // product out of the plane loop costs ~60 VGPRs (spills at 254 x 50 and 120 x 126)
+        int t = tid;
+        if constexpr (PERSIST) asm volatile("" : "+v"(t));
+        phase_mark(a.clk, 0, tid);
+        // ---- load + windows
+        if (!PERSIST && (!PAIRED || raw)) {
+            // element loads (odd C, or the raw cube's tx-strided view): a few at a time, straight into the LDS
+            const cplx<float> *in = raw ? raw_plane(in_base, plane, S, C, a.raw) : in_base + plane * a.in_plane_stride;
 #pragma unroll 4
-    for (int q = 0; q < ROUNDS; ++q) {
-        const int e = tid + q * NT;
-        if (CELLS % NT == 0 || q + 1 < ROUNDS || e < CELLS) {
-            const int k = e / C, dd = e - k * C;
-            int d = dd - HALF;
-            if (d < 0) d += C;
-            const int k2 = k / S1, k1 = k - k2 * S1, d2 = d / C1, d1 = d - d2 * C1;
-            __builtin_nontemporal_store(lds[(S2 * k1 + k2) * Cp + C2 * d1 + d2], out + e);
+            for (int q = 0; q < EROUNDS; ++q) {
+                const int e = t + q * NT;
+                if (CELLS % NT == 0 || q + 1 < EROUNDS || e < CELLS) {
+                    const int s = e / C, c = e - s * C;
+                    const cplx<float> v = __builtin_nontemporal_load(in + (long)e * ntx);
+                    lds[s * Cp + c] = v * (win_s[s] * win_c[c]);
+                }
+            }
+        } else
+            stash(t);
+        if constexpr (PERSIST) {
+            if (item + gridDim.x < n_items) fetch(in_base + skip_block_plane(item + gridDim.x, a.raw) * a.in_plane_stride);
         }
+        __syncthreads();
+        phase_mark(a.clk, 1, tid);
+        // ---- range axis: sample s = S2 n1 + n2 lives in row s.  A: groups (column, n2), radix S1; B: groups (column, k1), radix S2
+        dft_level_any_ct<S1, NT, C, 1, S2, Cp, S2 * Cp, (S2 > 1)>(lds, tw_s, cst, t, a.clk);
+        __syncthreads();
+        phase_mark(a.clk, 2, tid);
+        if constexpr (S2 > 1) {
+            dft_level_ct<S2, NT, C, 1, S1, S2 * Cp, Cp, false>(lds, nullptr, t);
+            __syncthreads();
+        }
+        phase_mark(a.clk, 3, tid);
+        // ---- Doppler axis: chirp c = C2 m1 + m2 lives in column c; lanes walk the rows (odd pitch: conflict free)
+        dft_level_any_ct<C1, NT, S, Cp, C2, 1, C2, (C2 > 1)>(lds, tw_c, cst, t, C1 == mixct::BIG_PRIME && S1 != mixct::BIG_PRIME ? a.clk : nullptr);
+        __syncthreads();
+        phase_mark(a.clk, 4, tid);
+        if constexpr (C2 > 1) {
+            dft_level_ct<C2, NT, S, Cp, C1, C2, 1, false>(lds, nullptr, t);
+            __syncthreads();
+        }
+        phase_mark(a.clk, 5, tid);
+        // ---- store: range bin k = k1 + S1 k2 sits in row S2 k1 + k2, Doppler bin d = d1 + C1 d2 in column C2 d1 + d2;
+        //      fftshift: out[(d + C/2) % C] = X[d]
+        cplx<float> *out = reinterpret_cast<cplx<float> *>(a.out) + plane * CELLS;
+        constexpr int HALF = C / 2, ROUNDS = (CELLS + NT - 1) / NT;
+#pragma unroll 4
+        for (int q = 0; q < ROUNDS; ++q) {
+            const int e = t + q * NT;
+            if (CELLS % NT == 0 || q + 1 < ROUNDS || e < CELLS) {
+                const int k = e / C, dd = e - k * C;
+                int d = dd - HALF;
+                if (d < 0) d += C;
+                const int k2 = k / S1, k1 = k - k2 * S1, d2 = d / C1, d1 = d - d2 * C1;
+                __builtin_nontemporal_store(lds[(S2 * k1 + k2) * Cp + C2 * d1 + d2], out + e);
+            }
+        }
+        phase_mark(a.clk, 6, tid);
+        if constexpr (!PERSIST) break;
+        item += gridDim.x;
+        if (item >= n_items) break;
+        plane = skip_block_plane(item, a.raw);
+        __syncthreads();        // the store has read the LDS plane: the next stash may overwrite it
     }
 }
 
@@ -288,7 +357,7 @@ inline int get_tw2_table(mmw_ctx *ctx, int N, int N1, const void **out) {
     return MMW_OK;
 }
 
-// [H][NBLK][8] coefficient table of dft_level_bigprime_ct, cached per context
+// cos(2 pi m / P), m = 0 .. P-1, then the P sines: the coefficient table of dft_level_bigprime_ct, cached per context
 inline int get_bigprime_table(mmw_ctx *ctx, int P, const void **out) {
     const auto key = std::make_tuple(201, P, 0);
     auto it = ctx->tables.find(key);
@@ -296,15 +365,12 @@ inline int get_bigprime_table(mmw_ctx *ctx, int P, const void **out) {
         *out = it->second;
         return MMW_OK;
     }
-    const int H = (P - 1) / 2, NBLK = (H + 1) / 4;
-    std::vector<float> h((size_t)H * NBLK * 8);
-    for (int j = 1; j <= H; ++j)
-        for (int b = 0; b < NBLK; ++b)
-            for (int q = 0; q < 4; ++q) {
-                const long double ang = 2.0L * M_PIl * (long double)(((long)j * (4 * b + q)) % P) / (long double)P;
-                h[((size_t)(j - 1) * NBLK + b) * 8 + q] = (float)cosl(ang);
-                h[((size_t)(j - 1) * NBLK + b) * 8 + 4 + q] = (float)sinl(ang);
-            }
+    std::vector<float> h(2 * (size_t)P);
+    for (int m = 0; m < P; ++m) {
+        const long double ang = 2.0L * M_PIl * (long double)m / (long double)P;
+        h[m] = (float)cosl(ang);
+        h[P + m] = (float)sinl(ang);
+    }
     void *d = nullptr;
     if (hipMalloc(&d, h.size() * sizeof(float)) != hipSuccess) return set_error(MMW_ERR_NOMEM, "hipMalloc for DFT coefficient table failed");
     MMW_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -336,11 +402,47 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
         MMW_TRY(get_bigprime_table(ctx, mixct::BIG_PRIME, &p));
         a.cs_big = (const float *)p;
     }
-    constexpr size_t lds_bytes = ((size_t)S * (C | 1) + S + C) * sizeof(cplx<float>);
-    auto kern = k_rd_mixed_ct<S, C, NT>;
+    constexpr bool big = S1 == mixct::BIG_PRIME || C1 == mixct::BIG_PRIME;
+    constexpr size_t lds_bytes = ((size_t)S * (C | 1) + S + C + (big ? mixct::BIG_PRIME : 0) + (S + C + 1) / 2) * sizeof(cplx<float>);
+    // persistent + next-plane prefetch where nothing else would overlap the load phase
+    static int persist_dflt = -1;       // persistent where only ONE one-plane workgroup would be resident per CU (LDS or registers)
+    if (persist_dflt < 0) {
+        int nb = 0;
+        MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_rd_mixed_ct<S, C, NT, false>), NT, lds_bytes));
+        persist_dflt = nb <= 1 ? 1 : 0;
+    }
+    const bool persist = rv.ntx <= 1 && (tune_int("MMW_MIXED_CT_PERSIST", -1) >= 0 ? tune_int("MMW_MIXED_CT_PERSIST", -1) : persist_dflt) != 0;
+    auto kern = persist ? k_rd_mixed_ct<S, C, NT, true> : k_rd_mixed_ct<S, C, NT, false>;
     if (lds_bytes > 64 * 1024)
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)skip_planes(planes, rv);
+    unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)skip_planes(planes, rv);
+    if (persist) {
+        static int per_cu = 0;          // residency by LDS AND registers (per shape: this function is a template)
+        if (!per_cu) {
+            int nb = 0;
+            MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), NT, lds_bytes));
+            per_cu = nb > 0 ? nb : 1;
+        }
+        const unsigned resident = (unsigned)((ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu) * per_cu);
+        if (grid > resident) grid = resident;
+    }
+    if (tune_int("MMW_PHASE_CLOCKS", 0)) {
+        // diagnostics: phase boundaries of workgroup 0 in shader clocks (marks 0..6 = start, load, range A, range B,
+        // Doppler A, Doppler B, store; 8, 9 = inside the big-prime level), printed to stderr
+        long long *d = nullptr, h[10] = {0};
+        MMW_HIP(hipMalloc((void **)&d, sizeof(h)));
+        MMW_HIP(hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
+        a.clk = d;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, ctx->stream, a);
+        MMW_HIP(hipStreamSynchronize(ctx->stream));
+        MMW_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+        MMW_HIP(hipFree(d));
+        std::fprintf(stderr, "rd_mixed_ct %dx%d NT=%d clocks:", S, C, NT);
+        for (int i = 1; i < 7; ++i) std::fprintf(stderr, " %lld", h[i] - h[i - 1]);
+        if (h[9]) std::fprintf(stderr, " | bigprime mfma %lld", h[9] - h[S1 == mixct::BIG_PRIME ? 1 : 3]);
+        std::fprintf(stderr, "\n");
+        return check_launch("rd_mixed_ct");
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, ctx->stream, a);
     return check_launch("rd_mixed_ct");
 }
