@@ -76,9 +76,11 @@ __device__ __forceinline__ bool chain_wait(unsigned *cnt, unsigned target, unsig
     }
 }
 // The eight pruned k1 passes + stores of one thread's two bins (shared by k_angle64 and k_angle64_sync).
-template <int VIN, bool MAG, bool NT>
+// ROWS (k_angle64_rows): the lane stores row a only if its pair lies in that row's line-aligned window of the wave.
+template <int VIN, bool MAG, bool NT, bool ROWS = false>
 __device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<float> (&xb)[VIN], void *__restrict__ out, long f,
-                                               long pairs_per_frame, long pair, int shift_off) {
+                                               long pairs_per_frame, long pair, int shift_off, int b16 = 0, int lane = 0,
+                                               bool pair_ok = true) {
     typedef cplx<float> C;
     static_for<8>([&](auto K1) {
         constexpr int k1 = decltype(K1)::value;
@@ -104,6 +106,12 @@ __device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<floa
             const int a = (k1 + 8 * k2 + shift_off) & 63;   // fftshift over the angle axis (shift_off = 32)
             const C va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
             const long o = (f * 64 + a) * pairs_per_frame + pair;
+            if constexpr (ROWS) {
+                // row a starts m cells past a cache-line boundary (m = a * bins mod 16; the + 32 of the fftshift drops out):
+                // this wave's aligned 112-cell window of the row begins m cells before its nominal base
+                const int lo = 8 - ((((k1 + 8 * k2) * b16) & 15) >> 1);
+                if (!(pair_ok && lane >= lo && lane < lo + 56)) return;
+            }
             if constexpr (MAG) {
                 // |.| as sqrt(x^2 + y^2): spectrum values are far from the float32 range limits, so hypotf's rescaling
                 // (and its register appetite, which spilled the persistent kernel) buys nothing; error <= 1.5 ulp
@@ -121,12 +129,21 @@ __device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<floa
 
 template <int VIN, bool MAG, bool NT, bool ZE>
 __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, void *__restrict__ out,
-                                                  long pairs_per_frame, AngleWin win, int shift_off) {
+                                                  long pairs_per_frame, AngleWin win, int shift_off, int n_frames) {
     typedef cplx<float> C;
-    // grid.x covers pairs of adjacent bins of one frame; grid.y = frame
-    const long pair = (long)blockIdx.x * 256 + threadIdx.x;
+    // n_frames == 0: grid.x covers pairs of adjacent bins of one frame; grid.y = frame.
+    // n_frames > 0 (rows of the output not 128-B aligned): grid.x = 8 * tiles, grid.y = groups of 8 frames, and workgroup
+    // x handles tile x / 8 of frame 8 y + x % 8.  Hardware dispatch is round-robin over the 8 XCDs, so ALL tiles of a
+    // frame run on one XCD: the cache lines that straddle two tiles' 4 KB pieces of an angle row then meet in that XCD's L2
+    // and leave as whole lines instead of two partial writes from two L2s (6300-bin rows: 4.3 -> TB/s, tools/angle_shape.py).
+    long f = blockIdx.y, tile = blockIdx.x;
+    if (n_frames > 0) {
+        f = (long)blockIdx.y * 8 + (blockIdx.x & 7);
+        tile = blockIdx.x >> 3;
+        if (f >= n_frames) return;
+    }
+    const long pair = tile * 256 + threadIdx.x;
     if (pair >= pairs_per_frame) return;
-    const long f = blockIdx.y;
     const f32x4 *src = rd + f * VIN * pairs_per_frame + pair;
     C xa[VIN], xb[VIN];
 #pragma unroll
@@ -142,6 +159,40 @@ __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, v
         xb[v] = C{t.z * h, t.w * h};
     }
     angle64_passes<VIN, MAG, NT>(xa, xb, out, f, pairs_per_frame, pair, shift_off);
+}
+
+// k_angle64_rows: k_angle64 for planes whose bin count is not a multiple of 16, i.e. whose angle rows [bins] c64 do not
+// start on 128-B lines (most shipped cfgs: 63 x 100, 63 x 70, 254 x 50 ...).  There a wave's 1 KB store instruction
+// straddles 9 lines instead of covering 8 (12 write requests per instruction instead of 8) and the store stream drops
+// from ~5.5 to ~4.3 TB/s (tools/angle_shape.py).  Here every WAVE computes 128 cells but stores, per row, the 112-cell
+// (7-line) window of them that is line aligned for THAT row; consecutive waves overlap by 16 cells (12.5 % more loads
+// and arithmetic, both far from their limits) and every store instruction writes whole lines.  Only the row ends share
+// a line with the next row (one per 50 KB).
+template <int VIN, bool ZE>
+__global__ __launch_bounds__(256) void k_angle64_rows(const f32x4 *__restrict__ rd, void *__restrict__ out,
+                                                       long pairs_per_frame, AngleWin win, int shift_off, int b16, int n_waves) {
+    typedef cplx<float> C;
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= n_waves) return;
+    const long f = blockIdx.y;
+    const long pair = wv * 56 - 8 + lane;           // cells 112 wv - 16 + 2 lane, + 1
+    const bool ok = pair >= 0 && pair < pairs_per_frame;
+    const f32x4 *src = rd + f * VIN * pairs_per_frame + (ok ? pair : 0);
+    C xa[VIN], xb[VIN];
+#pragma unroll
+    for (int v = 0; v < VIN; ++v) {
+        if (ZE && (v == 0 || v == VIN - 1)) {
+            xa[v] = C{0.f, 0.f};
+            xb[v] = C{0.f, 0.f};
+            continue;
+        }
+        const f32x4 t = src[(long)v * pairs_per_frame];
+        const float h = win.h[v];
+        xa[v] = C{t.x * h, t.y * h};
+        xb[v] = C{t.z * h, t.w * h};
+    }
+    angle64_passes<VIN, false, true, true>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, lane, ok);
 }
 
 // k_angle64_sync: the chain's device-synchronised angle stage (ChainSync above).  Persistent workgroups take
@@ -205,11 +256,22 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)F);
+    // frame-per-XCD mapping when the 4 KB pieces of an output row do not start on cache-line boundaries
+    const bool xcd_frames = (bins * (mag ? 4 : 8)) % 128 != 0 ? tune_int("MMW_ANGLE_XCD_FRAMES", 1) != 0 : tune_int("MMW_ANGLE_XCD_FRAMES", 0) == 2;
+    if (xcd_frames) grid = dim3(grid.x * 8, (unsigned)((F + 7) / 8));
+    const int nf_arg = xcd_frames ? F : 0;
     const bool nt = tune_int("MMW_ANGLE_NT", 1) != 0;
     const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f && tune_int("MMW_ANGLE_ZE", 1) != 0;
+    if (!mag && bins % 16 != 0 && tune_int("MMW_ANGLE_ROWS", 1)) {
+        const int n_waves = (int)((bins + 14 + 111) / 112);
+        dim3 g((unsigned)((n_waves + 3) / 4), (unsigned)F);
+        if (ze) hipLaunchKernelGGL((k_angle64_rows<VIN, true>), g, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, shift ? 32 : 0, (int)(bins & 15), n_waves);
+        else hipLaunchKernelGGL((k_angle64_rows<VIN, false>), g, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, shift ? 32 : 0, (int)(bins & 15), n_waves);
+        return check_launch("angle64_rows");
+    }
 #define MMW_ANGLE_LAUNCH(MAGV, NTV, ZEV) \
     hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV, ZEV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, \
-                       shift ? 32 : 0)
+                       shift ? 32 : 0, nf_arg)
     if (ze) {
         if (mag && nt) MMW_ANGLE_LAUNCH(true, true, true);
         else if (mag) MMW_ANGLE_LAUNCH(true, false, true);

@@ -1175,3 +1175,32 @@ def test_doppler_azimuth_entry_fused_range_mean(V, S, C, A, win, monkeypatch):
     assert L.mmw_doppler_azimuth(h, d_in.ptr, d_a.ptr, F, V, S, C, A, lo, hi, 1) == _lib.MMW_ERR_INVALID
     for b in (d_in, d_mag, d_a, d_b):
         b.free()
+
+
+@pytest.mark.parametrize("V,S,C", [(12, 63, 100), (8, 21, 10), (4, 25, 26), (12, 2, 5), (16, 7, 18), (12, 127, 2)])
+@pytest.mark.parametrize("flags", [0, _lib.ANGLE_NO_WINDOW | _lib.ANGLE_NO_SHIFT])
+def test_angle_rows_kernel_on_misaligned_rows(V, S, C, flags):
+    """k_angle64_rows (bins % 16 != 0: every wave stores a per-row line-aligned window of the cells it computed) against
+    numpy's FFT over the antenna axis (range_angle_resp_dbs_enhanced.py:175-196), several frames so that the frame
+    stride, the first / last wave of a row and rows with every misalignment (a * bins mod 16) are hit."""
+    ctx = _lib.default_context()
+    F, A, bins = 3, 64, S * C
+    assert bins % 16 != 0 and bins % 2 == 0
+    rng = np.random.default_rng(V * 1000 + bins)
+    rd = (rng.standard_normal((F, V, S, C)) + 1j * rng.standard_normal((F, V, S, C))).astype(np.complex64)
+    d_rd, d_out = ctx.alloc(rd.nbytes), ctx.alloc(F * A * bins * 8 + 256)
+    d_rd.upload(rd)
+    guard = np.full(32, 7.0 + 7.0j, np.complex64)           # nothing may be written past the last row
+    d_out.upload(guard, byte_offset=F * A * bins * 8)
+    _lib.check(ctx.lib.mmw_angle_fft(ctx.handle, d_rd.ptr, d_out.ptr, F, V, S, C, A, flags))
+    got = d_out.download((F, A, S, C), np.complex64)
+    np.testing.assert_array_equal(d_out.download((32,), np.complex64, byte_offset=F * A * bins * 8), guard)
+    x = rd.astype(np.complex128)
+    if not flags & _lib.ANGLE_NO_WINDOW:
+        x = x * np.hanning(V)[None, :, None, None]
+    ref = np.fft.fft(x, n=A, axis=1)
+    if not flags & _lib.ANGLE_NO_SHIFT:
+        ref = np.fft.fftshift(ref, axes=1)
+    assert rel_err(got, ref) <= SPEC_TOL
+    d_rd.free()
+    d_out.free()
