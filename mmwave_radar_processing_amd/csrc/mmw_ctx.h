@@ -58,6 +58,13 @@ enum TableKind { TAB_TWIDDLE = 0, TAB_HANN = 1, TAB_HAMMING = 2, TAB_DFTMAT = 3 
 
 constexpr int PIPE_RING_MAX = 4;      // deepest ring of RD chunks of the overlapped chain
 
+// tables of one chirp-z frequency list (mmw_czt.h), cached per context
+struct CztPlan {
+    std::vector<double> freq;
+    int n_used = 0, L = 0, n_seg = 0;
+    void *d_segs = nullptr, *d_tabs = nullptr;
+};
+
 struct PendingSpan {
     const char *family;
     hipEvent_t e0, e1;
@@ -98,6 +105,7 @@ struct mmw_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     std::vector<void *> owned;  // mmw_malloc'ed blocks still alive (freed at destroy)
+    std::vector<mmw::CztPlan> czt_plans;
 };
 
 namespace mmw {

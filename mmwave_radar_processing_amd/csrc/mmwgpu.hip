@@ -3,6 +3,7 @@
 #include "mmw_launch.h"
 #include "mmw_cfar.h"
 #include "mmw_misc.h"
+#include "mmw_czt.h"
 #include "mmw_beamform.h"
 
 #include <algorithm>
@@ -155,6 +156,10 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tables) (void)hipFree(kv.second);
+    for (auto &pl : ctx->czt_plans) {
+        (void)hipFree(pl.d_segs);
+        (void)hipFree(pl.d_tabs);
+    }
     for (void *p : ctx->owned) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
@@ -569,12 +574,17 @@ int mmw_doppler_azimuth_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, in
     char *d_rng = base + b_freq + b_tab;
     char *d_zoom = d_rng + up((size_t)chunk * f_rng);
     char *d_mag = d_zoom + up((size_t)chunk * f_zoom);
-    MMW_HIP(hipMemcpyAsync(d_freq, h_freq, (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MMW_HIP(hipStreamSynchronize(ctx->stream));     // h_freq is caller-owned host memory
-    const long tab_n = (long)n_used * M;
-    hipLaunchKernelGGL(k_zoom_table, dim3((unsigned)((tab_n + 255) / 256)), dim3(256), 0, ctx->stream, d_freq, d_tab,
-                       n_used, M);
-    MMW_TRY(check_launch("zoom_table"));
+    // chirp-z form (mmw_czt.h) unless the list has no usable plan; MMW_ZOOM_DIRECT=1 keeps the direct n_used x M table
+    const CztPlan *plan = nullptr;
+    if (czt_length(n_used) > 0 && !env_int("MMW_ZOOM_DIRECT", 0)) MMW_TRY(czt_plan(ctx, h_freq, M, n_used, &plan));
+    if (!plan) {
+        MMW_HIP(hipMemcpyAsync(d_freq, h_freq, (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        MMW_HIP(hipStreamSynchronize(ctx->stream));     // h_freq is caller-owned host memory
+        const long tab_n = (long)n_used * M;
+        hipLaunchKernelGGL(k_zoom_table, dim3((unsigned)((tab_n + 255) / 256)), dim3(256), 0, ctx->stream, d_freq, d_tab,
+                           n_used, M);
+        MMW_TRY(check_launch("zoom_table"));
+    }
     for (long f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = (int)((n_frames - f0 < chunk) ? n_frames - f0 : chunk);
         FftArgs a{};                                 // range FFT, Hann(S) x Hann(C) folded into the load
@@ -591,10 +601,24 @@ int mmw_doppler_azimuth_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, in
         a.scale = 1.0;
         MMW_TRY((launch_fft_axis<float, float>(ctx, a, S, false)));
         const long rows = (long)nf * V * Sk;
-        hipLaunchKernelGGL((k_zoom_rows<RB>), dim3((unsigned)((rows + RB - 1) / RB), (unsigned)((M + 255) / 256)), dim3(256),
-                           (size_t)RB * n_used * sizeof(float2), ctx->stream, (const float2 *)d_rng, d_tab,
-                           (float2 *)d_zoom, S, C, s_lo, Sk, n_used, M, rows);
-        MMW_TRY(check_launch("zoom_rows"));
+        if (plan) {
+            CztArgs z{};
+            z.x = (const float2 *)d_rng;
+            z.outer_stride = (long)S * C;
+            z.inner_stride = C;
+            z.elem_stride = 1;
+            z.s_lo = s_lo;
+            z.s_keep = Sk;
+            z.M = M;
+            z.rows = rows;
+            z.out = (float2 *)d_zoom;
+            MMW_TRY(launch_czt_rows(ctx, *plan, z));
+        } else {
+            hipLaunchKernelGGL((k_zoom_rows<RB>), dim3((unsigned)((rows + RB - 1) / RB), (unsigned)((M + 255) / 256)), dim3(256),
+                               (size_t)RB * n_used * sizeof(float2), ctx->stream, (const float2 *)d_rng, d_tab,
+                               (float2 *)d_zoom, S, C, s_lo, Sk, n_used, M, rows);
+            MMW_TRY(check_launch("zoom_rows"));
+        }
         // antenna window + zero-padded angle FFT + |.| on [nf][V][Sk][M] and the mean over the kept range bins
         MMW_TRY(angle_mean_impl(ctx, d_zoom, d_mag, up(angle_mean_work_bytes((int)chunk, V, Sk, M, A, Sk)), d_out + (size_t)f0 * M * A, nf, V, Sk, M,
                                 A, 0, Sk, flags));
@@ -972,10 +996,29 @@ int mmw_range_zoom(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames
     MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &hann));
     MMW_TRY(ensure_scratch(ctx, (size_t)n_frames * V * m * sizeof(float2)));
     // rows = (frame, antenna): x[row][i] = cube[frame][v][i][chirp]
-    hipLaunchKernelGGL(k_zoom_dft, dim3(n_frames * V), dim3(256), (size_t)S * sizeof(float2), ctx->stream,
-                       (const float2 *)d_cubes + chirp_idx, (long)S * C, (long)C, (const float *)hann,
-                       (float2 *)ctx->scratch, S, m, f0_cycles_per_sample, df_cycles_per_sample);
-    MMW_TRY(check_launch("zoom_dft"));
+    if (czt_length(S) > 0 && !env_int("MMW_ZOOM_DIRECT", 0)) {
+        std::vector<double> freq(m);
+        for (int k = 0; k < m; ++k) freq[k] = f0_cycles_per_sample + (double)k * df_cycles_per_sample;
+        const CztPlan *plan = nullptr;
+        MMW_TRY(czt_plan(ctx, freq.data(), m, S, &plan));
+        CztArgs z{};
+        z.x = (const float2 *)d_cubes + chirp_idx;
+        z.outer_stride = (long)S * C;
+        z.inner_stride = 0;
+        z.elem_stride = C;
+        z.s_lo = 0;
+        z.s_keep = 1;
+        z.win = (const float *)hann;
+        z.M = m;
+        z.rows = (long)n_frames * V;
+        z.out = (float2 *)ctx->scratch;
+        MMW_TRY(launch_czt_rows(ctx, *plan, z));
+    } else {
+        hipLaunchKernelGGL(k_zoom_dft, dim3(n_frames * V), dim3(256), (size_t)S * sizeof(float2), ctx->stream,
+                           (const float2 *)d_cubes + chirp_idx, (long)S * C, (long)C, (const float *)hann,
+                           (float2 *)ctx->scratch, S, m, f0_cycles_per_sample, df_cycles_per_sample);
+        MMW_TRY(check_launch("zoom_dft"));
+    }
     const long n = (long)n_frames * m;
     hipLaunchKernelGGL((k_mean_abs_over_v<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const cplx<float> *)ctx->scratch, d_out, n_frames, V, m);

@@ -1204,3 +1204,84 @@ def test_angle_rows_kernel_on_misaligned_rows(V, S, C, flags):
     assert rel_err(got, ref) <= SPEC_TOL
     d_rd.free()
     d_out.free()
+
+
+@pytest.mark.parametrize("V,S,C,n_used,kind", [(4, 32, 128, 128, "two_halves"), (4, 16, 64, 50, "long_run"), (4, 8, 320, 300, "l1024"),
+                                               (4, 16, 40, 40, "irregular"), (4, 16, 128, 127, "nan_runs")])
+def test_zoom_chirpz_against_direct_form(V, S, C, n_used, kind):
+    """mmw_doppler_azimuth_zoom evaluates the zoom transform by chirp-z (mmw_czt.h: uniform runs of the frequency list,
+    256- or 1024-point convolutions); MMW_ZOOM_DIRECT=1 keeps the direct n_used x M table of round 1.  Both against the
+    float64 sum, on lists that exercise run splitting, single-bin runs, NaN (zero-filled) bins and both FFT lengths."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, A = 2, 64
+    rng = np.random.default_rng(len(kind) * 100 + n_used)
+    if kind == "two_halves":
+        freq = np.concatenate((np.linspace(0.974, 1.0, 128, endpoint=False), np.linspace(0.0, 0.026, 128, endpoint=False)))
+    elif kind == "long_run":
+        freq = np.linspace(-0.3, 0.4, 500)                  # one run, split into pieces of 256 - 50 + 1 bins
+    elif kind == "l1024":
+        freq = np.linspace(0.1, 0.2, 200, endpoint=False)
+    elif kind == "irregular":
+        freq = np.sort(rng.uniform(-0.5, 0.5, 24))          # no two spacings equal: 2-bin and 1-bin runs
+    else:
+        freq = np.linspace(-0.1, 0.1, 90)
+        freq[:7] = np.nan
+        freq[40:43] = np.nan
+        freq[-1] = np.nan
+    M = freq.size
+    cubes = np.stack([synth.synth_cube(900 + f, (V, S, C)) for f in range(F)]).astype(np.complex64)
+    bufs = _lib.BufferSet(ctx)
+    d_in = bufs.get("in", cubes.nbytes)
+    d_in.upload(cubes)
+    d_out = bufs.get("out", F * M * A * 4)
+    fp = freq.ctypes.data_as(_lib.C.POINTER(_lib.C.c_double))
+    outs = {}
+    for mode in ("czt", "direct"):
+        if mode == "direct":
+            os.environ["MMW_ZOOM_DIRECT"] = "1"
+        try:
+            _lib.check(L.mmw_doppler_azimuth_zoom(h, d_in.ptr, d_out.ptr, F, V, S, C, A, 1, S - 2, n_used, fp, M, 0))
+        finally:
+            os.environ.pop("MMW_ZOOM_DIRECT", None)
+        outs[mode] = d_out.download((F, M, A), np.float32)
+    nan = np.isnan(freq)
+    Z = np.exp(-2j * np.pi * np.outer(np.where(nan, 0, freq), np.arange(n_used)))
+    Z[nan] = 0
+    for f in range(F):
+        x = cubes[f].astype(complex) * np.hanning(S)[None, :, None] * np.hanning(C)[None, None, :] * np.hanning(V)[:, None, None]
+        r = np.fft.fft(x, axis=1)[:, 1:S - 2, :n_used]
+        y = np.einsum("kc,vsc->skv", Z, r)
+        ref = np.mean(np.abs(np.fft.fftshift(np.fft.fft(y, n=A, axis=2), axes=2)), axis=0)
+        for mode in outs:
+            assert rel_err(outs[mode][f], ref) <= SPEC_TOL, mode
+        assert np.all(outs["czt"][f][nan] == 0)
+    bufs.free()
+
+
+def test_range_zoom_chirpz_against_float64_sum():
+    """mmw_range_zoom: 256 samples -> 1024-point chirp-z against the float64 direct sum (range_resp.py:59-102)."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, V, S, C, m = 2, 12, 256, 16, 300
+    cubes = np.stack([synth.synth_cube(70 + f, (V, S, C)) for f in range(F)]).astype(np.complex64)
+    d_in, d_out = ctx.alloc(cubes.nbytes), ctx.alloc(F * m * 4)
+    d_in.upload(cubes)
+    f0, df = 0.0123, 0.0007
+    outs = {}
+    for mode in ("czt", "direct"):
+        if mode == "direct":
+            os.environ["MMW_ZOOM_DIRECT"] = "1"
+        try:
+            _lib.check(L.mmw_range_zoom(h, d_in.ptr, d_out.ptr, F, V, S, C, 5, m, f0, df))
+        finally:
+            os.environ.pop("MMW_ZOOM_DIRECT", None)
+        outs[mode] = d_out.download((F, m), np.float32)
+    Z = np.exp(-2j * np.pi * np.outer(f0 + df * np.arange(m), np.arange(S)))
+    for f in range(F):
+        x = cubes[f][:, :, 5].astype(complex) * np.hanning(S)[None, :]
+        ref = np.mean(np.abs(x @ Z.T), axis=0)
+        for mode in outs:
+            assert rel_err(outs[mode][f], ref) <= SPEC_TOL, mode
+    d_in.free()
+    d_out.free()

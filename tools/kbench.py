@@ -149,6 +149,11 @@ def main():
         8.0 * Fz * V * S * C * 2 * C)                          # zoom-transform flops -> GFLOP/s
     if "dopaz_zoom_256bins" in res:
         res["dopaz_zoom_256bins"]["us_per_frame"] = round(1e3 * res["dopaz_zoom_256bins"]["ms"] / Fz, 3)
+    d_rz = ctx.alloc(Fz * 256 * 4)
+    run("range_zoom_256bins", lambda: _lib.check(L.mmw_range_zoom(ctx.handle, d_in.ptr, d_rz.ptr, Fz, V, S, C, 0, 256, 0.01, 0.0005)),
+        Fz * V * S * 8)
+    if "range_zoom_256bins" in res:
+        res["range_zoom_256bins"]["us_per_frame"] = round(1e3 * res["range_zoom_256bins"]["ms"] / Fz, 3)
     # ---- beamformers (BASELINE config 4 shapes): complex GEMM on f32 MFMA, MVDR covariance on f64 MFMA.
     # "GBs" of these entries is GFLOP/s of USEFUL flops (8 per complex multiply-add); "frac_of_mfma_peak" divides by the
     # matrix-core peak measured on this device by mmw_diag_mfma_peak (the guide lists 157.3 TF f32 MFMA, nothing for f64).
