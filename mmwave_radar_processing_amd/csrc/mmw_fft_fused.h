@@ -200,9 +200,10 @@ __global__ __launch_bounds__(256) void k_angle64_rows(const f32x4 *__restrict__ 
 // from the ring with sc1 loads, release the slot and run the same passes + streaming stores as k_angle64.
 // Register budget: 3 waves per SIMD (168 VGPRs) for the shapes that fit it -- the headline 12-antenna windowed case
 // among them -- and 2 where the unrolled passes need more (a spill costs more than the lost wave).
-template <int VIN, bool MAG, bool ZE>
-__global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG) || VIN <= 4 ? 3 : 2) void k_angle64_sync(const void *__restrict__ ring, void *__restrict__ out, long pairs_per_frame,
-                                                       AngleWin win, int shift_off, ChainSync cs) {
+// ROWS: the line-aligned row windows of k_angle64_rows (bins % 16 != 0): a tile is 4 waves x 112 stored cells.
+template <int VIN, bool MAG, bool ZE, bool ROWS = false>
+__global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4 ? 3 : 2) void k_angle64_sync(const void *__restrict__ ring, void *__restrict__ out, long pairs_per_frame,
+                                                       AngleWin win, int shift_off, ChainSync cs, int b16, int n_waves) {
     typedef cplx<float> C;
     __shared__ int sh[4];       // [0] ticket, [1] abort
     const int tid = threadIdx.x;
@@ -229,8 +230,15 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG) || VIN <= 4 ? 3 : 2)
         __syncthreads();    // between the poll and EVERY load of the published bytes
         if (__builtin_amdgcn_readfirstlane(sh[1])) return;
         prev_slot = slot;
-        const long pair = (long)tile * 256 + tid;
-        if (pair < pairs_per_frame) {
+        long pair = (long)tile * 256 + tid;
+        bool ok = pair < pairs_per_frame, run = ok;
+        if constexpr (ROWS) {
+            const long wv = (long)tile * 4 + (tid >> 6);
+            pair = wv * 56 - 8 + (tid & 63);            // cells 112 wv - 16 + 2 lane, + 1
+            ok = pair >= 0 && pair < pairs_per_frame;
+            run = wv < n_waves;
+        }
+        if (run) {
             C xa[VIN], xb[VIN];
 #pragma unroll
             for (int v = 0; v < VIN; ++v) {
@@ -239,13 +247,13 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG) || VIN <= 4 ? 3 : 2)
                     xb[v] = C{0.f, 0.f};
                     continue;
                 }
-                const unsigned off = (unsigned)((((long)slot * VIN + v) * pairs_per_frame + pair) * 16);
+                const unsigned off = (unsigned)((((long)slot * VIN + v) * pairs_per_frame + (ok ? pair : 0)) * 16);
                 const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
                 const float h = win.h[v];
                 xa[v] = C{t.x * h, t.y * h};
                 xb[v] = C{t.z * h, t.w * h};
             }
-            angle64_passes<VIN, MAG, true>(xa, xb, out, f, pairs_per_frame, pair, shift_off);
+            angle64_passes<VIN, MAG, true, ROWS>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, tid & 63, ok);
         }
     }
 }
@@ -287,6 +295,13 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     return check_launch("angle64");
 }
 
+// angle work items per frame of the device-synchronised chain
+inline bool angle_sync_rows(long bins, bool mag) { return !mag && bins % 16 != 0 && tune_int("MMW_ANGLE_ROWS", 1) != 0; }
+inline int angle_sync_tiles(long bins, bool mag) {
+    if (angle_sync_rows(bins, mag)) return (int)(((bins + 14 + 111) / 112 + 3) / 4);
+    return (int)((bins / 2 + 255) / 256);
+}
+
 template <int VIN>
 int launch_angle64_sync(mmw_ctx *ctx, const void *ring, void *out, long bins, bool mag, const float *h, bool shift,
                         ChainSync cs, int grid) {
@@ -294,9 +309,15 @@ int launch_angle64_sync(mmw_ctx *ctx, const void *ring, void *out, long bins, bo
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f;
+    if (angle_sync_rows(bins, mag)) {       // cs.tiles was sized for this variant by angle_sync_tiles()
+        const int n_waves = (int)((bins + 14 + 111) / 112);
+        if (ze) hipLaunchKernelGGL((k_angle64_sync<VIN, false, true, true>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
+        else hipLaunchKernelGGL((k_angle64_sync<VIN, false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
+        return check_launch("angle64_sync_rows");
+    }
 #define MMW_ANGLE_SYNC(MAGV, ZEV) \
     hipLaunchKernelGGL((k_angle64_sync<VIN, MAGV, ZEV>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, \
-                       shift ? 32 : 0, cs)
+                       shift ? 32 : 0, cs, 0, 0)
     if (ze) {
         if (mag) MMW_ANGLE_SYNC(true, true);
         else MMW_ANGLE_SYNC(false, true);

@@ -53,6 +53,11 @@ constexpr int threads_for(int S, int C) {
 }
 }  // namespace mixct
 
+constexpr size_t mixct_lds_bytes(int S, int C) {     // plane, inter-level twiddles, big-prime table, Hann tables, SYNC control words
+    const bool big = mixct::best_n1(S) == mixct::BIG_PRIME || mixct::best_n1(C) == mixct::BIG_PRIME;
+    return ((size_t)S * (C | 1) + S + C + (big ? mixct::BIG_PRIME : 0) + (S + C + 1) / 2) * sizeof(cplx<float>) + 16;
+}
+
 struct RdMixedCtArgs {
     const void *in;             // complex64 planes
     void *out;                  // complex64 planes
@@ -63,6 +68,7 @@ struct RdMixedCtArgs {
     RawView raw;
     long planes;
     long long *clk;             // diagnostics (MMW_PHASE_CLOCKS=1): s_memtime at the phase boundaries of workgroup 0
+    ChainSync cs;               // MODE 2: the chain's device-synchronised hand-over (mmw_fft_fused.h); `out` is the ring
 };
 
 __device__ __forceinline__ void phase_mark(long long *clk, int i, int tid) {
@@ -182,8 +188,13 @@ __device__ __forceinline__ void dft_level_any_ct(cplx<float> *lds, const cplx<fl
 // and the NEXT plane's global loads are issued into registers before this plane's levels run, so the HBM latency of the
 // load phase (~10 k of the 20..50 k clocks of a plane when the LDS holds only one or two planes per CU, phase clocks
 // above) hides behind the arithmetic instead of serialising with it.
-template <int S, int C, int NT, bool PERSIST>
+// MODE 2 (SYNC): the producer side of the device-synchronised chain for these shapes, same protocol as the 256 x 128
+// kernel (k_rd_fused_256x128_persist<SYNC>): items (frame, live antenna) from a ticket counter, the output plane goes to
+// the ring slot of its frame with sc1 (write-through) stores once the slot's previous frame has been consumed, every
+// storing wave drains its stores, and one lane bumps the slot's counter after the workgroup barrier.
+template <int S, int C, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
+    constexpr bool PERSIST = MODE >= 1, SYNC = MODE == 2;
     constexpr int S1 = mixct::best_n1(S), S2 = S / S1, C1 = mixct::best_n1(C), C2 = C / C1;
     constexpr int Cp = C | 1, CELLS = S * C;
     static_assert(S1 > 0 && C1 > 0, "no factorisation within the register-resident radices");
@@ -194,6 +205,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     constexpr bool BIG = S1 == mixct::BIG_PRIME || C1 == mixct::BIG_PRIME;
     // Hann tables in the LDS: a global load in the plane loop would wait (in-order vmcnt) for the previous plane's stores
     float *win_s = cst + (BIG ? 2 * mixct::BIG_PRIME : 0), *win_c = win_s + S;
+    int *lds_ctl = reinterpret_cast<int *>(win_c + C);                 // SYNC: [0] / [1] tickets (double buffered), [2] abort
     const int tid = threadIdx.x;
     const bool raw = !PERSIST && a.raw.ntx > 1;
     const int ntx = raw ? a.raw.ntx : 1;
@@ -242,14 +254,30 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         }
     };
     const cplx<float> *in_base = reinterpret_cast<const cplx<float> *>(a.in);
+    const ChainSync &cs = a.cs;
     long item = blockIdx.x;
-    const long n_items = PERSIST ? skip_planes(a.planes, a.raw) : 0;
+    const long n_items = SYNC ? (long)cs.n_frames * cs.v_live : (PERSIST ? skip_planes(a.planes, a.raw) : 0);
+    // SYNC: item -> input plane (the end antennas are skipped when the chain drops them)
+    auto sync_plane = [&](long it) {
+        const long f = it / cs.v_live;
+        return f * cs.V + (it - f * cs.v_live) + (cs.vskip > 2 ? 1 : 0);
+    };
     long plane;
-    if (raw) {
+    if constexpr (SYNC) {
+        if (tid == 0) {
+            lds_ctl[0] = (int)(__hip_atomic_fetch_add(cs.ctl + CTL_RD_TICKET, 1u, MMW_RLX_AGENT) - cs.rd_base);
+            lds_ctl[2] = 0;
+        }
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(lds_ctl[0]);
+        if (item >= n_items) return;
+        plane = sync_plane(item);
+    } else if (raw) {
         plane = raw_block_plane(blockIdx.x, a.planes, a.raw);
         if (plane < 0 || skip_raw_plane(plane, a.raw)) return;
     } else plane = skip_block_plane(item, a.raw);
     if (PERSIST || (PAIRED && !raw)) fetch(in_base + plane * a.in_plane_stride);
+    int iter = 0;
     if constexpr (S2 > 1)
         for (int i = tid; i < S; i += NT) tw_s[i] = a.tw2_s[i];
     if constexpr (C2 > 1)
@@ -265,6 +293,22 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         int t = tid;
         if constexpr (PERSIST) asm volatile("" : "+v"(t));
         phase_mark(a.clk, 0, tid);
+        // SYNC: ring slot of this plane's frame; thread 0 reads the slot's consumer counter and draws the next ticket now,
+        // un-waited -- both values are needed only after the first level
+        int slot = 0;
+        long ring_plane = 0;
+        unsigned free_target = 0, free_seen = 0, next_ticket = 0;
+        if constexpr (SYNC) {
+            const long f = item / cs.v_live;
+            const unsigned g = cs.s0 + (unsigned)f;
+            slot = (int)(g % (unsigned)cs.ring);
+            free_target = (cs.u0 + g / (unsigned)cs.ring) * (unsigned)cs.tiles;
+            ring_plane = (long)slot * cs.V + (plane - f * cs.V);
+            if (tid == 0) {
+                free_seen = __hip_atomic_load(cs.ctl + CTL_CNT + CTL_RING_MAX + slot, MMW_RLX_AGENT);
+                next_ticket = __hip_atomic_fetch_add(cs.ctl + CTL_RD_TICKET, 1u, MMW_RLX_AGENT) - cs.rd_base;
+            }
+        }
         // ---- load + windows
         if (!PERSIST && (!PAIRED || raw)) {
             // element loads (odd C, or the raw cube's tx-strided view): a few at a time, straight into the LDS
@@ -280,14 +324,22 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
             }
         } else
             stash(t);
-        if constexpr (PERSIST) {
+        if constexpr (PERSIST && !SYNC) {
             if (item + gridDim.x < n_items) fetch(in_base + skip_block_plane(item + gridDim.x, a.raw) * a.in_plane_stride);
         }
         __syncthreads();
         phase_mark(a.clk, 1, tid);
         // ---- range axis: sample s = S2 n1 + n2 lives in row s.  A: groups (column, n2), radix S1; B: groups (column, k1), radix S2
         dft_level_any_ct<S1, NT, C, 1, S2, Cp, S2 * Cp, (S2 > 1)>(lds, tw_s, cst, t, a.clk);
+        if constexpr (SYNC) {
+            if (tid == 0) lds_ctl[(iter + 1) & 1] = (int)next_ticket;      // the other waves learn it at this barrier
+        }
         __syncthreads();
+        long next_item = 0;
+        if constexpr (SYNC) {
+            next_item = __builtin_amdgcn_readfirstlane(lds_ctl[(iter + 1) & 1]);
+            if (next_item < n_items) fetch(in_base + sync_plane(next_item) * a.in_plane_stride);    // in flight behind the levels
+        }
         phase_mark(a.clk, 2, tid);
         if constexpr (S2 > 1) {
             dft_level_ct<S2, NT, C, 1, S1, S2 * Cp, Cp, false>(lds, nullptr, t);
@@ -306,6 +358,17 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         // ---- store: range bin k = k1 + S1 k2 sits in row S2 k1 + k2, Doppler bin d = d1 + C1 d2 in column C2 d1 + d2;
         //      fftshift: out[(d + C/2) % C] = X[d]
         cplx<float> *out = reinterpret_cast<cplx<float> *>(a.out) + plane * CELLS;
+        [[maybe_unused]] auto ring_rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, 0x00020000);
+        [[maybe_unused]] unsigned ring_soff = 0;
+        if constexpr (SYNC) {
+            // the slot's previous frame must have been consumed before the first store
+            if (tid == 0 && !chain_wait(cs.ctl + CTL_CNT + CTL_RING_MAX + slot, free_target, free_seen, cs.ctl, cs.timeout, cs.naps_rd))
+                lds_ctl[2] = 1;
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(lds_ctl[2])) return;         // timed out / aborted: no stores, everybody leaves
+            ring_rs = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)cs.ring * (unsigned)cs.V * (unsigned)(CELLS * 8)), 0x00020000);
+            ring_soff = (unsigned)ring_plane * (unsigned)(CELLS * 8);
+        }
         constexpr int HALF = C / 2, ROUNDS = (CELLS + NT - 1) / NT;
 #pragma unroll 4
         for (int q = 0; q < ROUNDS; ++q) {
@@ -315,11 +378,24 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
                 int d = dd - HALF;
                 if (d < 0) d += C;
                 const int k2 = k / S1, k1 = k - k2 * S1, d2 = d / C1, d1 = d - d2 * C1;
-                __builtin_nontemporal_store(lds[(S2 * k1 + k2) * Cp + C2 * d1 + d2], out + e);
+                const cplx<float> v = lds[(S2 * k1 + k2) * Cp + C2 * d1 + d2];
+                if constexpr (SYNC)     // sc1 (write-through, aux = 16): plane base in the scalar offset, lane part in voffset
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ring_rs, (unsigned)e * 8u, ring_soff, 16);
+                else __builtin_nontemporal_store(v, out + e);
             }
         }
         phase_mark(a.clk, 6, tid);
         if constexpr (!PERSIST) break;
+        if constexpr (SYNC) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its stores ...
+            __syncthreads();                                         // ... before one lane publishes the plane
+            if (tid == 0) __hip_atomic_fetch_add(cs.ctl + CTL_CNT + slot, 1u, MMW_RLX_AGENT);
+            item = next_item;
+            ++iter;
+            if (item >= n_items) break;
+            plane = sync_plane(item);
+            continue;           // (the barrier above also covers the LDS reuse)
+        }
         item += gridDim.x;
         if (item >= n_items) break;
         plane = skip_block_plane(item, a.raw);
@@ -380,8 +456,11 @@ inline int get_bigprime_table(mmw_ctx *ctx, int P, const void **out) {
     return MMW_OK;
 }
 
+// cs != nullptr: the device-synchronised producer (MODE 2) on sync_cus CUs; *sync_grid returns the workgroups launched
+// (each draws one ticket past the end, the host mirrors that in its counter base).  sync_grid only: just report the grid.
 template <int S, int C>
-int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, RawView rv) {
+int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, RawView rv,
+                          const ChainSync *cs = nullptr, int sync_cus = 0, int *sync_grid = nullptr, bool query_only = false) {
     constexpr int NT = mixct::threads_for(S, C), S1 = mixct::best_n1(S), C1 = mixct::best_n1(C);
     RdMixedCtArgs a{};
     a.in = d_in;
@@ -402,17 +481,34 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
         MMW_TRY(get_bigprime_table(ctx, mixct::BIG_PRIME, &p));
         a.cs_big = (const float *)p;
     }
-    constexpr bool big = S1 == mixct::BIG_PRIME || C1 == mixct::BIG_PRIME;
-    constexpr size_t lds_bytes = ((size_t)S * (C | 1) + S + C + (big ? mixct::BIG_PRIME : 0) + (S + C + 1) / 2) * sizeof(cplx<float>);
+    constexpr size_t lds_bytes = mixct_lds_bytes(S, C);
+    if (cs || query_only) {
+        auto kern = k_rd_mixed_ct<S, C, NT, 2>;
+        static int per_cu = 0;
+        if (!per_cu) {
+            if (lds_bytes > 64 * 1024)
+                MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            int nb = 0;
+            MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), NT, lds_bytes));
+            per_cu = nb > 0 ? nb : 1;
+        }
+        int grid = sync_cus * per_cu;
+        if (grid > planes) grid = planes;
+        if (sync_grid) *sync_grid = grid;
+        if (query_only) return MMW_OK;
+        a.cs = *cs;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds_bytes, ctx->stream, a);
+        return check_launch("rd_mixed_ct_sync");
+    }
     // persistent + next-plane prefetch where nothing else would overlap the load phase
     static int persist_dflt = -1;       // persistent where only ONE one-plane workgroup would be resident per CU (LDS or registers)
     if (persist_dflt < 0) {
         int nb = 0;
-        MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_rd_mixed_ct<S, C, NT, false>), NT, lds_bytes));
+        MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_rd_mixed_ct<S, C, NT, 0>), NT, lds_bytes));
         persist_dflt = nb <= 1 ? 1 : 0;
     }
     const bool persist = rv.ntx <= 1 && (tune_int("MMW_MIXED_CT_PERSIST", -1) >= 0 ? tune_int("MMW_MIXED_CT_PERSIST", -1) : persist_dflt) != 0;
-    auto kern = persist ? k_rd_mixed_ct<S, C, NT, true> : k_rd_mixed_ct<S, C, NT, false>;
+    auto kern = persist ? k_rd_mixed_ct<S, C, NT, 1> : k_rd_mixed_ct<S, C, NT, 0>;
     if (lds_bytes > 64 * 1024)
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)skip_planes(planes, rv);
@@ -456,8 +552,9 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
 #define MMW_MIXED_CT_LIST MMW_MIXED_CT_SHAPES_B
 #define MMW_MIXED_CT_FN launch_rd_mixed_ct_b
 #endif
-int MMW_MIXED_CT_FN(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv) {
-#define X(s, c) if (S == s && C == c) return launch_rd_mixed_ct_sc<s, c>(ctx, d_in, in_plane_stride, d_out, planes, rv);
+int MMW_MIXED_CT_FN(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
+                    const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only) {
+#define X(s, c) if (S == s && C == c) return launch_rd_mixed_ct_sc<s, c>(ctx, d_in, in_plane_stride, d_out, planes, rv, cs, sync_cus, sync_grid, query_only);
     MMW_MIXED_CT_LIST(X)
 #undef X
     return MMW_ERR_UNSUPPORTED;
@@ -465,7 +562,8 @@ int MMW_MIXED_CT_FN(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
 #endif
 
 #ifdef MMW_TU_MIXED_CT_A
-int launch_rd_mixed_ct_b(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv);
+int launch_rd_mixed_ct_b(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
+                         const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only);
 bool rd_mixed_ct_supported(int S, int C) {
 #define X(s, c) if (S == s && C == c) return true;
     MMW_MIXED_CT_SHAPES_A(X)
@@ -473,9 +571,10 @@ bool rd_mixed_ct_supported(int S, int C) {
 #undef X
     return false;
 }
-int launch_rd_mixed_ct(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv) {
-    int rc = launch_rd_mixed_ct_a(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv);
-    if (rc == MMW_ERR_UNSUPPORTED) rc = launch_rd_mixed_ct_b(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv);
+int launch_rd_mixed_ct(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
+                       const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only) {
+    int rc = launch_rd_mixed_ct_a(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only);
+    if (rc == MMW_ERR_UNSUPPORTED) rc = launch_rd_mixed_ct_b(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only);
     if (rc == MMW_ERR_UNSUPPORTED) return set_error(MMW_ERR_UNSUPPORTED, "no compile-time mixed-radix kernel for %dx%d", S, C);
     return rc;
 }

@@ -710,8 +710,13 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     const int v_live = p.vskip > 2 ? V - 2 : V;
     // CU split: half the chip each.  The angle stage is bound by HBM writes and needs ~128 CUs to saturate them (a CU
     // sustains ~44 GB/s of stores); the range-Doppler stage keeps up from 112 CUs on (sweep in DESIGN.md)
-    p.rd_cus = env_int("MMW_RD_CUS", ctx->num_cu / 2);
-    if (p.rd_cus < 0 || p.rd_cus >= ctx->num_cu) p.rd_cus = ctx->num_cu / 2;     // 0: unmasked queues
+    // Mixed-radix planes above 80 KB leave ONE range-Doppler workgroup per CU and are arithmetic bound: 5/8 of the chip
+    // (tools/chain_modes.sh: 254 x 50, 100 x 100, 120 x 126 are 6-25 % faster at 160 than at 128 CUs; the angle stage
+    // still saturates its store stream from the other 96).
+    const bool heavy_rd = !fused_rd_ok(S, C) && (size_t)S * (C | 1) * sizeof(cplx<float>) > 80 * 1024;
+    const int rd_cus_dflt = heavy_rd ? ctx->num_cu * 5 / 8 : ctx->num_cu / 2;
+    p.rd_cus = env_int("MMW_RD_CUS", rd_cus_dflt);
+    if (p.rd_cus < 0 || p.rd_cus >= ctx->num_cu) p.rd_cus = rd_cus_dflt;         // 0: unmasked queues
     p.ring = std::max(2, std::min(env_int("MMW_CHAIN_RING", 3), (int)PIPE_RING_MAX));
     // chunk: whole RD waves (rd_cus planes each) and `ring` chunks of live RD planes within ~250 MB of cache
     const size_t live_bytes = (size_t)v_live * S * C * sizeof(cplx<float>);
@@ -732,9 +737,10 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // Device-synchronised form (256 x 128 planes): needs the two disjoint CU sets, because persistent angle workgroups
     // that filled every CU would keep the range-Doppler workgroups they wait for from ever becoming resident.
     const char *mode = std::getenv("MMW_CHAIN_MODE");
-    (void)raw;
     // (windowed chains only: the un-windowed angle variants of the persistent kernel exceed its register budget)
-    p.sync = p.pipelined && fused_rd_ok(S, C) && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
+    const bool sync_shape = fused_rd_ok(S, C) || (!raw && rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0) &&
+                                                   tune_int("MMW_MIXED_CT_SYNC", 1));
+    p.sync = p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
     // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
     p.ring_frames = env_int("MMW_CHAIN_RING_FRAMES", (int)((120u << 20) / live_bytes));
@@ -749,7 +755,8 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
                         int S, int C, int flags) {
     const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
     const long bins = (long)S * C;
-    const int tiles = (int)((bins / 2 + 255) / 256), v_live = plan.vskip > 2 ? V - 2 : V;
+    const bool mag_out = (flags & MMW_ANGLE_MAGNITUDE) != 0;
+    const int tiles = angle_sync_tiles(bins, mag_out), v_live = plan.vskip > 2 ? V - 2 : V;
     MMW_REQUIRE((long)n_frames * std::max(tiles, v_live) < (1L << 30), "too many frames for one chain call");
     if (ensure_pipe_queues(ctx, plan.rd_cus) != MMW_OK) return MMW_ERR_UNSUPPORTED;
     MMW_TRY(ensure_scratch(ctx, (size_t)plan.ring_frames * cube_bytes));
@@ -801,7 +808,10 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     cs.naps_rd = std::max(0, env_int("MMW_SYNC_NAPS_RD", 32));
     cs.naps_ang = std::max(0, env_int("MMW_SYNC_NAPS_ANG", 4));
     const int n_rd_items = n_frames * v_live, n_ang_items = n_frames * tiles;
-    const int rd_grid = std::min(plan.rd_cus, n_rd_items);
+    const bool fused = fused_rd_ok(S, C);
+    int rd_grid = std::min(plan.rd_cus, n_rd_items);
+    if (!fused)     // compile-time mixed-radix producer: several workgroups per CU where they fit
+        MMW_TRY(launch_rd_mixed_ct(ctx, nullptr, 0, nullptr, n_rd_items, S, C, RawView{1, 0}, nullptr, plan.rd_cus, &rd_grid, true));
     const int ang_grid = std::min((ctx->num_cu - plan.rd_cus) * std::max(1, tune_int("MMW_ANGLE_WGS_PER_CU", 3)), n_ang_items);
     hipStream_t main_stream = ctx->stream;
     MMW_HIP(hipEventRecord(ctx->pipe_begin, main_stream));
@@ -822,7 +832,8 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     {
         ctx->stream = ctx->q_rd;
         ProfScope ps(ctx, "rd");
-        rc = launch_rd_fused_sync(ctx, d_cubes, ctx->scratch, n_rd_items, cs, rd_grid);
+        if (fused) rc = launch_rd_fused_sync(ctx, d_cubes, ctx->scratch, n_rd_items, cs, rd_grid);
+        else rc = launch_rd_mixed_ct(ctx, d_cubes, (long)S * C, ctx->scratch, n_rd_items, S, C, RawView{1, 0}, &cs, plan.rd_cus, &rd_grid);
     }
     if (rc == MMW_OK) {
         ctx->stream = ctx->q_ang;

@@ -1285,3 +1285,49 @@ def test_range_zoom_chirpz_against_float64_sum():
             assert rel_err(outs[mode][f], ref) <= SPEC_TOL, mode
     d_in.free()
     d_out.free()
+
+
+@pytest.mark.parametrize("S,C,F", [(63, 100, 700), (254, 50, 150), (64, 40, 900), (63, 127, 200), (100, 100, 300)])
+def test_device_synchronised_chain_on_shipped_cfg_shapes(monkeypatch, S, C, F):
+    """The device-synchronised chain with the compile-time mixed-radix range-Doppler producer (k_rd_mixed_ct MODE 2) and,
+    where the angle rows are not line aligned, the row-window consumer (k_angle64_sync ROWS): serial vs events vs sync
+    agree to float32 rounding, sync is bit-identical with itself for any batch length, frame 0 / last match the oracle.
+    63 x 127 has an odd bin count (no fused angle kernel): it must stay off the device-synchronised schedule."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    V, A = 12, 64
+    d_in = ctx.alloc(F * V * S * C * 8)
+    d_out = ctx.alloc(F * A * S * C * 8)
+    _lib.check(L.mmw_synth_cubes(h, d_in.ptr, F, V, S, C, 777, 6, 30.0))
+
+    def run(mode, n_frames, out):
+        monkeypatch.setenv("MMW_CHAIN_PIPELINE", "0" if mode == "serial" else "1")
+        monkeypatch.setenv("MMW_CHAIN_MODE", "events" if mode == "events" else "sync")
+        plan = (_lib.C.c_int * 8)()
+        _lib.check(L.mmw_diag_chain_plan(h, n_frames, V, S, C, A, 0, plan))
+        _lib.check(L.mmw_chain3d(h, d_in.ptr, None, out.ptr, n_frames, V, S, C, A, 0))
+        return bool(plan[0]), bool(plan[6])
+
+    run("serial", F, d_out)
+    ref = d_out.download((F, A, S, C), np.complex64)
+    for f in (0, F - 1):
+        cube = d_in.download((V, S, C), np.complex64, byte_offset=f * V * S * C * 8)
+        assert rel_err(ref[f], O.fft3d_windowed(cube, A)) <= SPEC_TOL
+    odd = (S * C) % 2 == 1
+    d_out.zero()
+    pipelined, sync = run("sync", F, d_out)
+    assert (pipelined, sync) == ((True, False) if odd else (True, True))     # pipelining is forced on; sync needs the fused angle kernel
+    got = d_out.download((F, A, S, C), np.complex64)
+    assert cross_schedule_dev(got, ref) <= CROSS_SCHEDULE_TOL
+    if not odd:
+        d_out.zero()
+        run("sync", 7, d_out)               # shorter than the ring, straight after the long call
+        run("sync", F // 3, d_out)
+        np.testing.assert_array_equal(d_out.download((F // 3, A, S, C), np.complex64), got[:F // 3])
+        d_out.zero()
+        assert run("events", F, d_out) == (True, False)
+        assert cross_schedule_dev(d_out.download((F, A, S, C), np.complex64), ref) <= CROSS_SCHEDULE_TOL
+        run("sync", F, d_out)
+        np.testing.assert_array_equal(d_out.download((F, A, S, C), np.complex64), got)
+    d_in.free()
+    d_out.free()
