@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
 // the non-power-of-two planes of the shipped cfgs (tests/golden/cfg_scalars.json) that need no prime radix above 20
 // (63 x 115 keeps the run-time kernel: 115 = 23 * 5)
 #define MMW_MIXED_CT_SHAPES_A(X) X(63, 70) X(63, 100) X(64, 40) X(70, 40) X(90, 80) X(100, 30) X(254, 50) X(127, 32)
-#define MMW_MIXED_CT_SHAPES_B(X) X(90, 100) X(100, 100) X(120, 126) X(130, 50) X(200, 40) X(63, 127)
+#define MMW_MIXED_CT_SHAPES_B(X) X(90, 100) X(100, 100) X(120, 126) X(130, 50) X(200, 40) X(63, 127) X(64, 64) X(128, 64) X(128, 128)
 
 // [N2][N1] table W_N^(n2 k1), cached per context
 inline int get_tw2_table(mmw_ctx *ctx, int N, int N1, const void **out) {
