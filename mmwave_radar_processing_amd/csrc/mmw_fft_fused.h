@@ -76,11 +76,13 @@ __device__ __forceinline__ bool chain_wait(unsigned *cnt, unsigned target, unsig
     }
 }
 // The eight pruned k1 passes + stores of one thread's two bins (shared by k_angle64 and k_angle64_sync).
-// ROWS (k_angle64_rows): the lane stores row a only if its pair lies in that row's line-aligned window of the wave.
-template <int VIN, bool MAG, bool NT, bool ROWS = false>
+// ROWS 1 (k_angle64_rows): the lane stores row a only if its pair lies in that row's line-aligned window of the wave.
+// ROWS 2 (k_angle64_rows_odd): odd bin count -- `pairs_per_frame` is the BIN count, `pair` the lane's first cell c0, and
+// rows that start at an odd cell offset store (second cell, next lane's first cell) so that every 16-B store is aligned.
+template <int VIN, bool MAG, bool NT, int ROWS = 0>
 __device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<float> (&xb)[VIN], void *__restrict__ out, long f,
                                                long pairs_per_frame, long pair, int shift_off, int b16 = 0, int lane = 0,
-                                               bool pair_ok = true) {
+                                               bool pair_ok = true, bool second_ok = true, bool next_ok = true) {
     typedef cplx<float> C;
     static_for<8>([&](auto K1) {
         constexpr int k1 = decltype(K1)::value;
@@ -106,7 +108,32 @@ __device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<floa
             const int a = (k1 + 8 * k2 + shift_off) & 63;   // fftshift over the angle axis (shift_off = 32)
             const C va = za[bitrev<8>(k2)], vb = zb[bitrev<8>(k2)];
             const long o = (f * 64 + a) * pairs_per_frame + pair;
-            if constexpr (ROWS) {
+            if constexpr (ROWS == 2) {
+                static_assert(!MAG, "complex output only");
+                const int m = ((k1 + 8 * k2) * b16) & 15;           // row a starts m cells past a line boundary
+                cplx<float> *dst = reinterpret_cast<cplx<float> *>(out) + o;      // cell c0 of row a
+                if constexpr (k1 % 2 == 0) {        // bins odd: m has the parity of a, i.e. of k1.  Even start: the lane's own pair
+                    const int lo = 8 - (m >> 1);
+                    if (lane >= lo && lane < lo + 56) {
+                        if (pair_ok && second_ok) __builtin_nontemporal_store(f32x4{va.x, va.y, vb.x, vb.y}, reinterpret_cast<f32x4 *>(dst));
+                        else if (pair_ok) __builtin_nontemporal_store(f32x2{va.x, va.y}, reinterpret_cast<f32x2 *>(dst));
+                    }
+                } else {                            // odd start: (own second cell, next lane's first cell)
+                    const int nb = (lane + 1) * 4;
+                    // (copies first: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0 for .y as well)
+                    const float ax = va.x, ay = va.y;
+                    const float nx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb, __builtin_bit_cast(int, ax)));
+                    const float ny = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb, __builtin_bit_cast(int, ay)));
+                    const int lo = (15 - m) >> 1;
+                    if (lane >= lo && lane < lo + 56) {
+                        if (second_ok && next_ok) __builtin_nontemporal_store(f32x4{vb.x, vb.y, nx, ny}, reinterpret_cast<f32x4 *>(dst + 1));
+                        else if (second_ok) __builtin_nontemporal_store(f32x2{vb.x, vb.y}, reinterpret_cast<f32x2 *>(dst + 1));
+                        else if (next_ok) __builtin_nontemporal_store(f32x2{nx, ny}, reinterpret_cast<f32x2 *>(dst + 2));
+                    }
+                }
+                return;
+            }
+            if constexpr (ROWS == 1) {
                 // row a starts m cells past a cache-line boundary (m = a * bins mod 16; the + 32 of the fftshift drops out):
                 // this wave's aligned 112-cell window of the row begins m cells before its nominal base
                 const int lo = 8 - ((((k1 + 8 * k2) * b16) & 15) >> 1);
@@ -192,7 +219,37 @@ __global__ __launch_bounds__(256) void k_angle64_rows(const f32x4 *__restrict__ 
         xa[v] = C{t.x * h, t.y * h};
         xb[v] = C{t.z * h, t.w * h};
     }
-    angle64_passes<VIN, false, true, true>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, lane, ok);
+    angle64_passes<VIN, false, true, 1>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, lane, ok);
+}
+
+// k_angle64_rows_odd: the same for an ODD bin count (63 x 127, 63 x 115): planes and rows then start at odd cell offsets,
+// so the loads are per cell (8 B) and every second row stores pairs shifted by one cell (angle64_passes ROWS 2).  Before,
+// such planes took the generic strided kernel (3.2 TB/s).
+template <int VIN, bool ZE>
+__global__ __launch_bounds__(256) void k_angle64_rows_odd(const cplx<float> *__restrict__ rd, void *__restrict__ out, long bins,
+                                                           AngleWin win, int shift_off, int b16, int n_waves) {
+    typedef cplx<float> C;
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= n_waves) return;
+    const long f = blockIdx.y;
+    const long c0 = wv * 112 - 16 + 2 * lane;
+    const bool ok_a = c0 >= 0 && c0 < bins, ok_b = c0 + 1 >= 0 && c0 + 1 < bins, ok_n = c0 + 2 >= 0 && c0 + 2 < bins;
+    const C *src = rd + f * VIN * bins;
+    C xa[VIN], xb[VIN];
+#pragma unroll
+    for (int v = 0; v < VIN; ++v) {
+        if (ZE && (v == 0 || v == VIN - 1)) {
+            xa[v] = C{0.f, 0.f};
+            xb[v] = C{0.f, 0.f};
+            continue;
+        }
+        const float h = win.h[v];
+        const C a = src[(long)v * bins + (ok_a ? c0 : 0)], b = src[(long)v * bins + (ok_b ? c0 + 1 : 0)];
+        xa[v] = a * h;
+        xb[v] = b * h;
+    }
+    angle64_passes<VIN, false, true, 2>(xa, xb, out, f, bins, c0, shift_off, b16, lane, ok_a, ok_b, ok_n);
 }
 
 // k_angle64_sync: the chain's device-synchronised angle stage (ChainSync above).  Persistent workgroups take
@@ -253,7 +310,7 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4
                 xa[v] = C{t.x * h, t.y * h};
                 xb[v] = C{t.z * h, t.w * h};
             }
-            angle64_passes<VIN, MAG, true, ROWS>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, tid & 63, ok);
+            angle64_passes<VIN, MAG, true, ROWS ? 1 : 0>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, tid & 63, ok);
         }
     }
 }
@@ -270,6 +327,13 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     const int nf_arg = xcd_frames ? F : 0;
     const bool nt = tune_int("MMW_ANGLE_NT", 1) != 0;
     const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f && tune_int("MMW_ANGLE_ZE", 1) != 0;
+    if (bins % 2) {         // angle_fast_path admits odd bin counts only for complex output
+        const int n_waves = (int)((bins + 15 + 111) / 112);
+        dim3 g((unsigned)((n_waves + 3) / 4), (unsigned)F);
+        if (ze) hipLaunchKernelGGL((k_angle64_rows_odd<VIN, true>), g, dim3(256), 0, ctx->stream, (const cplx<float> *)rd, out, bins, w, shift ? 32 : 0, (int)(bins & 15), n_waves);
+        else hipLaunchKernelGGL((k_angle64_rows_odd<VIN, false>), g, dim3(256), 0, ctx->stream, (const cplx<float> *)rd, out, bins, w, shift ? 32 : 0, (int)(bins & 15), n_waves);
+        return check_launch("angle64_rows_odd");
+    }
     if (!mag && bins % 16 != 0 && tune_int("MMW_ANGLE_ROWS", 1)) {
         const int n_waves = (int)((bins + 14 + 111) / 112);
         dim3 g((unsigned)((n_waves + 3) / 4), (unsigned)F);

@@ -29,8 +29,9 @@ constexpr int BIG_PRIME = 127;      // handled by dft_level_bigprime_ct (63 x 12
 constexpr int best_n1(int N) {
     if (N % BIG_PRIME == 0 && N / BIG_PRIME <= MAX_RADIX) return BIG_PRIME;
     int best = 0, best_cost = 1 << 30;
-    for (int a = 1; a <= N && a <= MAX_RADIX; ++a) {
+    for (int a = 1; a <= N && a <= 23; ++a) {
         if (N % a) continue;
+        if (a > MAX_RADIX && !(a == 23 && N == 115)) continue;          // 63 x 115 (one shipped cfg): radix 23 in registers
         const int b = N / a;
         if (b > a || b > MAX_RADIX) continue;
         const int c = split_cost(a, b);
@@ -49,6 +50,7 @@ constexpr int threads_for(int S, int C) {
     // 90 x 80 and 200 x 40 need ~100 VGPRs: 1024 threads would leave ONE workgroup per CU although two planes fit its
     // LDS; two 512-thread workgroups overlap each other's load and store phases (measured +12 % on both)
     if ((S == 90 && C == 80) || (S == 200 && C == 40)) return 512;
+    if (S == 63 && C == 115) return 512;        // RegDFT<23> spills under the 128-VGPR cap of 1024 threads
     return wgs < 3 ? 1024 : (wgs < 6 ? 512 : 256);
 }
 }  // namespace mixct
@@ -404,9 +406,8 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
 }
 
 // the non-power-of-two planes of the shipped cfgs (tests/golden/cfg_scalars.json) that need no prime radix above 20
-// (63 x 115 keeps the run-time kernel: 115 = 23 * 5)
 #define MMW_MIXED_CT_SHAPES_A(X) X(63, 70) X(63, 100) X(64, 40) X(70, 40) X(90, 80) X(100, 30) X(254, 50) X(127, 32)
-#define MMW_MIXED_CT_SHAPES_B(X) X(90, 100) X(100, 100) X(120, 126) X(130, 50) X(200, 40) X(63, 127) X(64, 64) X(128, 64) X(128, 128)
+#define MMW_MIXED_CT_SHAPES_B(X) X(90, 100) X(100, 100) X(120, 126) X(130, 50) X(200, 40) X(63, 127) X(64, 64) X(128, 64) X(128, 128) X(63, 115)
 
 // [N2][N1] table W_N^(n2 k1), cached per context
 inline int get_tw2_table(mmw_ctx *ctx, int N, int N1, const void **out) {

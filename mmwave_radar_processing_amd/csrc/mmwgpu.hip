@@ -414,7 +414,7 @@ int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, in
     return range_doppler_mag64_impl(ctx, d_cubes, d_mag, n_frames, V, S, C, rx_idx);
 }
 
-static bool angle_fast_path(int V, long bins, int A);
+static bool angle_fast_path(int V, long bins, int A, bool mag);
 
 static int angle_fft_impl(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_frames, int V, int S, int C, int A,
                          int flags) {
@@ -426,7 +426,7 @@ static int angle_fft_impl(mmw_ctx *ctx, const void *d_rd, void *d_out, int n_fra
                shift = !(flags & MMW_ANGLE_NO_SHIFT);
     ProfScope ps(ctx, "angle");
     const long bins = (long)S * C;
-    if (n_frames <= 65535 && angle_fast_path(V, bins, A)) {
+    if (n_frames <= 65535 && angle_fast_path(V, bins, A, magnitude)) {
         float h[16];
         for (int i = 0; i < V; ++i) h[i] = window ? (float)np_window(TAB_HANN, i, V) : 1.f;
         switch (V) {
@@ -679,11 +679,12 @@ static int ensure_pipe_queues(mmw_ctx *ctx, int rd_cus) {
 }
 
 // Does the angle stage of this call run k_angle64's ZE variant (planes 0 and V-1 never loaded)?
-static bool angle_fast_path(int V, long bins, int A) {      // per launch of at most 65535 frames
-    return A == 64 && bins % 2 == 0 && !env_int("MMW_NO_FUSED_ANGLE", 0) && (V == 4 || V == 8 || V == 12 || V == 16);
+static bool angle_fast_path(int V, long bins, int A, bool mag) {      // per launch of at most 65535 frames
+    // odd bin counts: complex output only (k_angle64_rows_odd)
+    return A == 64 && (bins % 2 == 0 || (!mag && tune_int("MMW_ANGLE_ROWS", 1))) && !env_int("MMW_NO_FUSED_ANGLE", 0) && (V == 4 || V == 8 || V == 12 || V == 16);
 }
 static bool angle_skips_end_planes(int V, long bins, int A, int flags) {
-    return angle_fast_path(V, bins, A) && V > 2 && !(flags & MMW_ANGLE_NO_WINDOW) &&
+    return angle_fast_path(V, bins, A, (flags & MMW_ANGLE_MAGNITUDE) != 0) && V > 2 && !(flags & MMW_ANGLE_NO_WINDOW) &&
            np_window(TAB_HANN, 0, V) == 0.0 && np_window(TAB_HANN, V - 1, V) == 0.0 && tune_int("MMW_ANGLE_ZE", 1) != 0;
 }
 
@@ -728,7 +729,7 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     }
     if (chunk_auto < 1) chunk_auto = 1;
     const bool fused_shape = (fused_rd_ok(S, C) || rd_lds_supported(S, C) || rd_mixed_supported(S, C)) &&
-                             angle_fast_path(V, (long)S * C, A);   // both stages have a single-pass kernel
+                             angle_fast_path(V, (long)S * C, A, (flags & MMW_ANGLE_MAGNITUDE) != 0);   // both stages have a single-pass kernel
     const int want_pipe = env_int("MMW_CHAIN_PIPELINE", -1);
     p.pipelined = !keep_rd && !ctx->pipe_unavailable &&
                   (want_pipe == 1 || (want_pipe == -1 && fused_shape && n_frames >= 2 * chunk_auto));
@@ -740,7 +741,8 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // (windowed chains only: the un-windowed angle variants of the persistent kernel exceed its register budget)
     const bool sync_shape = fused_rd_ok(S, C) || (!raw && rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0) &&
                                                    tune_int("MMW_MIXED_CT_SYNC", 1));
-    p.sync = p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
+    p.sync = p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && ((long)S * C) % 2 == 0 &&       // (odd planes: no sync consumer)
+             !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
     // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
     p.ring_frames = env_int("MMW_CHAIN_RING_FRAMES", (int)((120u << 20) / live_bytes));

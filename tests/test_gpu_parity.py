@@ -1177,15 +1177,16 @@ def test_doppler_azimuth_entry_fused_range_mean(V, S, C, A, win, monkeypatch):
         b.free()
 
 
-@pytest.mark.parametrize("V,S,C", [(12, 63, 100), (8, 21, 10), (4, 25, 26), (12, 2, 5), (16, 7, 18), (12, 127, 2)])
+@pytest.mark.parametrize("V,S,C", [(12, 63, 100), (8, 21, 10), (4, 25, 26), (12, 2, 5), (16, 7, 18), (12, 127, 2),
+                                   (12, 63, 127), (8, 21, 11), (4, 5, 5), (16, 1, 1), (12, 9, 25), (12, 3, 37)])
 @pytest.mark.parametrize("flags", [0, _lib.ANGLE_NO_WINDOW | _lib.ANGLE_NO_SHIFT])
 def test_angle_rows_kernel_on_misaligned_rows(V, S, C, flags):
-    """k_angle64_rows (bins % 16 != 0: every wave stores a per-row line-aligned window of the cells it computed) against
+    """k_angle64_rows / k_angle64_rows_odd (bins % 16 != 0: every wave stores a per-row line-aligned window of the cells it computed) against
     numpy's FFT over the antenna axis (range_angle_resp_dbs_enhanced.py:175-196), several frames so that the frame
     stride, the first / last wave of a row and rows with every misalignment (a * bins mod 16) are hit."""
     ctx = _lib.default_context()
     F, A, bins = 3, 64, S * C
-    assert bins % 16 != 0 and bins % 2 == 0
+    assert bins % 16 != 0                   # odd bin counts: k_angle64_rows_odd
     rng = np.random.default_rng(V * 1000 + bins)
     rd = (rng.standard_normal((F, V, S, C)) + 1j * rng.standard_normal((F, V, S, C))).astype(np.complex64)
     d_rd, d_out = ctx.alloc(rd.nbytes), ctx.alloc(F * A * bins * 8 + 256)
