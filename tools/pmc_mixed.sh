@@ -6,5 +6,6 @@ for shape in 12,63,100 12,254,50; do
   timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof/mix_${tag}_fetch -o p -- python3 tools/rd_prof.py --shape $shape --reps 2 > /dev/null 2>&1 || exit 1
   timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof/mix_${tag}_write -o p -- python3 tools/rd_prof.py --shape $shape --reps 2 > /dev/null 2>&1 || exit 1
   timeout -k 10 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY -d gpurun_out/prof/mix_${tag}_sq -o p -- python3 tools/rd_prof.py --shape $shape --reps 2 > /dev/null 2>&1 || exit 1
+  timeout -k 10 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d gpurun_out/prof/mix_${tag}_mfma -o p -- python3 tools/rd_prof.py --shape $shape --reps 2 > /dev/null 2>&1 || exit 1
   timeout -k 10 120 rocprofv3 --pmc GRBM_GUI_ACTIVE -d gpurun_out/prof/mix_${tag}_grbm -o p -- python3 tools/rd_prof.py --shape $shape --reps 2 > /dev/null 2>&1 || exit 1
 done
