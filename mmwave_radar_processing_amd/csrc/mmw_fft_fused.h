@@ -257,15 +257,16 @@ __global__ __launch_bounds__(256) void k_angle64_rows_odd(const cplx<float> *__r
 // from the ring with sc1 loads, release the slot and run the same passes + streaming stores as k_angle64.
 // Register budget: 3 waves per SIMD (168 VGPRs) for the shapes that fit it -- the headline 12-antenna windowed case
 // among them -- and 2 where the unrolled passes need more (a spill costs more than the lost wave).
-// ROWS: the line-aligned row windows of k_angle64_rows (bins % 16 != 0): a tile is 4 waves x 112 stored cells.
-template <int VIN, bool MAG, bool ZE, bool ROWS = false>
+// ROWS 1 / 2: the line-aligned row windows of k_angle64_rows / k_angle64_rows_odd (bins % 16 != 0): a tile is 4 waves x 112
+// stored cells; ROWS 2 (odd bin count): `pairs_per_frame` is the bin count and the ring is read per cell.
+template <int VIN, bool MAG, bool ZE, int ROWS = 0>
 __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4 ? 3 : 2) void k_angle64_sync(const void *__restrict__ ring, void *__restrict__ out, long pairs_per_frame,
                                                        AngleWin win, int shift_off, ChainSync cs, int b16, int n_waves) {
     typedef cplx<float> C;
     __shared__ int sh[4];       // [0] ticket, [1] abort
     const int tid = threadIdx.x;
     // wave-uniform descriptor of the ring (sc1 buffer loads: aux = 16)
-    const unsigned ring_bytes = (unsigned)((long)cs.ring * VIN * pairs_per_frame * 16);
+    const unsigned ring_bytes = (unsigned)((long)cs.ring * VIN * pairs_per_frame * (ROWS == 2 ? 8 : 16));
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ring), 0, (int)ring_bytes, 0x00020000);
     const int n_items = cs.n_frames * cs.tiles;
     int prev_slot = -1;
@@ -289,10 +290,19 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4
         prev_slot = slot;
         long pair = (long)tile * 256 + tid;
         bool ok = pair < pairs_per_frame, run = ok;
-        if constexpr (ROWS) {
+        [[maybe_unused]] bool ok_b = true, ok_n = true;
+        if constexpr (ROWS == 1) {
             const long wv = (long)tile * 4 + (tid >> 6);
             pair = wv * 56 - 8 + (tid & 63);            // cells 112 wv - 16 + 2 lane, + 1
             ok = pair >= 0 && pair < pairs_per_frame;
+            run = wv < n_waves;
+        }
+        if constexpr (ROWS == 2) {
+            const long wv = (long)tile * 4 + (tid >> 6);
+            pair = wv * 112 - 16 + 2 * (tid & 63);      // first cell c0 of the lane
+            ok = pair >= 0 && pair < pairs_per_frame;
+            ok_b = pair + 1 >= 0 && pair + 1 < pairs_per_frame;
+            ok_n = pair + 2 >= 0 && pair + 2 < pairs_per_frame;
             run = wv < n_waves;
         }
         if (run) {
@@ -304,13 +314,22 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4
                     xb[v] = C{0.f, 0.f};
                     continue;
                 }
+                if constexpr (ROWS == 2) {
+                    const long plane = ((long)slot * VIN + v) * pairs_per_frame;
+                    const C a = __builtin_bit_cast(C, __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)((plane + (ok ? pair : 0)) * 8), 0, 16));
+                    const C b = __builtin_bit_cast(C, __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)((plane + (ok_b ? pair + 1 : 0)) * 8), 0, 16));
+                    const float h = win.h[v];
+                    xa[v] = a * h;
+                    xb[v] = b * h;
+                    continue;
+                }
                 const unsigned off = (unsigned)((((long)slot * VIN + v) * pairs_per_frame + (ok ? pair : 0)) * 16);
                 const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
                 const float h = win.h[v];
                 xa[v] = C{t.x * h, t.y * h};
                 xb[v] = C{t.z * h, t.w * h};
             }
-            angle64_passes<VIN, MAG, true, ROWS ? 1 : 0>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, tid & 63, ok);
+            angle64_passes<VIN, MAG, true, ROWS>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, tid & 63, ok, ok_b, ok_n);
         }
     }
 }
@@ -362,6 +381,7 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
 // angle work items per frame of the device-synchronised chain
 inline bool angle_sync_rows(long bins, bool mag) { return !mag && bins % 16 != 0 && tune_int("MMW_ANGLE_ROWS", 1) != 0; }
 inline int angle_sync_tiles(long bins, bool mag) {
+    if (bins % 2) return (int)(((bins + 15 + 111) / 112 + 3) / 4);
     if (angle_sync_rows(bins, mag)) return (int)(((bins + 14 + 111) / 112 + 3) / 4);
     return (int)((bins / 2 + 255) / 256);
 }
@@ -373,10 +393,16 @@ int launch_angle64_sync(mmw_ctx *ctx, const void *ring, void *out, long bins, bo
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f;
+    if (bins % 2) {                         // odd bin count (complex output only): cs.tiles from angle_sync_tiles()
+        const int n_waves = (int)((bins + 15 + 111) / 112);
+        if (ze) hipLaunchKernelGGL((k_angle64_sync<VIN, false, true, 2>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, bins, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
+        else hipLaunchKernelGGL((k_angle64_sync<VIN, false, false, 2>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, bins, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
+        return check_launch("angle64_sync_rows_odd");
+    }
     if (angle_sync_rows(bins, mag)) {       // cs.tiles was sized for this variant by angle_sync_tiles()
         const int n_waves = (int)((bins + 14 + 111) / 112);
-        if (ze) hipLaunchKernelGGL((k_angle64_sync<VIN, false, true, true>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
-        else hipLaunchKernelGGL((k_angle64_sync<VIN, false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
+        if (ze) hipLaunchKernelGGL((k_angle64_sync<VIN, false, true, 1>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
+        else hipLaunchKernelGGL((k_angle64_sync<VIN, false, false, 1>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
         return check_launch("angle64_sync_rows");
     }
 #define MMW_ANGLE_SYNC(MAGV, ZEV) \

@@ -741,8 +741,7 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // (windowed chains only: the un-windowed angle variants of the persistent kernel exceed its register budget)
     const bool sync_shape = fused_rd_ok(S, C) || (!raw && rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0) &&
                                                    tune_int("MMW_MIXED_CT_SYNC", 1));
-    p.sync = p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && ((long)S * C) % 2 == 0 &&       // (odd planes: no sync consumer)
-             !(mode && !std::strcmp(mode, "events"));
+    p.sync = p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
     // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
     p.ring_frames = env_int("MMW_CHAIN_RING_FRAMES", (int)((120u << 20) / live_bytes));

@@ -1288,12 +1288,12 @@ def test_range_zoom_chirpz_against_float64_sum():
     d_out.free()
 
 
-@pytest.mark.parametrize("S,C,F", [(63, 100, 700), (254, 50, 150), (64, 40, 900), (63, 127, 200), (100, 100, 300)])
+@pytest.mark.parametrize("S,C,F", [(63, 100, 700), (254, 50, 150), (64, 40, 900), (63, 127, 200), (100, 100, 300), (63, 115, 160)])
 def test_device_synchronised_chain_on_shipped_cfg_shapes(monkeypatch, S, C, F):
     """The device-synchronised chain with the compile-time mixed-radix range-Doppler producer (k_rd_mixed_ct MODE 2) and,
     where the angle rows are not line aligned, the row-window consumer (k_angle64_sync ROWS): serial vs events vs sync
     agree to float32 rounding, sync is bit-identical with itself for any batch length, frame 0 / last match the oracle.
-    63 x 127 has an odd bin count (no fused angle kernel): it must stay off the device-synchronised schedule."""
+    63 x 127 and 63 x 115 have odd bin counts: per-cell ring reads and shifted pairs in the consumer (ROWS 2)."""
     ctx = _lib.default_context()
     L, h = ctx.lib, ctx.handle
     V, A = 12, 64
@@ -1314,13 +1314,11 @@ def test_device_synchronised_chain_on_shipped_cfg_shapes(monkeypatch, S, C, F):
     for f in (0, F - 1):
         cube = d_in.download((V, S, C), np.complex64, byte_offset=f * V * S * C * 8)
         assert rel_err(ref[f], O.fft3d_windowed(cube, A)) <= SPEC_TOL
-    odd = (S * C) % 2 == 1
     d_out.zero()
-    pipelined, sync = run("sync", F, d_out)
-    assert (pipelined, sync) == ((True, False) if odd else (True, True))     # pipelining is forced on; sync needs the fused angle kernel
+    assert run("sync", F, d_out) == (True, True)
     got = d_out.download((F, A, S, C), np.complex64)
     assert cross_schedule_dev(got, ref) <= CROSS_SCHEDULE_TOL
-    if not odd:
+    if True:
         d_out.zero()
         run("sync", 7, d_out)               # shorter than the ring, straight after the long call
         run("sync", F // 3, d_out)
