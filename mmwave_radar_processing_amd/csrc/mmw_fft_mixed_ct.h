@@ -29,11 +29,12 @@ constexpr int BIG_PRIME = 127;      // handled by dft_level_bigprime_ct (63 x 12
 constexpr int best_n1(int N) {
     if (N % BIG_PRIME == 0 && N / BIG_PRIME <= MAX_RADIX) return BIG_PRIME;
     int best = 0, best_cost = 1 << 30;
-    for (int a = 1; a <= N && a <= 23; ++a) {
+    for (int a = 1; a <= N && a <= 32; ++a) {
         if (N % a) continue;
-        if (a > MAX_RADIX && !(a == 23 && N == 115)) continue;          // 63 x 115 (one shipped cfg): radix 23 in registers
+        // 63 x 115 (one shipped cfg): radix 23 in registers; 512 / 1024 samples: radix 32 (RegFFT<32>, ~70 VGPRs)
+        if (a > MAX_RADIX && !(a == 23 && N == 115) && !(a == 32 && (N == 512 || N == 1024))) continue;
         const int b = N / a;
-        if (b > a || b > MAX_RADIX) continue;
+        if (b > a || (b > MAX_RADIX && !(b == 32 && N == 1024))) continue;
         const int c = split_cost(a, b);
         if (c < best_cost) {
             best_cost = c;
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
 }
 
 // the non-power-of-two planes of the shipped cfgs (tests/golden/cfg_scalars.json) that need no prime radix above 20
-#define MMW_MIXED_CT_SHAPES_A(X) X(63, 70) X(63, 100) X(64, 40) X(70, 40) X(90, 80) X(100, 30) X(254, 50) X(127, 32)
+#define MMW_MIXED_CT_SHAPES_A(X) X(63, 70) X(63, 100) X(64, 40) X(70, 40) X(90, 80) X(100, 30) X(254, 50) X(127, 32) X(512, 32) X(512, 8)
 #define MMW_MIXED_CT_SHAPES_B(X) X(90, 100) X(100, 100) X(120, 126) X(130, 50) X(200, 40) X(63, 127) X(64, 64) X(128, 64) X(128, 128) X(63, 115)
 
 // [N2][N1] table W_N^(n2 k1), cached per context

@@ -342,6 +342,8 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
             MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
         else if (rd_mixed_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0))
             MMW_TRY((launch_rd_mixed<float, false>(ctx, d_cubes, (long)S * C, d_out, n_frames * V, S, C, rv)));
+        else if (rv.ntx <= 1 && rd_split_ct_supported(S, C) && !env_int("MMW_NO_SPLIT_RD", 0))
+            MMW_TRY(launch_rd_split_ct(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
         else if (rv.ntx > 1) {
             // no single-pass kernel for this plane: de-interleave into the output buffer, then transform it in place
             const long total = (long)n_frames * V * S * C;

@@ -1330,3 +1330,34 @@ def test_device_synchronised_chain_on_shipped_cfg_shapes(monkeypatch, S, C, F):
         np.testing.assert_array_equal(d_out.download((F, A, S, C), np.complex64), got)
     d_in.free()
     d_out.free()
+
+
+@pytest.mark.parametrize("S,C", [(512, 64), (128, 256), (1024, 32)])
+def test_split_range_doppler_kernel_for_planes_beyond_the_lds(S, C, monkeypatch):
+    """k_rd_split2_ct: planes of 2 x 16384 cells in ONE pass over HBM (even chirps through the LDS, odd chirps and then the
+    even half's spectrum carried in registers, radix-2 combine in the store pass) against the oracle and the two-kernel
+    path, and through the chain (Hann(V) end planes skipped there)."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, V, A = 3, 4, 64
+    n = V * S * C
+    cubes = np.stack([synth.synth_cube(4100 + S + C + f, (V, S, C)) for f in range(F)]).astype(np.complex64)
+    d_in, d_rd, d_out = ctx.alloc(F * n * 8), ctx.alloc(F * n * 8), ctx.alloc(F * A * S * C * 8)
+    d_in.upload(cubes)
+    got = {}
+    for no_split in ("0", "1"):
+        monkeypatch.setenv("MMW_NO_SPLIT_RD", no_split)
+        d_rd.zero()
+        _lib.check(L.mmw_range_doppler(h, d_in.ptr, d_rd.ptr, None, F, V, S, C))
+        got[no_split] = d_rd.download((F, V, S, C), np.complex64)
+    monkeypatch.delenv("MMW_NO_SPLIT_RD")
+    for f in range(F):
+        ref = O.range_doppler(cubes[f])
+        for key in got:
+            assert rel_err(got[key][f], ref) <= SPEC_TOL, key
+    _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+    out = d_out.download((F, A, S, C), np.complex64)
+    for f in (0, F - 1):
+        assert rel_err(out[f], O.fft3d_windowed(cubes[f], A)) <= SPEC_TOL
+    for b in (d_in, d_rd, d_out):
+        b.free()
