@@ -350,7 +350,11 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
             hipLaunchKernelGGL(k_reformat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const float2 *)d_cubes, (float2 *)d_out, total, rv.nrx, rv.ntx, S, C);
             MMW_TRY(check_launch("reformat"));
-            MMW_TRY(range_doppler_generic(ctx, d_out, d_out, n_frames, V, S, C));
+            // (the split kernel reads its whole plane before its first store, so it may run in place as well)
+            if (rd_split_ct_supported(S, C) && !env_int("MMW_NO_SPLIT_RD", 0))
+                MMW_TRY(launch_rd_split_ct(ctx, d_out, d_out, n_frames * V, S, C, RawView{1, 0, rv.vskip}));
+            else
+                MMW_TRY(range_doppler_generic(ctx, d_out, d_out, n_frames, V, S, C));
         } else
             MMW_TRY(range_doppler_generic(ctx, d_cubes, d_out, n_frames, V, S, C));
         if (d_l1 && !l1_done) {
@@ -732,6 +736,8 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     if (chunk_auto < 1) chunk_auto = 1;
     const bool fused_shape = (fused_rd_ok(S, C) || rd_lds_supported(S, C) || rd_mixed_supported(S, C)) &&
                              angle_fast_path(V, (long)S * C, A, (flags & MMW_ANGLE_MAGNITUDE) != 0);   // both stages have a single-pass kernel
+    // (the split kernel of the 32768-cell planes is latency bound at 2 waves per SIMD: on half the chip it is slower than
+    //  the serial schedule -- 5.6 vs 5.3 us/frame at 12 x 512 x 64 -- so those planes stay serial)
     const int want_pipe = env_int("MMW_CHAIN_PIPELINE", -1);
     p.pipelined = !keep_rd && !ctx->pipe_unavailable &&
                   (want_pipe == 1 || (want_pipe == -1 && fused_shape && n_frames >= 2 * chunk_auto));
