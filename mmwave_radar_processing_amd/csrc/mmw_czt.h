@@ -277,12 +277,8 @@ inline int launch_czt_rows(mmw_ctx *ctx, const CztPlan &plan, CztArgs a) {
         hipLaunchKernelGGL(k_czt_rows<16>, grid_for(16), dim3(256), lds_bytes, ctx->stream, a);
     } else {
         constexpr size_t lds_bytes = (8 * 32 * 33 + 4 * 1024) * sizeof(cplx<float>);     // 98 KB: above the default dynamic limit
-        static bool attr_set = false;
-        if (!attr_set) {
-            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_czt_rows<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_bytes));
-            attr_set = true;
-        }
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_czt_rows<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes));       // per device, so on every call
         hipLaunchKernelGGL(k_czt_rows<32>, grid_for(8), dim3(256), lds_bytes, ctx->stream, a);
     }
     return check_launch("czt_rows");

@@ -408,6 +408,8 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
 
 // the non-power-of-two planes of the shipped cfgs (tests/golden/cfg_scalars.json) that need no prime radix above 20
 #define MMW_MIXED_CT_SHAPES_A(X) X(63, 70) X(63, 100) X(64, 40) X(70, 40) X(90, 80) X(100, 30) X(254, 50) X(127, 32) X(512, 32) X(512, 8)
+// the remaining power-of-two planes that fit the LDS (k_rd_lds' list): same kernel, and with it the synchronised chain
+#define MMW_MIXED_CT_SHAPES_C(X) X(32, 32) X(64, 32) X(128, 32) X(256, 32) X(32, 64) X(256, 64) X(32, 128) X(64, 128)
 #define MMW_MIXED_CT_SHAPES_B(X) X(90, 100) X(100, 100) X(120, 126) X(130, 50) X(200, 40) X(63, 127) X(64, 64) X(128, 64) X(128, 128) X(63, 115)
 
 // [N2][N1] table W_N^(n2 k1), cached per context
@@ -486,10 +488,11 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
     constexpr size_t lds_bytes = mixct_lds_bytes(S, C);
     if (cs || query_only) {
         auto kern = k_rd_mixed_ct<S, C, NT, 2>;
+        // (the attribute is per device: set it on every call, a process may drive several devices)
+        if (lds_bytes > 64 * 1024)
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         static int per_cu = 0;
         if (!per_cu) {
-            if (lds_bytes > 64 * 1024)
-                MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             int nb = 0;
             MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), NT, lds_bytes));
             per_cu = nb > 0 ? nb : 1;
@@ -545,14 +548,17 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
     return check_launch("rd_mixed_ct");
 }
 
-// one translation unit per half of the shape list (mmw_tu_mixed_ct_a/b.hip), so the library still builds in parallel
-#if defined(MMW_TU_MIXED_CT_A) || defined(MMW_TU_MIXED_CT_B)
-#ifdef MMW_TU_MIXED_CT_A
+// one translation unit per part of the shape list (mmw_tu_mixed_ct_a/b/c.hip), so the library still builds in parallel
+#if defined(MMW_TU_MIXED_CT_A) || defined(MMW_TU_MIXED_CT_B) || defined(MMW_TU_MIXED_CT_C)
+#if defined(MMW_TU_MIXED_CT_A)
 #define MMW_MIXED_CT_LIST MMW_MIXED_CT_SHAPES_A
 #define MMW_MIXED_CT_FN launch_rd_mixed_ct_a
-#else
+#elif defined(MMW_TU_MIXED_CT_B)
 #define MMW_MIXED_CT_LIST MMW_MIXED_CT_SHAPES_B
 #define MMW_MIXED_CT_FN launch_rd_mixed_ct_b
+#else
+#define MMW_MIXED_CT_LIST MMW_MIXED_CT_SHAPES_C
+#define MMW_MIXED_CT_FN launch_rd_mixed_ct_c
 #endif
 int MMW_MIXED_CT_FN(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
                     const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only) {
@@ -566,10 +572,13 @@ int MMW_MIXED_CT_FN(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
 #ifdef MMW_TU_MIXED_CT_A
 int launch_rd_mixed_ct_b(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
                          const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only);
+int launch_rd_mixed_ct_c(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
+                         const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only);
 bool rd_mixed_ct_supported(int S, int C) {
 #define X(s, c) if (S == s && C == c) return true;
     MMW_MIXED_CT_SHAPES_A(X)
     MMW_MIXED_CT_SHAPES_B(X)
+    MMW_MIXED_CT_SHAPES_C(X)
 #undef X
     return false;
 }
@@ -577,6 +586,7 @@ int launch_rd_mixed_ct(mmw_ctx *ctx, const void *d_in, long in_plane_stride, voi
                        const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only) {
     int rc = launch_rd_mixed_ct_a(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only);
     if (rc == MMW_ERR_UNSUPPORTED) rc = launch_rd_mixed_ct_b(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only);
+    if (rc == MMW_ERR_UNSUPPORTED) rc = launch_rd_mixed_ct_c(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only);
     if (rc == MMW_ERR_UNSUPPORTED) return set_error(MMW_ERR_UNSUPPORTED, "no compile-time mixed-radix kernel for %dx%d", S, C);
     return rc;
 }
