@@ -103,6 +103,8 @@ int range_profile_impl(mmw_ctx *ctx, const void *d_cubes, T *d_out, int n_frames
 
 }  // namespace
 
+static void sync_slot_forget(mmw_ctx *ctx);
+
 extern "C" {
 
 const char *mmw_version(void) { return "mmwgpu 0.1 (gfx950)"; }
@@ -153,6 +155,7 @@ int mmw_ctx_create(mmw_ctx **out, int device) {
 
 int mmw_ctx_destroy(mmw_ctx *ctx) {
     if (!ctx) return MMW_OK;
+    sync_slot_forget(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tables) (void)hipFree(kv.second);
@@ -707,7 +710,8 @@ struct ChainPlan {
     bool sync;              // device-synchronised form: one RD launch + one angle launch per call (ChainSync)
     int ring_frames;        // sync: frames in the ring of RD cubes
 };
-static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_frames, int V, int S, int C, int A, int flags) {
+static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_frames, int V, int S, int C, int A, int flags,
+                            bool allow_sync = true) {
     ChainPlan p{};
     // Planes nobody reads are not transformed: with the Hann(V) antenna window the end antennas have weight exactly 0
     // (np.hanning end points) and k_angle64's ZE variant never loads them, so when the RD cube is only an internal
@@ -749,7 +753,7 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // (windowed chains only: the un-windowed angle variants of the persistent kernel exceed its register budget)
     const bool sync_shape = fused_rd_ok(S, C) || (!raw && rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0) &&
                                                    tune_int("MMW_MIXED_CT_SYNC", 1));
-    p.sync = p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
+    p.sync = allow_sync && p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
     // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
     p.ring_frames = env_int("MMW_CHAIN_RING_FRAMES", (int)((120u << 20) / live_bytes));
@@ -757,6 +761,34 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     while ((size_t)p.ring_frames * V * S * C * sizeof(cplx<float>) >= ((size_t)1 << 31)) --p.ring_frames;   // 32-bit buffer offsets
     if (p.sync) p.chunk = n_frames;
     return p;
+}
+
+// The device-synchronised chain keeps two persistent kernels resident on disjoint halves of the chip.  Two contexts of
+// ONE process doing that on the same device could starve each other (each one's consumer holding the slots the other's
+// producer needs) until the bounded spins give up, so per device only one context at a time may have such work in
+// flight; a second context takes the event schedule for that call.  (Two PROCESSES on one device cannot see each other:
+// INTEGRATION.md.)
+static std::mutex g_sync_mu;
+static mmw_ctx *g_sync_owner[64] = {};
+static bool sync_slot_acquire(mmw_ctx *ctx) {
+    if (ctx->device < 0 || ctx->device >= 64) return true;
+    std::lock_guard<std::mutex> lock(g_sync_mu);
+    mmw_ctx *&owner = g_sync_owner[ctx->device];
+    if (owner && owner != ctx) {
+        // still running?  (its last device-synchronised call recorded pipe_ang[0] / [1] behind the two launches)
+        bool busy = false;
+        for (int i = 0; i < 2; ++i)
+            if (owner->pipe_ang_used[i] && owner->pipe_ang[i] && hipEventQuery(owner->pipe_ang[i]) == hipErrorNotReady) busy = true;
+        (void)hipGetLastError();
+        if (busy) return false;
+    }
+    owner = ctx;
+    return true;
+}
+static void sync_slot_forget(mmw_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(g_sync_mu);
+    for (auto &o : g_sync_owner)
+        if (o == ctx) o = nullptr;
 }
 
 // One RD launch + one angle launch for the whole call, synchronised through device counters (ChainSync).
@@ -878,7 +910,9 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
     MMW_HIP(hipSetDevice(ctx->device));
     const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
     const size_t out_frame_bytes = (size_t)A * S * C * (magnitude ? sizeof(float) : sizeof(cplx<float>));
-    const ChainPlan plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags);
+    ChainPlan plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags);
+    if (plan.sync && !sync_slot_acquire(ctx))       // another context of this process has synchronised work in flight here
+        plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags, false);
     rv.vskip = plan.vskip;
     const bool pipelined = plan.pipelined;
     const int ring = plan.ring, rd_cus = plan.rd_cus;

@@ -1361,3 +1361,44 @@ def test_split_range_doppler_kernel_for_planes_beyond_the_lds(S, C, monkeypatch)
         assert rel_err(out[f], O.fft3d_windowed(cubes[f], A)) <= SPEC_TOL
     for b in (d_in, d_rd, d_out):
         b.free()
+
+
+def test_two_contexts_on_one_device_share_the_synchronised_chain():
+    """Two contexts of one process on the SAME device, each driving large batches through mmw_chain3d from its own thread.
+    Only one context at a time may keep the two persistent kernels of the device-synchronised schedule resident
+    (sync_slot_acquire in mmwgpu.hip); the other takes the event schedule for that call.  Both must finish without the
+    hand-off timing out and produce the single-context result."""
+    import threading
+    S, C, V, A, F = 256, 128, 12, 64, 300
+    base = _lib.default_context()
+    ctxs = [_lib.Context(base.device) for _ in range(2)]
+    outs, errs = [None, None], []
+
+    def work(i):
+        try:
+            ctx = ctxs[i]
+            d_in, d_out = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * A * S * C * 8)
+            _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 31337, 8, 30.0))
+            for _ in range(4):
+                _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+            ctx.sync()
+            outs[i] = d_out.download((F, A, S, C), np.complex64)[[0, F // 2, F - 1]]
+            d_in.free()
+            d_out.free()
+        except Exception as exc:        # noqa: BLE001 - reported below, in the main thread
+            errs.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    assert cross_schedule_dev(outs[0], outs[1]) <= CROSS_SCHEDULE_TOL
+    d_in = base.alloc(V * S * C * 8)
+    _lib.check(base.lib.mmw_synth_cubes(base.handle, d_in.ptr, 1, V, S, C, 31337, 8, 30.0))
+    cube0 = d_in.download((V, S, C), np.complex64)
+    assert rel_err(outs[0][0], O.fft3d_windowed(cube0, A)) <= SPEC_TOL
+    d_in.free()
+    for c in ctxs:
+        c.close()
