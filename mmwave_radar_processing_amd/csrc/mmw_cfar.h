@@ -404,6 +404,97 @@ __global__ __launch_bounds__(CFAR_TR *CFAR_TC) void k_cfar2d(Cfar2dArgs p) {
     if (p.mask) p.mask[o] = (tile[(lr + hr) * TW + lc + hd] > thr) ? 1 : 0;
 }
 
+// CA-CFAR 2-D on a larger tile.  k_cfar2d's 16 x 16 tile suits the OS path (the tile + halo must fit a 1024-element sort);
+// for CA it means a 28 x 28 tile + halo for the reference's (4,4)/(2,2) window -- 3.06 input cells loaded per output -- and
+// 128 short-lived workgroups per 256 x 128 plane.  Here a 256-thread workgroup owns CA_TR x CA_TC = 32 x 32 cells (halo
+// factor 1.9, a quarter of the workgroups): phase 1 computes, for every (tile row, window start column), the row sum of
+// the full window row and of the guard-masked one in NumPy's 8-accumulator pairwise order (each shared by the Wr cells
+// under test of that column); phase 2 adds Wr of them per cell in row order, / N, x alpha.  Same arithmetic, same
+// order, bit-identical thresholds.
+constexpr int CA_TR = 32, CA_TC = 32;
+__global__ __launch_bounds__(256) void k_cfar2d_ca(Cfar2dArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *tile = reinterpret_cast<double *>(smem);
+    const int hr = p.tr + p.gr, hd = p.td + p.gd;
+    const int TW = CA_TC + 2 * hd, TH = CA_TR + 2 * hr;
+    double *rs_full = tile + TW * TH;                 // [TH][CA_TC]
+    double *rs_mask = rs_full + TH * CA_TC;
+    const long plane = (long)p.R * p.D;
+    const double *X = p.X + (long)blockIdx.z * plane;
+    const int r0 = blockIdx.y * CA_TR, c0 = blockIdx.x * CA_TC;
+    for (int e = threadIdx.x; e < TH * TW; e += 256) {
+        const int y = e / TW, x = e - y * TW;
+        const int rr = r0 - hr + y, cc = c0 - hd + x;
+        tile[e] = (rr >= 0 && rr < p.R && cc >= 0 && cc < p.D) ? X[(long)rr * p.D + cc] : 0.0;
+    }
+    __syncthreads();
+    const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
+    const int z0 = p.td, z1 = p.td + 2 * p.gd;        // guard columns of the window
+    for (int t = threadIdx.x; t < TH * CA_TC; t += 256) {
+        const int row = t / CA_TC, col = t - row * CA_TC;
+        const double *src = tile + row * TW + col;
+        double sf, sm;
+        if (Wd > 128) {                               // rare: generic pairwise recursion
+            sf = np_pairwise<2>([&](int wd) { return src[wd]; }, 0, Wd);
+            sm = np_pairwise<2>([&](int wd) { return (wd >= z0 && wd <= z1) ? 0.0 : src[wd]; }, 0, Wd);
+        } else if (Wd < 8) {
+            sf = sm = 0.0;
+            for (int i = 0; i < Wd; ++i) {
+                const double v = src[i];
+                sf += v;
+                sm += (i >= z0 && i <= z1) ? 0.0 : v;
+            }
+        } else {                                      // NumPy's 8-accumulator block, both sums in one sweep
+            double f[8], m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double v = src[j];
+                f[j] = v;
+                m[j] = (j >= z0 && j <= z1) ? 0.0 : v;
+            }
+            int i = 8;
+            for (; i < Wd - (Wd % 8); i += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double v = src[i + j];
+                    f[j] += v;
+                    m[j] += (i + j >= z0 && i + j <= z1) ? 0.0 : v;
+                }
+            }
+            sf = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+            sm = ((m[0] + m[1]) + (m[2] + m[3])) + ((m[4] + m[5]) + (m[6] + m[7]));
+            for (; i < Wd; ++i) {
+                const double v = src[i];
+                sf += v;
+                sm += (i >= z0 && i <= z1) ? 0.0 : v;
+            }
+        }
+        rs_full[t] = sf;
+        rs_mask[t] = sm;
+    }
+    __syncthreads();
+    const int ntrain = Wr * Wd - (2 * p.gr + 1) * (2 * p.gd + 1);
+    for (int cell = threadIdx.x; cell < CA_TR * CA_TC; cell += 256) {
+        const int lr = cell / CA_TC, lc = cell - lr * CA_TC;
+        const int r = r0 + lr, c = c0 + lc;
+        if (r >= p.R || c >= p.D) continue;
+        const long o = (long)blockIdx.z * plane + (long)r * p.D + c;
+        double thr = INFINITY, est = 0.0;
+        if (r >= hr && r < p.R - hr && c >= hd && c < p.D - hd) {
+            double sum = 0.0;
+            for (int wr = 0; wr < Wr; ++wr) {
+                const bool guard_row = wr >= p.tr && wr <= p.tr + 2 * p.gr;
+                sum += (guard_row ? rs_mask : rs_full)[(lr + wr) * CA_TC + lc];
+            }
+            est = sum / (double)ntrain;
+            thr = p.scale * est;
+        }
+        if (p.thr) p.thr[o] = thr;
+        if (p.noise) p.noise[o] = est;
+        if (p.mask) p.mask[o] = (tile[(lr + hr) * TW + lc + hd] > thr) ? 1 : 0;
+    }
+}
+
 // OS-CFAR when only the detection mask is wanted (mmw_detect_batch, FramePipeline): no selection at all.
 //   X > alpha * T*,  T* = k-th smallest training cell   <=>   #{ training cells t : alpha * t < X } >= k
 // because t -> alpha * t (one float64 multiply, the very product the reference forms for T*) is monotone, so the k-th

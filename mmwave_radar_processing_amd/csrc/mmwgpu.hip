@@ -1165,6 +1165,19 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
         }
     }
     MMW_REQUIRE(2 * hd + 1 <= 512, "Doppler window too wide for the exact summation order");
+    if (kind == MMW_CFAR_CA && !env_int("MMW_CA_SMALL_TILE", 0)) {
+        // 32 x 32 tile (k_cfar2d_ca) while tile + halo + row-sum tables fit the default LDS limit
+        const size_t th = CA_TR + 2 * hr, tw = CA_TC + 2 * hd;
+        const size_t lds_ca = (th * tw + 2 * th * CA_TC) * sizeof(double);
+        if (lds_ca <= 64 * 1024) {
+            if (n_frames == 0) return MMW_OK;
+            ProfScope ps(ctx, "cfar");
+            Cfar2dArgs a{d_X, d_thr, d_noise, d_mask, R, D, kind, train_r, train_d, guard_r, guard_d, scale, k_rank, 0};
+            dim3 grid((D + CA_TC - 1) / CA_TC, (R + CA_TR - 1) / CA_TR, n_frames);
+            hipLaunchKernelGGL(k_cfar2d_ca, grid, dim3(256), lds_ca, ctx->stream, a);
+            return check_launch("cfar2d_ca");
+        }
+    }
     const size_t n_tile = (size_t)(CFAR_TR + 2 * hr) * (CFAR_TC + 2 * hd);
     size_t npad = 1;
     while (npad < n_tile) npad <<= 1;
