@@ -387,11 +387,15 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
         if (rd_mixed_plan(S, C, sizeof(cplx<double>), &mp) && !env_int("MMW_NO_MIXED_RD", 0))
             return launch_rd_mixed<double, true>(ctx, (const cplx<float> *)d_cubes + (long)rx_idx * S * C,
                                                  (long)V * S * C, d_mag, n_frames, S, C);
-    MMW_TRY(ensure_scratch(ctx, (size_t)n_frames * S * C * sizeof(cplx<double>)));
+    // two passes with a complex128 intermediate: chunks of frames small enough for the intermediate to stay in the
+    // Infinity Cache between them (128 MB; it also bounds the scratch: all 1250 frames of the bench at once were 640 MB)
+    const size_t plane_bytes = (size_t)S * C * sizeof(cplx<double>);
+    long chunk = (long)(((size_t)tune_int("MMW_RD64_CHUNK_MB", 128) << 20) / plane_bytes);
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_frames) chunk = n_frames;
+    MMW_TRY(ensure_scratch(ctx, (size_t)chunk * plane_bytes));
     FftArgs a{};
-    a.in = (const cplx<float> *)d_cubes + (long)rx_idx * S * C;
     a.out = ctx->scratch;
-    a.outer = n_frames;
     a.inner = C;
     a.n_in = S;
     a.in_outer_stride = (long)V * S * C;
@@ -401,11 +405,8 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &a.win_axis));
     MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &a.win_inner));
     a.scale = 1.0;
-    MMW_TRY((launch_fft_axis<double, float>(ctx, a, S, false)));
     FftArgs b{};
     b.in = ctx->scratch;
-    b.out = d_mag;
-    b.outer = n_frames * S;
     b.inner = 1;
     b.n_in = C;
     b.in_outer_stride = b.out_outer_stride = C;
@@ -413,7 +414,16 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     b.scale = 1.0;
     b.shift = 1;
     b.magnitude = 1;
-    return launch_fft_axis<double, double>(ctx, b, C, true);
+    for (long f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = (int)std::min<long>(chunk, n_frames - f0);
+        a.in = (const cplx<float> *)d_cubes + (f0 * V + rx_idx) * (long)S * C;
+        a.outer = nf;
+        MMW_TRY((launch_fft_axis<double, float>(ctx, a, S, false)));
+        b.out = d_mag + f0 * (long)S * C;
+        b.outer = nf * S;
+        MMW_TRY((launch_fft_axis<double, double>(ctx, b, C, true)));
+    }
+    return MMW_OK;
 }
 
 int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S,
