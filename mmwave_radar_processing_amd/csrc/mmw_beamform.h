@@ -214,9 +214,9 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void k_capon_batch(const cplx<float> *__restrict__ X, const cplx<double> *__restrict__ Ast,
+__global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__restrict__ X, const cplx<double> *__restrict__ Ast,
                                                       float *__restrict__ out, int V, int R, int K, int T, long n_bins,
-                                                      double delta) {
+                                                      double delta, long long *clk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     char *base = smem + (size_t)w * CAPON_WAVE_LDS;
@@ -227,10 +227,25 @@ __global__ __launch_bounds__(256) void k_capon_batch(const cplx<float> *__restri
     // rows >= V of the tile stay zero
     for (int e = l; e < 16 * CAPON_XP; e += 64) Xs[e] = cplx<float>{0.f, 0.f};
     wave_lds_sync();
+    // Steering vectors by recurrence: a_v(theta) = z^v with z = a_1 = exp(-j pi sin(theta)).  A lane serves the same
+    // angles t = l, l + 64, ... for every bin, so their z live in registers for the whole kernel; the table form read
+    // a_i[t] from global memory inside the substitution loop -- twelve dependent L2 round trips per angle and bin, which
+    // made phase 4 ~60 k of the ~67 k clocks a wave spent on a bin.  (11 complex products: ~3e-15 relative.)
+    constexpr int ZR = 4;                       // angle rounds held in registers (T <= 256); further rounds reload z
+    cplx<double> zreg[ZR];
+#pragma unroll
+    for (int q = 0; q < ZR; ++q) {
+        const int t = l + 64 * q;
+        zreg[q] = (t < T && V > 1) ? Ast[(long)T + t] : cplx<double>{1.0, 0.0};
+    }
     for (long bin = (long)blockIdx.x * 4 + w; bin < n_bins; bin += (long)gridDim.x * 4) {
         const long f = bin / R;
         const int r = (int)(bin - f * R);
         const cplx<float> *xb = X + ((f * V) * R + r) * (long)K;        // antenna v at xb + v * R * K
+        auto mark = [&](int i) {        // diagnostics (MMW_PHASE_CLOCKS=1): phase boundaries of workgroup 0, wave 0
+            if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[i] = (long long)__builtin_amdgcn_s_memtime();
+        };
+        mark(0);
         // ---- 1 + 2: covariance
         v4d cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
         for (int k0 = 0; k0 < K; k0 += CAPON_KT) {
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(256) void k_capon_batch(const cplx<float> *__restri
             }
             wave_lds_sync();
         }
+        mark(1);
         // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
         const double invK = 1.0 / (double)K;
 #pragma unroll
@@ -287,22 +303,30 @@ __global__ __launch_bounds__(256) void k_capon_batch(const cplx<float> *__restri
             }
             wave_lds_sync();
         }
+        mark(2);
         // ---- 4: P(theta) = 1 / |L^-1 a(theta)|^2
-        for (int t = l; t < T; t += 64) {
+        auto solve = [&](int t, cplx<double> z) {
             cplx<double> y[16];
+            cplx<double> a = cplx<double>{1.0, 0.0};      // a_0
             double p = 0.0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (i < V) {
-                    cplx<double> s = Ast[(long)i * T + t];
+                    cplx<double> s = a;
 #pragma unroll
                     for (int k = 0; k < i; ++k) s = s - cmul(Mx[i][k], y[k]);      // Mx[i][k]: same address in every lane
                     y[i] = s * inv_d[i];
                     p += y[i].x * y[i].x + y[i].y * y[i].y;
+                    a = cmul(a, z);
                 }
             }
             out[bin * T + t] = (float)(1.0 / p);
-        }
+        };
+#pragma unroll
+        for (int q = 0; q < ZR; ++q)
+            if (l + 64 * q < T) solve(l + 64 * q, zreg[q]);
+        for (int t = l + 64 * ZR; t < T; t += 64) solve(t, V > 1 ? Ast[(long)T + t] : cplx<double>{1.0, 0.0});
+        mark(3);
         wave_lds_sync();
     }
 }
@@ -325,8 +349,21 @@ inline int capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d
     // three workgroups (12 waves) fit a CU's LDS; a few per CU, each wave walking its share of the bins
     const long want = (n_bins + 3) / 4;
     const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 3 * std::max(1, tune_int("MMW_CAPON_WG_ROUNDS", 2)));
+    if (tune_int("MMW_PHASE_CLOCKS", 0)) {
+        long long *d = nullptr, h[4] = {0};
+        MMW_HIP(hipMalloc((void **)&d, sizeof(h)));
+        MMW_HIP(hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
+        hipLaunchKernelGGL(k_capon_batch, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
+                           (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, n_bins, delta, d);
+        MMW_HIP(hipStreamSynchronize(ctx->stream));
+        MMW_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+        MMW_HIP(hipFree(d));
+        std::fprintf(stderr, "capon clocks (last bin of workgroup 0 wave 0): covariance %lld, Cholesky %lld, substitution %lld\n",
+                     h[1] - h[0], h[2] - h[1], h[3] - h[2]);
+        return check_launch("capon");
+    }
     hipLaunchKernelGGL(k_capon_batch, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
-                       (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, n_bins, delta);
+                       (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, n_bins, delta, (long long *)nullptr);
     return check_launch("capon");
 }
 
