@@ -156,19 +156,10 @@ __device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<floa
 
 template <int VIN, bool MAG, bool NT, bool ZE>
 __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, void *__restrict__ out,
-                                                  long pairs_per_frame, AngleWin win, int shift_off, int n_frames) {
+                                                  long pairs_per_frame, AngleWin win, int shift_off) {
     typedef cplx<float> C;
-    // n_frames == 0: grid.x covers pairs of adjacent bins of one frame; grid.y = frame.
-    // n_frames > 0 (rows of the output not 128-B aligned): grid.x = 8 * tiles, grid.y = groups of 8 frames, and workgroup
-    // x handles tile x / 8 of frame 8 y + x % 8.  Hardware dispatch is round-robin over the 8 XCDs, so ALL tiles of a
-    // frame run on one XCD: the cache lines that straddle two tiles' 4 KB pieces of an angle row then meet in that XCD's L2
-    // and leave as whole lines instead of two partial writes from two L2s (6300-bin rows: 4.3 -> TB/s, tools/angle_shape.py).
-    long f = blockIdx.y, tile = blockIdx.x;
-    if (n_frames > 0) {
-        f = (long)blockIdx.y * 8 + (blockIdx.x & 7);
-        tile = blockIdx.x >> 3;
-        if (f >= n_frames) return;
-    }
+    // grid.x covers pairs of adjacent bins of one frame; grid.y = frame
+    const long f = blockIdx.y, tile = blockIdx.x;
     const long pair = tile * 256 + threadIdx.x;
     if (pair >= pairs_per_frame) return;
     const f32x4 *src = rd + f * VIN * pairs_per_frame + pair;
@@ -191,7 +182,8 @@ __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, v
 // k_angle64_rows: k_angle64 for planes whose bin count is not a multiple of 16, i.e. whose angle rows [bins] c64 do not
 // start on 128-B lines (most shipped cfgs: 63 x 100, 63 x 70, 254 x 50 ...).  There a wave's 1 KB store instruction
 // straddles 9 lines instead of covering 8 (12 write requests per instruction instead of 8) and the store stream drops
-// from ~5.5 to ~4.3 TB/s (tools/angle_shape.py).  Here every WAVE computes 128 cells but stores, per row, the 112-cell
+// from ~5.5 to ~4.3 TB/s (tools/angle_shape.py; running all tiles of a frame on one XCD, so that split lines meet in
+// one L2, changed nothing -- it is the request count per instruction).  Here every WAVE computes 128 cells but stores, per row, the 112-cell
 // (7-line) window of them that is line aligned for THAT row; consecutive waves overlap by 16 cells (12.5 % more loads
 // and arithmetic, both far from their limits) and every store instruction writes whole lines.  Only the row ends share
 // a line with the next row (one per 50 KB).
@@ -340,10 +332,6 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)F);
-    // frame-per-XCD mapping when the 4 KB pieces of an output row do not start on cache-line boundaries
-    const bool xcd_frames = (bins * (mag ? 4 : 8)) % 128 != 0 ? tune_int("MMW_ANGLE_XCD_FRAMES", 1) != 0 : tune_int("MMW_ANGLE_XCD_FRAMES", 0) == 2;
-    if (xcd_frames) grid = dim3(grid.x * 8, (unsigned)((F + 7) / 8));
-    const int nf_arg = xcd_frames ? F : 0;
     const bool nt = tune_int("MMW_ANGLE_NT", 1) != 0;
     const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f && tune_int("MMW_ANGLE_ZE", 1) != 0;
     if (bins % 2) {         // angle_fast_path admits odd bin counts only for complex output
@@ -362,7 +350,7 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     }
 #define MMW_ANGLE_LAUNCH(MAGV, NTV, ZEV) \
     hipLaunchKernelGGL((k_angle64<VIN, MAGV, NTV, ZEV>), grid, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, \
-                       shift ? 32 : 0, nf_arg)
+                       shift ? 32 : 0)
     if (ze) {
         if (mag && nt) MMW_ANGLE_LAUNCH(true, true, true);
         else if (mag) MMW_ANGLE_LAUNCH(true, false, true);
