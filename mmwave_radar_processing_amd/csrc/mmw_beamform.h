@@ -214,6 +214,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int HV>       // antennas V <= 2 HV: sizes the register arrays (prefetched rows, substitution vector)
 __global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__restrict__ X, const cplx<double> *__restrict__ Ast,
                                                       float *__restrict__ out, int V, int R, int K, int T, long n_bins,
                                                       double delta, long long *clk) {
@@ -231,14 +232,40 @@ __global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__res
     // angles t = l, l + 64, ... for every bin, so their z live in registers for the whole kernel; the table form read
     // a_i[t] from global memory inside the substitution loop -- twelve dependent L2 round trips per angle and bin, which
     // made phase 4 ~60 k of the ~67 k clocks a wave spent on a bin.  (11 complex products: ~3e-15 relative.)
-    constexpr int ZR = 4;                       // angle rounds held in registers (T <= 256); further rounds reload z
+    constexpr int ZR = 1;                       // angle rounds held in registers (T <= 256); further rounds reload z
     cplx<double> zreg[ZR];
 #pragma unroll
     for (int q = 0; q < ZR; ++q) {
         const int t = l + 64 * q;
         zreg[q] = (t < T && V > 1) ? Ast[(long)T + t] : cplx<double>{1.0, 0.0};
     }
-    for (long bin = (long)blockIdx.x * 4 + w; bin < n_bins; bin += (long)gridDim.x * 4) {
+    // half a wave per antenna row: lane h = l & 31 brings snapshots k0 + 2h, 2h + 1 of rows (l >> 5), (l >> 5) + 2, ...
+    f32x4 pre[HV];
+    auto fetch_chunk = [&](const cplx<float> *xrow, int k0) {
+#pragma unroll
+        for (int i = 0; i < HV; ++i) {
+            const int v = (l >> 5) + 2 * i, k = k0 + 2 * (l & 31);
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (v < V) {
+                const cplx<float> *src = xrow + (long)v * R * K + k;
+                if (k + 1 < K && ((K & 1) == 0)) q = *reinterpret_cast<const f32x4 *>(src);     // 16-B aligned when K is even
+                else {
+                    if (k < K) { q.x = src[0].x; q.y = src[0].y; }
+                    if (k + 1 < K) { q.z = src[1].x; q.w = src[1].y; }
+                }
+            }
+            pre[i] = q;
+        }
+    };
+    auto stash_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < HV; ++i) {
+            const int v = (l >> 5) + 2 * i;
+            if (v < V) *reinterpret_cast<f32x4 *>(&Xs[v * CAPON_XP + 2 * (l & 31)]) = pre[i];
+        }
+    };
+    const long first_bin = (long)blockIdx.x * 4 + w, bin_step = (long)gridDim.x * 4;
+    for (long bin = first_bin; bin < n_bins; bin += bin_step) {
         const long f = bin / R;
         const int r = (int)(bin - f * R);
         const cplx<float> *xb = X + ((f * V) * R + r) * (long)K;        // antenna v at xb + v * R * K
@@ -246,22 +273,18 @@ __global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__res
             if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[i] = (long long)__builtin_amdgcn_s_memtime();
         };
         mark(0);
-        // ---- 1 + 2: covariance
+        // ---- 1 + 2: covariance.  The snapshot chunks are software pipelined: chunk c + 1 travels from global memory to
+        //      registers while the MFMAs of chunk c run out of the LDS tile, and chunk 0 of the NEXT bin during this bin's
+        //      Cholesky (below) -- the exposed load latency was ~2/3 of this phase's 18 k clocks.
         v4d cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < K; k0 += CAPON_KT) {
-            // half a wave per antenna row: lane h = l & 31 brings snapshots k0 + 2h, 2h + 1
-            for (int v = l >> 5; v < V; v += 2) {
-                const int k = k0 + 2 * (l & 31);
-                const cplx<float> *src = xb + (long)v * R * K + k;
-                f32x4 q = {0.f, 0.f, 0.f, 0.f};
-                if (k + 1 < K && ((K & 1) == 0)) q = *reinterpret_cast<const f32x4 *>(src);     // 16-B aligned when K is even
-                else {
-                    if (k < K) { q.x = src[0].x; q.y = src[0].y; }
-                    if (k + 1 < K) { q.z = src[1].x; q.w = src[1].y; }
-                }
-                *reinterpret_cast<f32x4 *>(&Xs[v * CAPON_XP + 2 * (l & 31)]) = q;
-            }
+        if (bin == first_bin) {
+            fetch_chunk(xb, 0);
+            stash_chunk();
             wave_lds_sync();
+        }
+        for (int k0 = 0; k0 < K; k0 += CAPON_KT) {
+            const bool more = k0 + CAPON_KT < K;
+            if (more) fetch_chunk(xb, k0 + CAPON_KT);
 #pragma unroll 4
             for (int kk = 0; kk < CAPON_KT; kk += 4) {
                 const cplx<float> x = Xs[li * CAPON_XP + kk + lk];       // operand maps: A[i = l&15][k = l>>4], B[k][j = l&15]
@@ -272,6 +295,10 @@ __global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__res
                 ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr, xi, ci, 0, 0, 0);
             }
             wave_lds_sync();
+            if (more) {
+                stash_chunk();
+                wave_lds_sync();
+            }
         }
         mark(1);
         // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -279,6 +306,12 @@ __global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__res
 #pragma unroll
         for (int q = 0; q < 4; ++q) Mx[lk + 4 * q][li] = cplx<double>{cr[q] * invK, ci[q] * invK};
         wave_lds_sync();
+        // next bin's first chunk: in flight during the Cholesky, into the (free) tile before the substitution
+        const long nbin = bin + bin_step;
+        if (nbin < n_bins) {
+            const long nf = nbin / R;
+            fetch_chunk(X + ((nf * V) * R + (nbin - nf * R)) * (long)K, 0);
+        }
         // ---- 3: diagonal loading, Cholesky (lower triangle of Mx becomes L, diagonal real)
         double tr = (l < V) ? Mx[l][l].x : 0.0;
         for (int d = 8; d >= 1; d >>= 1) tr += __shfl_xor(tr, d, 64);      // lanes 0..15 hold the 16 diagonal terms
@@ -303,14 +336,18 @@ __global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__res
             }
             wave_lds_sync();
         }
+        if (nbin < n_bins) {
+            stash_chunk();
+            wave_lds_sync();
+        }
         mark(2);
         // ---- 4: P(theta) = 1 / |L^-1 a(theta)|^2
         auto solve = [&](int t, cplx<double> z) {
-            cplx<double> y[16];
+            cplx<double> y[2 * HV];
             cplx<double> a = cplx<double>{1.0, 0.0};      // a_0
             double p = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 2 * HV; ++i) {
                 if (i < V) {
                     cplx<double> s = a;
 #pragma unroll
@@ -349,11 +386,12 @@ inline int capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d
     // three workgroups (12 waves) fit a CU's LDS; a few per CU, each wave walking its share of the bins
     const long want = (n_bins + 3) / 4;
     const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 3 * std::max(1, tune_int("MMW_CAPON_WG_ROUNDS", 2)));
+    auto kern = V <= 4 ? k_capon_batch<2> : V <= 8 ? k_capon_batch<4> : V <= 12 ? k_capon_batch<6> : k_capon_batch<8>;
     if (tune_int("MMW_PHASE_CLOCKS", 0)) {
         long long *d = nullptr, h[4] = {0};
         MMW_HIP(hipMalloc((void **)&d, sizeof(h)));
         MMW_HIP(hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
-        hipLaunchKernelGGL(k_capon_batch, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
                            (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, n_bins, delta, d);
         MMW_HIP(hipStreamSynchronize(ctx->stream));
         MMW_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
@@ -362,7 +400,7 @@ inline int capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d
                      h[1] - h[0], h[2] - h[1], h[3] - h[2]);
         return check_launch("capon");
     }
-    hipLaunchKernelGGL(k_capon_batch, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
                        (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, n_bins, delta, (long long *)nullptr);
     return check_launch("capon");
 }
