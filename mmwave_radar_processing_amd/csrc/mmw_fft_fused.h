@@ -76,7 +76,11 @@ __device__ __forceinline__ bool chain_wait(unsigned *cnt, unsigned target, unsig
     }
 }
 // The eight pruned k1 passes + stores of one thread's two bins (shared by k_angle64 and k_angle64_sync).
-// ROWS 1 (k_angle64_rows): the lane stores row a only if its pair lies in that row's line-aligned window of the wave.
+// Output rows that do not start on 64-B boundaries: alignment unit in cells (complex64: 8, float32 magnitude: 16).
+// Measured (tools/angle_shape.py, plain kernel): rows aligned to 128 B / 64 B / 32 B / 16 B give 5.1 / 5.4 / 4.7 / 4.1 TB/s
+// for complex and 5.5 / 5.2 / 4.2 / 3.8 TB/s for magnitude output -- 64 B is enough.
+constexpr int angle_rows_unit(bool mag) { return mag ? 16 : 8; }
+// ROWS 1 (k_angle64_rows): the lane stores row a only if its pair lies in that row's 64-B aligned window of the wave.
 // ROWS 2 (k_angle64_rows_odd): odd bin count -- `pairs_per_frame` is the BIN count, `pair` the lane's first cell c0, and
 // rows that start at an odd cell offset store (second cell, next lane's first cell) so that every 16-B store is aligned.
 template <int VIN, bool MAG, bool NT, int ROWS = 0>
@@ -134,10 +138,11 @@ __device__ __forceinline__ void angle64_passes(cplx<float> (&xa)[VIN], cplx<floa
                 return;
             }
             if constexpr (ROWS == 1) {
-                // row a starts m cells past a cache-line boundary (m = a * bins mod 16; the + 32 of the fftshift drops out):
-                // this wave's aligned 112-cell window of the row begins m cells before its nominal base
-                const int lo = 8 - ((((k1 + 8 * k2) * b16) & 15) >> 1);
-                if (!(pair_ok && lane >= lo && lane < lo + 56)) return;
+                // row a starts m cells past a 64-B boundary (m = a * bins mod U, U = 64 B of output cells; the + 32 of the
+                // fftshift drops out): this wave's aligned (128 - U)-cell window of the row begins m cells before its base
+                constexpr int U = angle_rows_unit(MAG);
+                const int lo = U / 2 - ((((k1 + 8 * k2) * b16) & (U - 1)) >> 1);
+                if (!(pair_ok && lane >= lo && lane < lo + (128 - U) / 2)) return;
             }
             if constexpr (MAG) {
                 // |.| as sqrt(x^2 + y^2): spectrum values are far from the float32 range limits, so hypotf's rescaling
@@ -187,15 +192,16 @@ __global__ __launch_bounds__(256) void k_angle64(const f32x4 *__restrict__ rd, v
 // (7-line) window of them that is line aligned for THAT row; consecutive waves overlap by 16 cells (12.5 % more loads
 // and arithmetic, both far from their limits) and every store instruction writes whole lines.  Only the row ends share
 // a line with the next row (one per 50 KB).
-template <int VIN, bool ZE>
-__global__ __launch_bounds__(256) void k_angle64_rows(const f32x4 *__restrict__ rd, void *__restrict__ out,
-                                                       long pairs_per_frame, AngleWin win, int shift_off, int b16, int n_waves) {
+template <int VIN, bool ZE, bool MAG>
+__global__ __launch_bounds__(256, (VIN <= 12 && ZE && !MAG) ? 3 : 2) void k_angle64_rows(const f32x4 *__restrict__ rd, void *__restrict__ out,
+                                                       long pairs_per_frame, AngleWin win, int shift_off, int bu, int n_waves) {
     typedef cplx<float> C;
+    constexpr int U = angle_rows_unit(MAG), WL = (128 - U) / 2;       // stored lanes per wave and row
     const int lane = threadIdx.x & 63;
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= n_waves) return;
     const long f = blockIdx.y;
-    const long pair = wv * 56 - 8 + lane;           // cells 112 wv - 16 + 2 lane, + 1
+    const long pair = wv * WL - U / 2 + lane;       // cells (128 - U) wv - U + 2 lane, + 1
     const bool ok = pair >= 0 && pair < pairs_per_frame;
     const f32x4 *src = rd + f * VIN * pairs_per_frame + (ok ? pair : 0);
     C xa[VIN], xb[VIN];
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256) void k_angle64_rows(const f32x4 *__restrict__ 
         xa[v] = C{t.x * h, t.y * h};
         xb[v] = C{t.z * h, t.w * h};
     }
-    angle64_passes<VIN, false, true, 1>(xa, xb, out, f, pairs_per_frame, pair, shift_off, b16, lane, ok);
+    angle64_passes<VIN, MAG, true, 1>(xa, xb, out, f, pairs_per_frame, pair, shift_off, bu, lane, ok);
 }
 
 // k_angle64_rows_odd: the same for an ODD bin count (63 x 127, 63 x 115): planes and rows then start at odd cell offsets,
@@ -284,8 +290,9 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4
         bool ok = pair < pairs_per_frame, run = ok;
         [[maybe_unused]] bool ok_b = true, ok_n = true;
         if constexpr (ROWS == 1) {
+            constexpr int U = angle_rows_unit(MAG);
             const long wv = (long)tile * 4 + (tid >> 6);
-            pair = wv * 56 - 8 + (tid & 63);            // cells 112 wv - 16 + 2 lane, + 1
+            pair = wv * ((128 - U) / 2) - U / 2 + (tid & 63);
             ok = pair >= 0 && pair < pairs_per_frame;
             run = wv < n_waves;
         }
@@ -326,6 +333,15 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4
     }
 }
 
+// even bin counts whose rows are not 64-B aligned take the row-window kernels
+inline bool angle_rows_needed(long bins, bool mag) {
+    return bins % 2 == 0 && bins % angle_rows_unit(mag) != 0 && tune_int("MMW_ANGLE_ROWS", 1) != 0;
+}
+inline int angle_rows_waves(long bins, bool mag) {      // waves per frame: the last window must reach the row end for every m
+    const int U = angle_rows_unit(mag);
+    return (int)((bins + (U - 2) + (128 - U) - 1) / (128 - U));
+}
+
 template <int VIN>
 int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bool mag, const float *h, bool shift) {
     AngleWin w;
@@ -341,11 +357,16 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
         else hipLaunchKernelGGL((k_angle64_rows_odd<VIN, false>), g, dim3(256), 0, ctx->stream, (const cplx<float> *)rd, out, bins, w, shift ? 32 : 0, (int)(bins & 15), n_waves);
         return check_launch("angle64_rows_odd");
     }
-    if (!mag && bins % 16 != 0 && tune_int("MMW_ANGLE_ROWS", 1)) {
-        const int n_waves = (int)((bins + 14 + 111) / 112);
+    if (angle_rows_needed(bins, mag)) {
+        const int n_waves = angle_rows_waves(bins, mag), bu = (int)(bins & (angle_rows_unit(mag) - 1));
         dim3 g((unsigned)((n_waves + 3) / 4), (unsigned)F);
-        if (ze) hipLaunchKernelGGL((k_angle64_rows<VIN, true>), g, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, shift ? 32 : 0, (int)(bins & 15), n_waves);
-        else hipLaunchKernelGGL((k_angle64_rows<VIN, false>), g, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, shift ? 32 : 0, (int)(bins & 15), n_waves);
+#define MMW_ANGLE_ROWS_LAUNCH(ZEV, MAGV) \
+    hipLaunchKernelGGL((k_angle64_rows<VIN, ZEV, MAGV>), g, dim3(256), 0, ctx->stream, (const f32x4 *)rd, out, pairs, w, shift ? 32 : 0, bu, n_waves)
+        if (ze && mag) MMW_ANGLE_ROWS_LAUNCH(true, true);
+        else if (ze) MMW_ANGLE_ROWS_LAUNCH(true, false);
+        else if (mag) MMW_ANGLE_ROWS_LAUNCH(false, true);
+        else MMW_ANGLE_ROWS_LAUNCH(false, false);
+#undef MMW_ANGLE_ROWS_LAUNCH
         return check_launch("angle64_rows");
     }
 #define MMW_ANGLE_LAUNCH(MAGV, NTV, ZEV) \
@@ -367,10 +388,10 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
 }
 
 // angle work items per frame of the device-synchronised chain
-inline bool angle_sync_rows(long bins, bool mag) { return !mag && bins % 16 != 0 && tune_int("MMW_ANGLE_ROWS", 1) != 0; }
+inline bool angle_sync_rows(long bins, bool mag) { return angle_rows_needed(bins, mag); }
 inline int angle_sync_tiles(long bins, bool mag) {
     if (bins % 2) return (int)(((bins + 15 + 111) / 112 + 3) / 4);
-    if (angle_sync_rows(bins, mag)) return (int)(((bins + 14 + 111) / 112 + 3) / 4);
+    if (angle_sync_rows(bins, mag)) return (angle_rows_waves(bins, mag) + 3) / 4;
     return (int)((bins / 2 + 255) / 256);
 }
 
@@ -388,9 +409,14 @@ int launch_angle64_sync(mmw_ctx *ctx, const void *ring, void *out, long bins, bo
         return check_launch("angle64_sync_rows_odd");
     }
     if (angle_sync_rows(bins, mag)) {       // cs.tiles was sized for this variant by angle_sync_tiles()
-        const int n_waves = (int)((bins + 14 + 111) / 112);
-        if (ze) hipLaunchKernelGGL((k_angle64_sync<VIN, false, true, 1>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
-        else hipLaunchKernelGGL((k_angle64_sync<VIN, false, false, 1>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, (int)(bins & 15), n_waves);
+        const int n_waves = angle_rows_waves(bins, mag), bu = (int)(bins & (angle_rows_unit(mag) - 1));
+#define MMW_ANGLE_SYNC_ROWS(MAGV, ZEV) \
+    hipLaunchKernelGGL((k_angle64_sync<VIN, MAGV, ZEV, 1>), dim3(grid), dim3(256), 0, ctx->stream, ring, out, pairs, w, shift ? 32 : 0, cs, bu, n_waves)
+        if (ze && mag) MMW_ANGLE_SYNC_ROWS(true, true);
+        else if (ze) MMW_ANGLE_SYNC_ROWS(false, true);
+        else if (mag) MMW_ANGLE_SYNC_ROWS(true, false);
+        else MMW_ANGLE_SYNC_ROWS(false, false);
+#undef MMW_ANGLE_SYNC_ROWS
         return check_launch("angle64_sync_rows");
     }
 #define MMW_ANGLE_SYNC(MAGV, ZEV) \

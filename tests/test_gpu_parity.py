@@ -1178,30 +1178,35 @@ def test_doppler_azimuth_entry_fused_range_mean(V, S, C, A, win, monkeypatch):
 
 
 @pytest.mark.parametrize("V,S,C", [(12, 63, 100), (8, 21, 10), (4, 25, 26), (12, 2, 5), (16, 7, 18), (12, 127, 2),
-                                   (12, 63, 127), (8, 21, 11), (4, 5, 5), (16, 1, 1), (12, 9, 25), (12, 3, 37)])
-@pytest.mark.parametrize("flags", [0, _lib.ANGLE_NO_WINDOW | _lib.ANGLE_NO_SHIFT])
+                                   (12, 63, 127), (8, 21, 11), (4, 5, 5), (16, 1, 1), (12, 9, 25), (12, 3, 37),
+                                   (12, 90, 100), (8, 13, 24), (4, 3, 4), (12, 7, 40)])
+@pytest.mark.parametrize("flags", [0, _lib.ANGLE_NO_WINDOW | _lib.ANGLE_NO_SHIFT, _lib.ANGLE_MAGNITUDE])
 def test_angle_rows_kernel_on_misaligned_rows(V, S, C, flags):
     """k_angle64_rows / k_angle64_rows_odd (bins % 16 != 0: every wave stores a per-row line-aligned window of the cells it computed) against
     numpy's FFT over the antenna axis (range_angle_resp_dbs_enhanced.py:175-196), several frames so that the frame
     stride, the first / last wave of a row and rows with every misalignment (a * bins mod 16) are hit."""
     ctx = _lib.default_context()
     F, A, bins = 3, 64, S * C
-    assert bins % 16 != 0                   # odd bin counts: k_angle64_rows_odd
+    assert bins % 16 != 0                   # odd bin counts: k_angle64_rows_odd (complex output only: generic kernel for |.|)
     rng = np.random.default_rng(V * 1000 + bins)
     rd = (rng.standard_normal((F, V, S, C)) + 1j * rng.standard_normal((F, V, S, C))).astype(np.complex64)
-    d_rd, d_out = ctx.alloc(rd.nbytes), ctx.alloc(F * A * bins * 8 + 256)
+    mag = bool(flags & _lib.ANGLE_MAGNITUDE)
+    esz = 4 if mag else 8
+    d_rd, d_out = ctx.alloc(rd.nbytes), ctx.alloc(F * A * bins * esz + 256)
     d_rd.upload(rd)
     guard = np.full(32, 7.0 + 7.0j, np.complex64)           # nothing may be written past the last row
-    d_out.upload(guard, byte_offset=F * A * bins * 8)
+    d_out.upload(guard, byte_offset=F * A * bins * esz)
     _lib.check(ctx.lib.mmw_angle_fft(ctx.handle, d_rd.ptr, d_out.ptr, F, V, S, C, A, flags))
-    got = d_out.download((F, A, S, C), np.complex64)
-    np.testing.assert_array_equal(d_out.download((32,), np.complex64, byte_offset=F * A * bins * 8), guard)
+    got = d_out.download((F, A, S, C), np.float32 if mag else np.complex64)
+    np.testing.assert_array_equal(d_out.download((32,), np.complex64, byte_offset=F * A * bins * esz), guard)
     x = rd.astype(np.complex128)
     if not flags & _lib.ANGLE_NO_WINDOW:
         x = x * np.hanning(V)[None, :, None, None]
     ref = np.fft.fft(x, n=A, axis=1)
     if not flags & _lib.ANGLE_NO_SHIFT:
         ref = np.fft.fftshift(ref, axes=1)
+    if mag:
+        ref = np.abs(ref)
     assert rel_err(got, ref) <= SPEC_TOL
     d_rd.free()
     d_out.free()
