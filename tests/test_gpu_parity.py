@@ -1293,15 +1293,16 @@ def test_range_zoom_chirpz_against_float64_sum():
     d_out.free()
 
 
-@pytest.mark.parametrize("S,C,F", [(63, 100, 700), (254, 50, 150), (64, 40, 900), (63, 127, 200), (100, 100, 300), (63, 115, 160)])
-def test_device_synchronised_chain_on_shipped_cfg_shapes(monkeypatch, S, C, F):
+@pytest.mark.parametrize("S,C,F,V", [(63, 100, 700, 12), (254, 50, 150, 12), (64, 40, 900, 12), (63, 127, 200, 12), (100, 100, 300, 12),
+                                     (63, 115, 160, 12), (127, 32, 900, 4), (63, 70, 500, 8), (32, 32, 2000, 16)])
+def test_device_synchronised_chain_on_shipped_cfg_shapes(monkeypatch, S, C, F, V):
     """The device-synchronised chain with the compile-time mixed-radix range-Doppler producer (k_rd_mixed_ct MODE 2) and,
     where the angle rows are not line aligned, the row-window consumer (k_angle64_sync ROWS): serial vs events vs sync
     agree to float32 rounding, sync is bit-identical with itself for any batch length, frame 0 / last match the oracle.
     63 x 127 and 63 x 115 have odd bin counts: per-cell ring reads and shifted pairs in the consumer (ROWS 2)."""
     ctx = _lib.default_context()
     L, h = ctx.lib, ctx.handle
-    V, A = 12, 64
+    A = 64
     d_in = ctx.alloc(F * V * S * C * 8)
     d_out = ctx.alloc(F * A * S * C * 8)
     _lib.check(L.mmw_synth_cubes(h, d_in.ptr, F, V, S, C, 777, 6, 30.0))
