@@ -504,6 +504,7 @@ int get_rader_tables(mmw_ctx *ctx, int P, int r1, int r2, RaderTab *rt) {
 bool rd_split_ct_supported(int S, int C);       // mmw_fft_split_ct.h: planes of 2 x 16384 cells, single pass
 int launch_rd_split_ct(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv);
 bool rd_mixed_ct_supported(int S, int C);
+bool rd_mixed_ct_raw_sync_supported(int S, int C);
 int launch_rd_mixed_ct(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
                        const ChainSync *cs = nullptr, int sync_cus = 0, int *sync_grid = nullptr, bool query_only = false);
 

@@ -197,7 +197,7 @@ __device__ __forceinline__ void dft_level_any_ct(cplx<float> *lds, const cplx<fl
 // storing wave drains its stores, and one lane bumps the slot's counter after the workgroup barrier.
 template <int S, int C, int NT, int MODE>
 __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
-    constexpr bool PERSIST = MODE >= 1, SYNC = MODE == 2;
+    constexpr bool PERSIST = MODE >= 1, SYNC = MODE >= 2, RAWSYNC = MODE == 3;     // MODE 3: SYNC on the raw [F][nrx][S][ntx C] cube
     constexpr int S1 = mixct::best_n1(S), S2 = S / S1, C1 = mixct::best_n1(C), C2 = C / C1;
     constexpr int Cp = C | 1, CELLS = S * C;
     static_assert(S1 > 0 && C1 > 0, "no factorisation within the register-resident radices");
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     int *lds_ctl = reinterpret_cast<int *>(win_c + C);                 // SYNC: [0] / [1] tickets (double buffered), [2] abort
     const int tid = threadIdx.x;
     const bool raw = !PERSIST && a.raw.ntx > 1;
-    const int ntx = raw ? a.raw.ntx : 1;
-    constexpr bool PAIRED = C % 2 == 0;         // two adjacent chirps per 16-B load (virtual-array cubes)
+    const int ntx = raw ? a.raw.ntx : (RAWSYNC ? a.cs.ntx : 1);
+    constexpr bool PAIRED = C % 2 == 0 && !RAWSYNC;         // two adjacent chirps per 16-B load (virtual-array cubes)
     constexpr int PAIRS = CELLS / 2, PROUNDS = PAIRED ? (PAIRS + NT - 1) / NT : 1, EROUNDS = (CELLS + NT - 1) / NT;
     f32x4 pre4[PROUNDS];
     cplx<float> pre1[EROUNDS];
@@ -228,7 +228,8 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
 #pragma unroll
             for (int q = 0; q < EROUNDS; ++q) {
                 const int e = tid + q * NT;
-                if (CELLS % NT == 0 || q + 1 < EROUNDS || e < CELLS) pre1[q] = __builtin_nontemporal_load(in + e);
+                if (CELLS % NT == 0 || q + 1 < EROUNDS || e < CELLS)
+                    pre1[q] = __builtin_nontemporal_load(in + (RAWSYNC ? (long)e * ntx : (long)e));       // raw: every ntx-th chirp
             }
         }
     };
@@ -260,10 +261,17 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     const ChainSync &cs = a.cs;
     long item = blockIdx.x;
     const long n_items = SYNC ? (long)cs.n_frames * cs.v_live : (PERSIST ? skip_planes(a.planes, a.raw) : 0);
-    // SYNC: item -> input plane (the end antennas are skipped when the chain drops them)
+    // SYNC: item -> plane f * V + v (the end antennas are skipped when the chain drops them; raw cubes: the host's
+    // rx-major order of the live antennas, packed in cs.vmap) and its first sample
     auto sync_plane = [&](long it) {
         const long f = it / cs.v_live;
-        return f * cs.V + (it - f * cs.v_live) + (cs.vskip > 2 ? 1 : 0);
+        const int vi = (int)(it - f * cs.v_live);
+        if constexpr (RAWSYNC) return f * cs.V + (long)((cs.vmap >> (4 * vi)) & 15);
+        else return f * cs.V + vi + (cs.vskip > 2 ? 1 : 0);
+    };
+    auto sync_src = [&](long pl) {
+        if constexpr (RAWSYNC) return raw_plane(in_base, pl, S, C, RawView{cs.ntx, cs.nrx, 0});
+        else return in_base + pl * a.in_plane_stride;
     };
     long plane;
     if constexpr (SYNC) {
@@ -279,7 +287,8 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         plane = raw_block_plane(blockIdx.x, a.planes, a.raw);
         if (plane < 0 || skip_raw_plane(plane, a.raw)) return;
     } else plane = skip_block_plane(item, a.raw);
-    if (PERSIST || (PAIRED && !raw)) fetch(in_base + plane * a.in_plane_stride);
+    if constexpr (SYNC) fetch(sync_src(plane));
+    else if (PERSIST || (PAIRED && !raw)) fetch(in_base + plane * a.in_plane_stride);
     int iter = 0;
     if constexpr (S2 > 1)
         for (int i = tid; i < S; i += NT) tw_s[i] = a.tw2_s[i];
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         long next_item = 0;
         if constexpr (SYNC) {
             next_item = __builtin_amdgcn_readfirstlane(lds_ctl[(iter + 1) & 1]);
-            if (next_item < n_items) fetch(in_base + sync_plane(next_item) * a.in_plane_stride);    // in flight behind the levels
+            if (next_item < n_items) fetch(sync_src(sync_plane(next_item)));    // in flight behind the levels
         }
         phase_mark(a.clk, 2, tid);
         if constexpr (S2 > 1) {
@@ -487,11 +496,13 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
     }
     constexpr size_t lds_bytes = mixct_lds_bytes(S, C);
     if (cs || query_only) {
-        auto kern = k_rd_mixed_ct<S, C, NT, 2>;
+        const bool raw_sync = (cs && cs->ntx > 1) || (query_only && rv.ntx > 1);
+        auto kern = raw_sync ? k_rd_mixed_ct<S, C, NT, 3> : k_rd_mixed_ct<S, C, NT, 2>;
         // (the attribute is per device: set it on every call, a process may drive several devices)
         if (lds_bytes > 64 * 1024)
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        static int per_cu = 0;
+        static int per_cu_tab[2] = {0, 0};
+        int &per_cu = per_cu_tab[raw_sync ? 1 : 0];
         if (!per_cu) {
             int nb = 0;
             MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), NT, lds_bytes));
@@ -574,6 +585,13 @@ int launch_rd_mixed_ct_b(mmw_ctx *ctx, const void *d_in, long in_plane_stride, v
                          const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only);
 int launch_rd_mixed_ct_c(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
                          const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only);
+// MODE 3 (raw-cube producer of the synchronised chain): three of the 16384-cell power-of-two planes would spill there
+// (32 carried registers of strided element loads beside a 32-point register FFT at 1024 threads); their raw chains
+// keep the event schedule
+bool rd_mixed_ct_raw_sync_supported(int S, int C) {
+    if ((S == 512 && C == 32) || (S == 128 && C == 128) || (S == 256 && C == 64)) return false;
+    return rd_mixed_ct_supported(S, C);
+}
 bool rd_mixed_ct_supported(int S, int C) {
 #define X(s, c) if (S == s && C == c) return true;
     MMW_MIXED_CT_SHAPES_A(X)

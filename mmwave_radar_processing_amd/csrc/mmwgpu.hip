@@ -761,8 +761,9 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // that filled every CU would keep the range-Doppler workgroups they wait for from ever becoming resident.
     const char *mode = std::getenv("MMW_CHAIN_MODE");
     // (windowed chains only: the un-windowed angle variants of the persistent kernel exceed its register budget)
-    const bool sync_shape = fused_rd_ok(S, C) || (!raw && rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0) &&
-                                                   tune_int("MMW_MIXED_CT_SYNC", 1));
+    // raw cubes: RAWIN variant of the 256 x 128 kernel, MODE 3 of the compile-time mixed-radix ones
+    const bool sync_shape = fused_rd_ok(S, C) || ((raw ? rd_mixed_ct_raw_sync_supported(S, C) : rd_mixed_ct_supported(S, C)) &&
+                                                  !tune_int("MMW_NO_MIXED_CT", 0) && tune_int("MMW_MIXED_CT_SYNC", 1));
     p.sync = allow_sync && p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
     // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
@@ -862,7 +863,8 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     const bool fused = fused_rd_ok(S, C);
     int rd_grid = std::min(plan.rd_cus, n_rd_items);
     if (!fused)     // compile-time mixed-radix producer: several workgroups per CU where they fit
-        MMW_TRY(launch_rd_mixed_ct(ctx, nullptr, 0, nullptr, n_rd_items, S, C, RawView{1, 0}, nullptr, plan.rd_cus, &rd_grid, true));
+        MMW_TRY(launch_rd_mixed_ct(ctx, nullptr, 0, nullptr, n_rd_items, S, C, RawView{rv.ntx > 1 ? rv.ntx : 1, rv.nrx}, nullptr, plan.rd_cus,
+                                   &rd_grid, true));
     const int ang_grid = std::min((ctx->num_cu - plan.rd_cus) * std::max(1, tune_int("MMW_ANGLE_WGS_PER_CU", 3)), n_ang_items);
     hipStream_t main_stream = ctx->stream;
     MMW_HIP(hipEventRecord(ctx->pipe_begin, main_stream));

@@ -1408,3 +1408,37 @@ def test_two_contexts_on_one_device_share_the_synchronised_chain():
     d_in.free()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("nrx,ntx,S,C,F", [(4, 3, 63, 100, 500), (4, 3, 254, 50, 120), (4, 2, 64, 40, 700), (4, 3, 63, 127, 150)])
+def test_raw_cube_device_synchronised_chain_on_shipped_shapes(monkeypatch, nrx, ntx, S, C, F):
+    """mmw_chain3d_raw through the device-synchronised schedule with the raw-cube producer of the compile-time kernels
+    (k_rd_mixed_ct MODE 3: every ntx-th chirp of a raw row, rx-major hand-out order): bit-identical to
+    mmw_virtual_array_reformat + mmw_chain3d on the same schedule, and equal to the serial raw chain to float32 rounding."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    V, A = nrx * ntx, 64
+    rng = np.random.default_rng(S * C + F)
+    raw = (rng.integers(-512, 512, (F, nrx, S, ntx * C)) + 1j * rng.integers(-512, 512, (F, nrx, S, ntx * C))).astype(np.complex64)
+    d_raw, d_virt = ctx.alloc(raw.nbytes), ctx.alloc(raw.nbytes)
+    d_a, d_b = ctx.alloc(F * A * S * C * 8), ctx.alloc(F * A * S * C * 8)
+    d_raw.upload(raw)
+    _lib.check(L.mmw_virtual_array_reformat(h, d_raw.ptr, d_virt.ptr, F, nrx, ntx, S, C))
+
+    def plan(mode):
+        monkeypatch.setenv("MMW_CHAIN_PIPELINE", "0" if mode == "serial" else "1")
+        monkeypatch.setenv("MMW_CHAIN_MODE", "sync")
+
+    plan("sync")
+    _lib.check(L.mmw_chain3d(h, d_virt.ptr, None, d_a.ptr, F, V, S, C, A, 0))
+    _lib.check(L.mmw_chain3d_raw(h, d_raw.ptr, None, d_b.ptr, F, nrx, ntx, S, C, A, 0))
+    a, b = d_a.download((F, A, S, C), np.complex64), d_b.download((F, A, S, C), np.complex64)
+    np.testing.assert_array_equal(a, b)
+    plan("serial")
+    d_b.zero()
+    _lib.check(L.mmw_chain3d_raw(h, d_raw.ptr, None, d_b.ptr, F, nrx, ntx, S, C, A, 0))
+    assert cross_schedule_dev(d_b.download((F, A, S, C), np.complex64), a) <= CROSS_SCHEDULE_TOL
+    virt0 = d_virt.download((V, S, C), np.complex64)
+    assert rel_err(a[0], O.fft3d_windowed(virt0, A)) <= SPEC_TOL
+    for buf in (d_raw, d_virt, d_a, d_b):
+        buf.free()
