@@ -1442,3 +1442,23 @@ def test_raw_cube_device_synchronised_chain_on_shipped_shapes(monkeypatch, nrx, 
     assert rel_err(a[0], O.fft3d_windowed(virt0, A)) <= SPEC_TOL
     for buf in (d_raw, d_virt, d_a, d_b):
         buf.free()
+
+
+def test_chirpz_plan_cache_eviction():
+    """The context keeps at most 8 chirp-z plans (mmw_czt.h); a ninth frequency list drops the oldest.  Twelve lists in a
+    row, then the first again: every result against the float64 sum."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    V, S, C, m = 4, 64, 8, 40
+    cube = synth.synth_cube(77, (V, S, C)).astype(np.complex64)
+    d_in, d_out = ctx.alloc(cube.nbytes), ctx.alloc(m * 4)
+    d_in.upload(cube[None])
+    x = cube[:, :, 2].astype(complex) * np.hanning(S)[None, :]
+    params = [(0.01 + 0.013 * i, 0.0009 + 0.0001 * i) for i in range(12)] + [(0.01, 0.0009)]
+    for f0, df in params:
+        _lib.check(L.mmw_range_zoom(h, d_in.ptr, d_out.ptr, 1, V, S, C, 2, m, f0, df))
+        got = d_out.download((m,), np.float32)
+        Z = np.exp(-2j * np.pi * np.outer(f0 + df * np.arange(m), np.arange(S)))
+        assert rel_err(got, np.mean(np.abs(x @ Z.T), axis=0)) <= SPEC_TOL, (f0, df)
+    d_in.free()
+    d_out.free()
