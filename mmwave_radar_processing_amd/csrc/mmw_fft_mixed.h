@@ -506,7 +506,8 @@ int launch_rd_split_ct(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, 
 bool rd_mixed_ct_supported(int S, int C);
 bool rd_mixed_ct_raw_sync_supported(int S, int C);
 int launch_rd_mixed_ct(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
-                       const ChainSync *cs = nullptr, int sync_cus = 0, int *sync_grid = nullptr, bool query_only = false);
+                       const ChainSync *cs = nullptr, int sync_cus = 0, int *sync_grid = nullptr, bool query_only = false,
+                       float *d_l1 = nullptr);
 
 // planes x [S][C] complex64 at d_in (plane pitch in_plane_stride elements) -> d_out planes, contiguous:
 // T = float: complex64 spectrum; T = double, MAG: float64 magnitude (the CFAR plane).

@@ -52,13 +52,14 @@ constexpr int threads_for(int S, int C) {
     // LDS; two 512-thread workgroups overlap each other's load and store phases (measured +12 % on both)
     if ((S == 90 && C == 80) || (S == 200 && C == 40)) return 512;
     if (S == 63 && C == 115) return 512;        // RegDFT<23> spills under the 128-VGPR cap of 1024 threads
+    if (S == 512 && C == 32) return 512;        // RegFFT<32> + the carried next plane spill at 1024 threads (same speed)
     return wgs < 3 ? 1024 : (wgs < 6 ? 512 : 256);
 }
 }  // namespace mixct
 
 constexpr size_t mixct_lds_bytes(int S, int C) {     // plane, inter-level twiddles, big-prime table, Hann tables, SYNC control words
     const bool big = mixct::best_n1(S) == mixct::BIG_PRIME || mixct::best_n1(C) == mixct::BIG_PRIME;
-    return ((size_t)S * (C | 1) + S + C + (big ? mixct::BIG_PRIME : 0) + (S + C + 1) / 2) * sizeof(cplx<float>) + 16;
+    return ((size_t)S * (C | 1) + S + C + (big ? mixct::BIG_PRIME : 0) + (S + C + 1) / 2) * sizeof(cplx<float>) + 16 + 64;
 }
 
 struct RdMixedCtArgs {
@@ -72,6 +73,8 @@ struct RdMixedCtArgs {
     long planes;
     long long *clk;             // diagnostics (MMW_PHASE_CLOCKS=1): s_memtime at the phase boundaries of workgroup 0
     ChainSync cs;               // MODE 2: the chain's device-synchronised hand-over (mmw_fft_fused.h); `out` is the ring
+    float *l1;                  // MODE 0 / 1, optional: l1[plane] = sum |re| + |im| of the windowed plane (the error-bound
+                                // scale of mmw_angle_argmax_exact, as the 256 x 128 kernel's L1N variant: no extra pass)
 };
 
 __device__ __forceinline__ void phase_mark(long long *clk, int i, int tid) {
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     // Hann tables in the LDS: a global load in the plane loop would wait (in-order vmcnt) for the previous plane's stores
     float *win_s = cst + (BIG ? 2 * mixct::BIG_PRIME : 0), *win_c = win_s + S;
     int *lds_ctl = reinterpret_cast<int *>(win_c + C);                 // SYNC: [0] / [1] tickets (double buffered), [2] abort
+    float *lds_l1 = reinterpret_cast<float *>(lds_ctl + 4);            // one partial L1 norm per wave
     const int tid = threadIdx.x;
     const bool raw = !PERSIST && a.raw.ntx > 1;
     const int ntx = raw ? a.raw.ntx : (RAWSYNC ? a.cs.ntx : 1);
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     constexpr int PAIRS = CELLS / 2, PROUNDS = PAIRED ? (PAIRS + NT - 1) / NT : 1, EROUNDS = (CELLS + NT - 1) / NT;
     f32x4 pre4[PROUNDS];
     cplx<float> pre1[EROUNDS];
+    float l1_acc = 0.f;
     auto fetch = [&](const cplx<float> *in) {
         if constexpr (PAIRED) {
             const f32x4 *in4 = reinterpret_cast<const f32x4 *>(in);
@@ -242,8 +247,10 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
                     const int s = (2 * e) / C, c = (2 * e) - s * C;
                     const f32x4 v = pre4[q];
                     const float ws = win_s[s], w0 = ws * win_c[c], w1 = ws * win_c[c + 1];
-                    lds[s * Cp + c] = cplx<float>{v.x * w0, v.y * w0};
-                    lds[s * Cp + c + 1] = cplx<float>{v.z * w1, v.w * w1};
+                    const cplx<float> y0 = cplx<float>{v.x * w0, v.y * w0}, y1 = cplx<float>{v.z * w1, v.w * w1};
+                    lds[s * Cp + c] = y0;
+                    lds[s * Cp + c + 1] = y1;
+                    if constexpr (!SYNC) l1_acc += (fabsf(y0.x) + fabsf(y0.y)) + (fabsf(y1.x) + fabsf(y1.y));
                 }
             }
         } else {
@@ -252,7 +259,9 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
                 const int e = t + q * NT;
                 if (CELLS % NT == 0 || q + 1 < EROUNDS || e < CELLS) {
                     const int s = e / C, c = e - s * C;
-                    lds[s * Cp + c] = pre1[q] * (win_s[s] * win_c[c]);
+                    const cplx<float> y = pre1[q] * (win_s[s] * win_c[c]);
+                    lds[s * Cp + c] = y;
+                    if constexpr (!SYNC) l1_acc += fabsf(y.x) + fabsf(y.y);
                 }
             }
         }
@@ -330,8 +339,9 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
                 const int e = t + q * NT;
                 if (CELLS % NT == 0 || q + 1 < EROUNDS || e < CELLS) {
                     const int s = e / C, c = e - s * C;
-                    const cplx<float> v = __builtin_nontemporal_load(in + (long)e * ntx);
-                    lds[s * Cp + c] = v * (win_s[s] * win_c[c]);
+                    const cplx<float> y = __builtin_nontemporal_load(in + (long)e * ntx) * (win_s[s] * win_c[c]);
+                    lds[s * Cp + c] = y;
+                    if constexpr (!SYNC) l1_acc += fabsf(y.x) + fabsf(y.y);
                 }
             }
         } else
@@ -339,7 +349,21 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         if constexpr (PERSIST && !SYNC) {
             if (item + gridDim.x < n_items) fetch(in_base + skip_block_plane(item + gridDim.x, a.raw) * a.in_plane_stride);
         }
+        if constexpr (!SYNC) {
+            if (a.l1) {             // (uniform) wave partial by a fixed shuffle tree, then a fixed-order sum: deterministic
+                for (int d = 32; d >= 1; d >>= 1) l1_acc += __shfl_xor(l1_acc, d, 64);
+                if ((tid & 63) == 0) lds_l1[tid >> 6] = l1_acc;
+            }
+            l1_acc = 0.f;
+        }
         __syncthreads();
+        if constexpr (!SYNC) {
+            if (a.l1 && tid == 0) {
+                float acc = 0.f;
+                for (int i = 0; i < NT / 64; ++i) acc += lds_l1[i];
+                a.l1[plane] = acc;
+            }
+        }
         phase_mark(a.clk, 1, tid);
         // ---- range axis: sample s = S2 n1 + n2 lives in row s.  A: groups (column, n2), radix S1; B: groups (column, k1), radix S2
         dft_level_any_ct<S1, NT, C, 1, S2, Cp, S2 * Cp, (S2 > 1)>(lds, tw_s, cst, t, a.clk);
@@ -473,7 +497,8 @@ inline int get_bigprime_table(mmw_ctx *ctx, int P, const void **out) {
 // (each draws one ticket past the end, the host mirrors that in its counter base).  sync_grid only: just report the grid.
 template <int S, int C>
 int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, RawView rv,
-                          const ChainSync *cs = nullptr, int sync_cus = 0, int *sync_grid = nullptr, bool query_only = false) {
+                          const ChainSync *cs = nullptr, int sync_cus = 0, int *sync_grid = nullptr, bool query_only = false,
+                          float *d_l1 = nullptr) {
     constexpr int NT = mixct::threads_for(S, C), S1 = mixct::best_n1(S), C1 = mixct::best_n1(C);
     RdMixedCtArgs a{};
     a.in = d_in;
@@ -481,6 +506,7 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
     a.in_plane_stride = in_plane_stride;
     a.raw = rv;
     a.planes = planes;
+    a.l1 = d_l1;
     const void *p;
     MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &p));
     a.win_s = (const float *)p;
@@ -572,8 +598,8 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
 #define MMW_MIXED_CT_FN launch_rd_mixed_ct_c
 #endif
 int MMW_MIXED_CT_FN(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
-                    const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only) {
-#define X(s, c) if (S == s && C == c) return launch_rd_mixed_ct_sc<s, c>(ctx, d_in, in_plane_stride, d_out, planes, rv, cs, sync_cus, sync_grid, query_only);
+                    const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only, float *d_l1) {
+#define X(s, c) if (S == s && C == c) return launch_rd_mixed_ct_sc<s, c>(ctx, d_in, in_plane_stride, d_out, planes, rv, cs, sync_cus, sync_grid, query_only, d_l1);
     MMW_MIXED_CT_LIST(X)
 #undef X
     return MMW_ERR_UNSUPPORTED;
@@ -582,14 +608,14 @@ int MMW_MIXED_CT_FN(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
 
 #ifdef MMW_TU_MIXED_CT_A
 int launch_rd_mixed_ct_b(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
-                         const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only);
+                         const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only, float *d_l1);
 int launch_rd_mixed_ct_c(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
-                         const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only);
-// MODE 3 (raw-cube producer of the synchronised chain): three of the 16384-cell power-of-two planes would spill there
+                         const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only, float *d_l1);
+// MODE 3 (raw-cube producer of the synchronised chain): two of the 16384-cell power-of-two planes would spill there
 // (32 carried registers of strided element loads beside a 32-point register FFT at 1024 threads); their raw chains
 // keep the event schedule
 bool rd_mixed_ct_raw_sync_supported(int S, int C) {
-    if ((S == 512 && C == 32) || (S == 128 && C == 128) || (S == 256 && C == 64)) return false;
+    if ((S == 128 && C == 128) || (S == 256 && C == 64)) return false;
     return rd_mixed_ct_supported(S, C);
 }
 bool rd_mixed_ct_supported(int S, int C) {
@@ -601,10 +627,10 @@ bool rd_mixed_ct_supported(int S, int C) {
     return false;
 }
 int launch_rd_mixed_ct(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C, RawView rv,
-                       const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only) {
-    int rc = launch_rd_mixed_ct_a(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only);
-    if (rc == MMW_ERR_UNSUPPORTED) rc = launch_rd_mixed_ct_b(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only);
-    if (rc == MMW_ERR_UNSUPPORTED) rc = launch_rd_mixed_ct_c(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only);
+                       const ChainSync *cs, int sync_cus, int *sync_grid, bool query_only, float *d_l1) {
+    int rc = launch_rd_mixed_ct_a(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only, d_l1);
+    if (rc == MMW_ERR_UNSUPPORTED) rc = launch_rd_mixed_ct_b(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only, d_l1);
+    if (rc == MMW_ERR_UNSUPPORTED) rc = launch_rd_mixed_ct_c(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv, cs, sync_cus, sync_grid, query_only, d_l1);
     if (rc == MMW_ERR_UNSUPPORTED) return set_error(MMW_ERR_UNSUPPORTED, "no compile-time mixed-radix kernel for %dx%d", S, C);
     return rc;
 }

@@ -343,7 +343,12 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
             MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C, rv, rv.ntx > 1 ? nullptr : d_l1, &l1_done));
         else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && !(rd_mixed_ct_supported(S, C) && !env_int("MMW_PREFER_LDS_RD", 0)))      // the compile-time kernel is faster where both exist (64 x 64: 6.0 vs 4.4 TB/s)
             MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
-        else if (rd_mixed_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0))
+        else if (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0) && !tune_int("MMW_NO_MIXED_CT", 0)) {
+            // compile-time kernel; on virtual-array cubes it also leaves the planes' L1 norms when asked
+            float *l1 = rv.ntx > 1 ? nullptr : d_l1;
+            MMW_TRY(launch_rd_mixed_ct(ctx, d_cubes, (long)S * C, d_out, n_frames * V, S, C, rv, nullptr, 0, nullptr, false, l1));
+            l1_done = l1 != nullptr;
+        } else if (rd_mixed_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0))
             MMW_TRY((launch_rd_mixed<float, false>(ctx, d_cubes, (long)S * C, d_out, n_frames * V, S, C, rv)));
         else if (rv.ntx <= 1 && rd_split_ct_supported(S, C) && !env_int("MMW_NO_SPLIT_RD", 0))
             MMW_TRY(launch_rd_split_ct(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
