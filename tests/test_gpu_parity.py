@@ -1462,3 +1462,27 @@ def test_chirpz_plan_cache_eviction():
         assert rel_err(got, np.mean(np.abs(x @ Z.T), axis=0)) <= SPEC_TOL, (f0, df)
     d_in.free()
     d_out.free()
+
+
+@pytest.mark.parametrize("S,C,F", [(63, 100, 400), (90, 100, 300), (63, 127, 200)])
+def test_device_synchronised_chain_magnitude_output_on_misaligned_rows(monkeypatch, S, C, F):
+    """MMW_ANGLE_MAGNITUDE through the synchronised chain on planes whose float32 rows are not 64-B aligned (row-window
+    consumer with 16-cell units; 63 x 127 is odd and takes the event schedule with the generic |.| kernel): against the
+    serial schedule and the oracle."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    V, A = 12, 64
+    d_in, d_out = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * A * S * C * 4)
+    _lib.check(L.mmw_synth_cubes(h, d_in.ptr, F, V, S, C, 4711, 6, 30.0))
+    outs = {}
+    for mode in ("serial", "sync"):
+        monkeypatch.setenv("MMW_CHAIN_PIPELINE", "0" if mode == "serial" else "1")
+        monkeypatch.setenv("MMW_CHAIN_MODE", "sync")
+        d_out.zero()
+        _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, _lib.ANGLE_MAGNITUDE))
+        outs[mode] = d_out.download((F, A, S, C), np.float32)
+    assert cross_schedule_dev(outs["sync"], outs["serial"]) <= CROSS_SCHEDULE_TOL
+    cube = d_in.download((V, S, C), np.complex64, byte_offset=(F - 1) * V * S * C * 8)
+    assert rel_err(outs["sync"][F - 1], np.abs(O.fft3d_windowed(cube, A))) <= SPEC_TOL
+    d_in.free()
+    d_out.free()
