@@ -1486,3 +1486,39 @@ def test_device_synchronised_chain_magnitude_output_on_misaligned_rows(monkeypat
     assert rel_err(outs["sync"][F - 1], np.abs(O.fft3d_windowed(cube, A))) <= SPEC_TOL
     d_in.free()
     d_out.free()
+
+
+def _shipped_cube_shapes():
+    with open(os.path.join(GOLDEN, "cfg_scalars.json")) as f:
+        d = json.load(f)
+    return sorted({(e["expect"]["num_rx"] * e["expect"]["num_tx"], e["expect"]["num_samples"], e["expect"]["loops"])
+                   for e in d.values()})
+
+
+@pytest.mark.parametrize("V,S,C", _shipped_cube_shapes())
+def test_every_shipped_cfg_shape_through_the_synchronised_chain(monkeypatch, V, S, C):
+    """Every cube shape (virtual antennas x samples x loops) of the cfg files the reference ships, 160 frames through
+    mmw_chain3d on the serial and on the device-synchronised schedule: the plan must say 'synchronised' (each of them has a
+    single-pass range-Doppler producer and an angle consumer), the schedules agree to float32 rounding and the first and
+    last frame match the oracle."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    A, F = 64, 160
+    d_in, d_out = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * A * S * C * 8)
+    _lib.check(L.mmw_synth_cubes(h, d_in.ptr, F, V, S, C, 9000 + S + C, 6, 30.0))
+    outs = {}
+    for mode in ("serial", "sync"):
+        monkeypatch.setenv("MMW_CHAIN_PIPELINE", "0" if mode == "serial" else "1")
+        monkeypatch.setenv("MMW_CHAIN_MODE", "sync")
+        plan = (_lib.C.c_int * 8)()
+        _lib.check(L.mmw_diag_chain_plan(h, F, V, S, C, A, 0, plan))
+        assert bool(plan[6]) == (mode == "sync"), (mode, list(plan))
+        d_out.zero()
+        _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+        outs[mode] = d_out.download((F, A, S, C), np.complex64)
+    assert cross_schedule_dev(outs["sync"], outs["serial"]) <= CROSS_SCHEDULE_TOL
+    for f in (0, F - 1):
+        cube = d_in.download((V, S, C), np.complex64, byte_offset=f * V * S * C * 8)
+        assert rel_err(outs["sync"][f], O.fft3d_windowed(cube, A)) <= SPEC_TOL
+    d_in.free()
+    d_out.free()
