@@ -11,9 +11,13 @@ ctx = _lib.Context(0)
 L = ctx.lib
 out = {}
 # power-of-two planes, then the (samples, loops) planes of the cfg files the reference ships
-SHAPES = ((12, 64, 64), (12, 128, 128), (12, 256, 128), (12, 512, 64), (12, 256, 256), (12, 512, 128), (8, 128, 64),
-          (12, 63, 70), (12, 63, 100), (12, 100, 100), (12, 90, 100), (12, 200, 40), (12, 254, 50), (12, 63, 127),
-          (4, 127, 32), (12, 130, 50), (12, 63, 115), (12, 70, 40), (12, 120, 126), (12, 512, 32), (12, 512, 8))
+SHAPES = ((12, 64, 64), (12, 128, 128), (12, 256, 128), (12, 512, 64), (12, 128, 256), (12, 256, 256), (12, 512, 128),
+          # (virtual antennas, samples, loops) of the 25 cfg files the reference ships (tests/golden/cfg_scalars.json)
+          (8, 63, 100), (8, 63, 115), (8, 63, 127), (8, 64, 40), (8, 64, 64), (8, 90, 80), (8, 90, 100), (8, 127, 32),
+          (8, 130, 50), (8, 200, 40), (8, 254, 50), (8, 512, 8), (8, 512, 32), (12, 63, 70), (12, 63, 100), (12, 70, 40),
+          (12, 100, 30), (12, 100, 100), (12, 120, 126),
+          # same planes with 12 antennas, as in round 1's table
+          (12, 90, 100), (12, 200, 40), (12, 254, 50), (12, 63, 127), (12, 130, 50), (12, 63, 115))
 for (V, S, C) in SHAPES:
     A = 64
     frames = max(8, min(2048, (4 << 30) // (V * S * C * 8 * 8)))      # <= 4 GiB of 3-D output, >= ~20 waves of workgroups
