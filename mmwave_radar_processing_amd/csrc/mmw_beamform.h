@@ -45,14 +45,20 @@ __global__ __launch_bounds__(256) void k_steer(cplx<float> *W, const double *P, 
 // exact float32 (an fmaf chain in k order), so the 1e-5 spectrum tolerance holds; 4 real MFMAs per complex k pair.
 constexpr int CG_TM = 128, CG_TN = 64, CG_TK = 16, CG_PA = CG_TM + 1, CG_PB = CG_TN + 1;
 constexpr int CG_LDS_FLOATS = 2 * CG_TK * CG_PA + 2 * CG_TK * CG_PB;       // one buffer: Ar, Ai, Br, Bi
+// ksplit > 1 (small batches: a 256 x 64 x 256 product is two workgroups stepping through K one latency at a time):
+// blockIdx.z = batch * ksplit + kz, workgroup kz multiplies the K range [kz kc, (kz + 1) kc) and writes its partial
+// product to Cm + kz * spart; k_sum_parts adds the partials in a fixed order.
 __global__ __launch_bounds__(256) void k_cgemm_mfma(const cplx<float> *__restrict__ A, const cplx<float> *__restrict__ B,
                                                      cplx<float> *__restrict__ Cm, int M, int N, int K, int lda,
-                                                     int ldb, int ldc, long sa, long sb, long sc) {
+                                                     int ldb, int ldc, long sa, long sb, long sc, int ksplit, int kc, long spart) {
     __shared__ float lds[2 * CG_LDS_FLOATS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    A += (long)blockIdx.z * sa;
-    B += (long)blockIdx.z * sb;
-    Cm += (long)blockIdx.z * sc;
+    const int bz = blockIdx.z / ksplit, kz = blockIdx.z - bz * ksplit;
+    A += (long)bz * sa;
+    B += (long)bz * sb;
+    Cm += (long)bz * sc + (long)kz * spart;
+    const int k_begin = kz * kc;
+    if (ksplit > 1) K = K < k_begin + kc ? K : k_begin + kc;
     const int m0 = blockIdx.y * CG_TM, n0 = blockIdx.x * CG_TN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
     // global -> register staging: A rows (thread = row, 8 consecutive k), B rows (thread = k, 4 consecutive n)
@@ -86,11 +92,11 @@ __global__ __launch_bounds__(256) void k_cgemm_mfma(const cplx<float> *__restric
         }
     };
     v16f acc_r[2] = {{0}, {0}}, acc_i[2] = {{0}, {0}};
-    fetch(0);
+    fetch(k_begin);
     stash(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += CG_TK, buf ^= 1) {
+    for (int k0 = k_begin; k0 < K; k0 += CG_TK, buf ^= 1) {
         const bool more = k0 + CG_TK < K;
         if (more) fetch(k0 + CG_TK);                    // in flight while this step's MFMAs run
         const float *Ar = lds + buf * CG_LDS_FLOATS, *Ai = Ar + CG_TK * CG_PA, *Br = Ai + CG_TK * CG_PA, *Bi = Br + CG_TK * CG_PB;
@@ -121,14 +127,32 @@ __global__ __launch_bounds__(256) void k_cgemm_mfma(const cplx<float> *__restric
         }
 }
 
+__global__ __launch_bounds__(256) void k_sum_parts(const cplx<float> *__restrict__ parts, cplx<float> *__restrict__ out, long n,
+                                                    int ksplit) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    cplx<float> acc = parts[i];
+    for (int k = 1; k < ksplit; ++k) acc = acc + parts[(long)k * n + i];
+    out[i] = acc;
+}
+
 // d_X [F][S][E] c64, d_P [F][3][E] f64, d_dirs [3][T] f64 -> d_out [F][S][T] c64
 inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int n_frames, int S,
                     int E, int T, double lambda_m) {
     const int Tp = (T + 3) & ~3;
     const size_t w_bytes = (size_t)n_frames * E * Tp * sizeof(cplx<float>), c_bytes = (size_t)n_frames * S * T * sizeof(cplx<float>);
-    MMW_TRY(ensure_scratch(ctx, w_bytes + c_bytes));
+    // small batches: split K over workgroups until about half the chip is busy (each part at least two K steps)
+    const long wgs = (long)((T + CG_TN - 1) / CG_TN) * ((S + CG_TM - 1) / CG_TM) * n_frames;
+    int ksplit = 1;
+    if (wgs * 2 <= ctx->num_cu && E >= 4 * CG_TK && !tune_int("MMW_CGEMM_NO_KSPLIT", 0))
+        ksplit = (int)std::min<long>(std::min<long>(16, E / (2 * CG_TK)), ctx->num_cu / (2 * wgs));
+    if (ksplit < 2) ksplit = 1;
+    const int kc = ksplit > 1 ? ((E + ksplit - 1) / ksplit + CG_TK - 1) / CG_TK * CG_TK : E;
+    if (ksplit > 1) ksplit = (E + kc - 1) / kc;         // no empty part
+    MMW_TRY(ensure_scratch(ctx, w_bytes + c_bytes * (ksplit > 1 ? ksplit + 1 : 1)));
     cplx<float> *W = (cplx<float> *)ctx->scratch;
     cplx<float> *Cm = (cplx<float> *)((char *)ctx->scratch + w_bytes);
+    cplx<float> *Cparts = Cm + (size_t)n_frames * S * T;
     const void *ham, *hann;
     MMW_TRY(get_table<float>(ctx, TAB_HAMMING, E, &ham));
     MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &hann));
@@ -139,10 +163,15 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
     MMW_TRY(check_launch("steer"));
     {
         ProfScope pg(ctx, "cgemm");
-        dim3 grid((T + CG_TN - 1) / CG_TN, (S + CG_TM - 1) / CG_TM, (unsigned)n_frames);
-        hipLaunchKernelGGL(k_cgemm_mfma, grid, dim3(256), 0, ctx->stream, (const cplx<float> *)d_X, W, Cm, S, T, E, E, Tp, T,
-                           (long)S * E, (long)E * Tp, (long)S * T);
+        dim3 grid((T + CG_TN - 1) / CG_TN, (S + CG_TM - 1) / CG_TM, (unsigned)(n_frames * ksplit));
+        const long n_c = (long)n_frames * S * T;
+        hipLaunchKernelGGL(k_cgemm_mfma, grid, dim3(256), 0, ctx->stream, (const cplx<float> *)d_X, W, ksplit > 1 ? Cparts : Cm, S, T, E,
+                           E, Tp, T, (long)S * E, (long)E * Tp, (long)S * T, ksplit, kc, n_c);
         MMW_TRY(check_launch("cgemm_mfma"));
+        if (ksplit > 1) {
+            hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n_c + 255) / 256)), dim3(256), 0, ctx->stream, Cparts, Cm, n_c, ksplit);
+            MMW_TRY(check_launch("sum_parts"));
+        }
     }
     // hann(S) window and FFT along S for every steering column of every frame (:537-540)
     FftArgs a{};
