@@ -92,3 +92,54 @@ def test_os_cfar_detection_indices_bit_exact_over_many_frames(shape):
     bad = sum(0 if np.array_equal(dets[f], ref[f]) else 1 for f in range(n_frames))
     print(f"OS sweep {shape}: {n_frames} frames, {total} detections, {bad} frames with any index difference")
     assert bad == 0 and total > 0
+
+
+_SEQ_KINDS = {"ca_cfar_1d": ("ca_cfar_1d", dict(num_train=6, num_guard=2, pfa=1e-3)),
+              "go_cfar_1d": ("go_cfar_1d", dict(num_train=6, num_guard=2, pfa=1e-3)),
+              "so_cfar_1d": ("so_cfar_1d", dict(num_train=6, num_guard=2, pfa=1e-3)),
+              "os_cfar_1d": ("os_cfar_1d", dict(num_train=5, num_guard=3, rho=0.6, alpha=2.5))}
+
+
+def _oracle_1d(kind, x, p):
+    from oracle import oracle_np as O
+    if kind == "os_cfar_1d":
+        return O.os_cfar_1d(x, p["num_train"], p["num_guard"], p["rho"], p["alpha"])[2]
+    return getattr(O, kind)(x, p["num_train"], p["num_guard"], p["pfa"])[2]
+
+
+def _oracle_sequential(args):
+    cube, rk, vk = args
+    from oracle import oracle_np as O
+    rows = _oracle_1d(rk, O.range_profile(cube, 0), _SEQ_KINDS[rk][1])
+    mag = np.abs(O.range_doppler(cube)[0])
+    ref = [(r, d) for r in rows for d in _oracle_1d(vk, mag[r], _SEQ_KINDS[vk][1])]
+    return np.array(ref, dtype=np.int64).reshape(-1, 2)
+
+
+@pytest.mark.parametrize("shape", [(12, 256, 128), (12, 63, 100)])
+def test_sequential_detector_all_1d_kinds_over_many_frames(shape):
+    """RangeDopplerDetectorSequential (range CFAR on the range profile, then Doppler CFAR on the selected rows;
+    range_doppler_detector_sequential.py) with every pairing of the four 1-D detectors, frames from the device generator:
+    detection lists identical to the oracle's, values and order."""
+    from mmwave_radar_processing_amd.processors.range_doppler_detection import RangeDopplerDetectorSequential
+    n_frames = max(4, int(os.environ.get("MMW_SWEEP_FRAMES", "96")) // 16)
+    procs = int(os.environ.get("MMW_SWEEP_PROCS", "4"))
+    cm = ConfigManager()
+    cm.load_cfg_text(synth.synth_cfg_text(num_samples=shape[1], num_loops=shape[2]))
+    pipe = FramePipeline(cm, max_frames=n_frames, shape=shape, cfar=CaCFAR2D((4, 4), (2, 2), 1e-5))
+    pipe.synth(n_frames, seed0=910_000)
+    cubes = pipe.cubes(0, n_frames)
+    kinds = list(_SEQ_KINDS)
+    total, bad, cases = 0, 0, 0
+    with get_context("spawn").Pool(procs) as pool:
+        for i, rk in enumerate(kinds):
+            for vk in (kinds[i], kinds[(i + 1) % 4]):
+                det = RangeDopplerDetectorSequential(cm, _SEQ_KINDS[rk][0], dict(_SEQ_KINDS[rk][1]), _SEQ_KINDS[vk][0],
+                                                     dict(_SEQ_KINDS[vk][1]))
+                got = [np.asarray(det.process(cubes[f].astype(np.complex128)), dtype=np.int64).reshape(-1, 2) for f in range(n_frames)]
+                ref = pool.map(_oracle_sequential, [(cubes[f], rk, vk) for f in range(n_frames)])
+                total += sum(r.shape[0] for r in ref)
+                bad += sum(0 if np.array_equal(got[f], ref[f]) else 1 for f in range(n_frames))
+                cases += 1
+    print(f"sequential sweep {shape}: {cases} detector pairings x {n_frames} frames, {total} detections, {bad} frames with any difference")
+    assert bad == 0 and total > 0
