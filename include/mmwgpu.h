@@ -80,6 +80,12 @@ int mmw_synth_cubes(mmw_ctx *ctx, void *d_cubes, int n_frames, int V, int S, int
                     uint64_t seed0, int num_targets, float noise_sigma);
 int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, int n_frames,
                                int num_rx, int num_tx, int S, int loops);
+/* mmw_virtual_array_reformat_i16: the same from int16 I/Q samples, raw [F][num_rx][S][num_tx*loops][2] (I, Q) ->
+ *   complex64 [F][num_rx*num_tx][S][loops] (half the bytes over PCIe and HBM).  NO UPSTREAM ORACLE for this sample
+ *   layout: the reference receives complex cubes from the cpsl_datasets reader, which is not part of its tree
+ *   (SURVEY.md F3); the layout here is "the raw cube of mmw_virtual_array_reformat with int16 I/Q pairs". */
+int mmw_virtual_array_reformat_i16(mmw_ctx *ctx, const void *d_raw_i16, void *d_virt, int n_frames,
+                                   int num_rx, int num_tx, int S, int loops);
 
 /* ---------------------------------------------------------------- FFT chain
  * mmw_range_doppler: d_out[F][V][S][C] c64 = fftshift_C( FFT_S FFT_C( hann(S) hann(C) x ) )

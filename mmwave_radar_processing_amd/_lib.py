@@ -49,6 +49,7 @@ _SIGNATURES = {
     "mmw_timer_stop": [_vp, C.POINTER(_f)],
     "mmw_synth_cubes": [_vp, _vp, _i, _i, _i, _i, C.c_uint64, _i, _f],
     "mmw_virtual_array_reformat": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_virtual_array_reformat_i16": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_doppler": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_range_doppler_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_angle_fft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],

@@ -111,6 +111,22 @@ class FramePipeline:
         _lib.check(self.ctx.lib.mmw_virtual_array_reformat(self.ctx.handle, self.d_raw.ptr, self.d_in.ptr, self.n_frames,
                                                            self.V // num_tx, num_tx, self.S, self.C))
 
+    def load_raw_i16(self, raw_iq: np.ndarray, num_tx: int):
+        """``[F, num_rx, S, num_tx * loops, 2]`` int16 I/Q samples: uploaded as they are (half the bytes of complex64)
+        and converted + de-interleaved on the device.  No upstream oracle for this layout (the reference receives complex
+        cubes from a dataset reader that is not in its tree): it is the raw cube of ``load_raw`` with int16 pairs."""
+        raw = np.ascontiguousarray(raw_iq, dtype=np.int16)
+        num_tx = int(num_tx)
+        if raw.ndim != 5 or raw.shape[4] != 2 or num_tx < 1 or self.V % num_tx or raw.shape[1] != self.V // num_tx or \
+                raw.shape[2:4] != (self.S, num_tx * self.C) or raw.shape[0] > self.max_frames:
+            raise ValueError(f"expected [F<={self.max_frames}, {self.V}/num_tx, {self.S}, num_tx*{self.C}, 2] int16 samples, "
+                             f"got {raw.shape} with num_tx={num_tx}")
+        d_i16 = self.bufs.get("raw_i16", self.max_frames * self.cube_bytes // 2)
+        d_i16.upload(raw)
+        self.n_frames = raw.shape[0]
+        _lib.check(self.ctx.lib.mmw_virtual_array_reformat_i16(self.ctx.handle, d_i16.ptr, self.d_in.ptr, self.n_frames,
+                                                               self.V // num_tx, num_tx, self.S, self.C))
+
     def chain3d_raw(self, magnitude: bool = False):
         """3-D windowed FFT straight from the raw cubes of ``load_raw`` (``mmw_chain3d_raw``)."""
         F, A, S, C = self.n_frames, self.A, self.S, self.C

@@ -74,6 +74,22 @@ __global__ __launch_bounds__(256) void k_reformat(const float2 *raw, float2 *vir
     virt[gid] = raw[((f * num_rx + r) * S + s) * ((long)num_tx * loops) + (long)l * num_tx + t];
 }
 
+// The same de-interleave from int16 I/Q samples: raw[F][num_rx][S][num_tx*loops][2] (I, Q) -> complex64 virtual-array cube.
+// NO UPSTREAM ORACLE for the sample layout: the reference gets its cubes from the absent cpsl_datasets reader;
+// this is "the raw cube mmw_*_raw accepts, with int16 I/Q instead of complex64" -- half the bytes over PCIe and HBM.
+__global__ __launch_bounds__(256) void k_reformat_i16(const short2 *raw, float2 *virt, long total, int num_rx, int num_tx, int S,
+                                                       int loops) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int l = (int)(gid % loops);
+    const int s = (int)((gid / loops) % S);
+    const int va = (int)((gid / ((long)loops * S)) % (num_rx * num_tx));
+    const long f = gid / ((long)loops * S * num_rx * num_tx);
+    const int t = va / num_rx, r = va % num_rx;
+    const short2 v = raw[((f * num_rx + r) * S + s) * ((long)num_tx * loops) + (long)l * num_tx + t];
+    virt[gid] = make_float2((float)v.x, (float)v.y);
+}
+
 __global__ __launch_bounds__(256) void k_abs_c64(const float2 *in, float *out, size_t n) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid < n) {

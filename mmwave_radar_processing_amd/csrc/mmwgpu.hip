@@ -324,6 +324,18 @@ int mmw_virtual_array_reformat(mmw_ctx *ctx, const void *d_raw, void *d_virt, in
     return check_launch("reformat");
 }
 
+int mmw_virtual_array_reformat_i16(mmw_ctx *ctx, const void *d_raw_i16, void *d_virt, int n_frames, int num_rx,
+                                   int num_tx, int S, int loops) {
+    MMW_REQUIRE(ctx && d_raw_i16 && d_virt, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && num_rx > 0 && num_tx > 0 && S > 0 && loops > 0, "bad shape");
+    const long total = (long)n_frames * num_rx * num_tx * S * loops;
+    if (!total) return MMW_OK;
+    hipLaunchKernelGGL(k_reformat_i16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const short2 *)d_raw_i16, (float2 *)d_virt, total, num_rx, num_tx, S, loops);
+    return check_launch("reformat_i16");
+}
+
 // ------------------------------------------------------------------ FFT chain
 // rv.ntx > 1: d_cubes is the raw [F][num_rx][S][num_tx * C] cube and the virtual-array de-interleave is folded into
 // the load of the single-pass kernels (V == rv.ntx * rv.nrx).

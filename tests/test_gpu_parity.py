@@ -1522,3 +1522,24 @@ def test_every_shipped_cfg_shape_through_the_synchronised_chain(monkeypatch, V, 
         assert rel_err(outs["sync"][f], O.fft3d_windowed(cube, A)) <= SPEC_TOL
     d_in.free()
     d_out.free()
+
+
+def test_int16_iq_ingest_matches_the_complex64_raw_path():
+    """mmw_virtual_array_reformat_i16 / FramePipeline.load_raw_i16 (int16 I/Q pairs, NO UPSTREAM ORACLE for the sample layout:
+    defined as the raw cube of load_raw with int16 pairs) == load_raw on the same samples as complex64, bit for bit, and the
+    chain on top of it matches the oracle."""
+    from mmwave_radar_processing_amd.batch import FramePipeline
+    F, nrx, ntx, S, C = 3, 4, 3, 63, 100
+    cm = make_cm(synth.synth_cfg_text(num_samples=S, num_loops=C))
+    rng = np.random.default_rng(16)
+    iq = rng.integers(-2048, 2048, (F, nrx, S, ntx * C, 2)).astype(np.int16)
+    raw = (iq[..., 0].astype(np.float32) + 1j * iq[..., 1].astype(np.float32)).astype(np.complex64)
+    a = FramePipeline(cm, max_frames=F, shape=(nrx * ntx, S, C))
+    b = FramePipeline(cm, max_frames=F, shape=(nrx * ntx, S, C))
+    a.load_raw(raw, ntx)
+    b.load_raw_i16(iq, ntx)
+    np.testing.assert_array_equal(a.cubes(0, F), b.cubes(0, F))
+    b.chain3d()
+    assert rel_err(b.fetch_chain3d(F - 1), O.fft3d_windowed(a.cubes(F - 1, F)[0])) <= SPEC_TOL
+    with pytest.raises(ValueError):
+        b.load_raw_i16(iq[..., 0], ntx)
