@@ -469,7 +469,10 @@ __global__ __launch_bounds__(256) void k_argmax64_cells(const cplx<double> *cell
 //                          uses each cell's window * phase factor for all antennas of the list;
 //   k_argmax_refine_finish adds the slices in a fixed order and runs the float64 argmax (one wave per detection);
 //   k_argmax_refine_whole  whole planes in one workgroup: the (never yet seen) overflow beyond n_split detections.
-constexpr int REFINE_PARTS = 8, REFINE_NA = 8;
+#ifndef MMW_REFINE_PARTS
+#define MMW_REFINE_PARTS 8
+#endif
+constexpr int REFINE_PARTS = MMW_REFINE_PARTS, REFINE_NA = 8;
 
 struct RefineArgs {
     const float2 *cubes;
