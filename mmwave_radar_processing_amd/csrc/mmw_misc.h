@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_argmax64_cells(const cplx<double> *cell
 //   k_argmax_refine_finish adds the slices in a fixed order and runs the float64 argmax (one wave per detection);
 //   k_argmax_refine_whole  whole planes in one workgroup: the (never yet seen) overflow beyond n_split detections.
 #ifndef MMW_REFINE_PARTS
-#define MMW_REFINE_PARTS 8
+#define MMW_REFINE_PARTS 16
 #endif
 constexpr int REFINE_PARTS = MMW_REFINE_PARTS, REFINE_NA = 8;
 
