@@ -120,7 +120,8 @@ __global__ __launch_bounds__(NT) void k_rd_split2_ct(RdSplitArgs a) {
 
 template <int S, int C>
 int launch_rd_split_ct_sc(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, RawView rv) {
-    constexpr int NT = 512, CH = C / 2, S1 = mixct::best_n1(S), C1 = mixct::best_n1(CH);
+    // 512 threads; 128 x 256 (16-point radices) also fits the 128-VGPR budget of 1024 threads and is 6 % faster there
+    constexpr int NT = (S == 128 && C == 256) ? 1024 : 512, CH = C / 2, S1 = mixct::best_n1(S), C1 = mixct::best_n1(CH);
     RdSplitArgs a{};
     a.in = d_in;
     a.out = d_out;
