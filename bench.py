@@ -169,22 +169,32 @@ class DetectWorkload:
     azimuth / elevation argmax for every frame of the resident batch (FramePipeline.point_clouds without the host
     table look-ups)."""
 
-    def __init__(self, ctx, F):
+    def __init__(self, ctx, F, path="fused"):
         from mmwave_radar_processing_amd import _lib
-        self.ctx, self.F, self._lib = ctx, F, _lib
+        self.ctx, self.F, self._lib, self.path = ctx, F, _lib, path
         n = S * C
-        self.d_rd, self.d_mag, self.d_mask = ctx.alloc(F * CUBE_BYTES), ctx.alloc(F * n * 8), ctx.alloc(F * n)
+        self.d_rd = ctx.alloc(F * CUBE_BYTES)
         self.d_dets, self.d_cnt = ctx.alloc(F * DET_CAP * 8), ctx.alloc(F * 4)
         self.d_l1, self.d_az, self.d_el = ctx.alloc(F * V * 4), ctx.alloc(F * DET_CAP * 4), ctx.alloc(F * DET_CAP * 4)
+        if path == "fused":
+            self.d_mag32 = ctx.alloc(F * n * 4)
+        else:
+            self.d_mag, self.d_mask = ctx.alloc(F * n * 8), ctx.alloc(F * n)
         (tr, td), (gr, gd) = DET_CFAR["train"], DET_CFAR["guard"]
         n_train = (2 * (tr + gr) + 1) * (2 * (td + gd) + 1) - (2 * gr + 1) * (2 * gd + 1)
         self.scale = ca_alpha(n_train, DET_CFAR["pfa"])
         self.az, self.n_az = _lib.int_array(AZ_ANT)
         self.el, self.n_el = _lib.int_array(EL_ANT)
 
-    def step(self, d_in):
+    def step(self, d_in, stats=None):
         L, h, lib, F = self.ctx.lib, self.ctx.handle, self._lib, self.F
         (tr, td), (gr, gd) = DET_CFAR["train"], DET_CFAR["guard"]
+        if self.path == "fused":
+            # one call: RD + screened CFAR (undecided cells settled in float64) + ordered detections + az / el argmax
+            lib.check(L.mmw_detect_points(h, d_in.ptr, self.d_rd.ptr, self.d_l1.ptr, self.d_mag32.ptr, self.d_dets.ptr,
+                                          self.d_cnt.ptr, self.d_az.ptr, self.d_el.ptr, F, V, S, C, DET_CFAR["kind"], tr, td, gr, gd,
+                                          self.scale, 0, DET_CAP, self.az, self.n_az, 1, self.el, self.n_el, 0, A, stats))
+            return
         lib.check(L.mmw_detect_batch(h, d_in.ptr, self.d_rd.ptr, self.d_mag.ptr, self.d_mask.ptr, self.d_dets.ptr,
                                      self.d_cnt.ptr, self.d_l1.ptr, F, V, S, C, DET_CFAR["kind"], tr, td, gr, gd, self.scale,
                                      0, DET_CAP))
@@ -242,6 +252,8 @@ def main():
     ap.add_argument("--workload", choices=("chain", "detect"), default="chain",
                     help="chain: range+Doppler+angle FFT chain (BASELINE configs[1], the headline); detect: RD + CA-CFAR + "
                          "point-cloud angle argmax (configs[2])")
+    ap.add_argument("--detect-path", choices=("fused", "float64"), default="fused",
+                    help="detect workload: mmw_detect_points (default) or round 2's mmw_detect_batch + mmw_angle_argmax_exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--profile-every", type=int, default=0,
@@ -272,7 +284,7 @@ def main():
     detect = args.workload == "detect"
     d_in = ctx.alloc(F * CUBE_BYTES)
     d_out = None if detect else ctx.alloc(F * OUT_BYTES)
-    work = DetectWorkload(ctx, F) if detect else None
+    work = DetectWorkload(ctx, F, args.detect_path) if detect else None
     # distinct frames per rank: seed0 offsets by the rank's first global frame index
     _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 7_000_000 + rank * F, 8, 30.0))
     ctx.sync()
@@ -328,13 +340,14 @@ def main():
                                     "64-bin angle FFT -> complex64 [64,256,128] (BASELINE configs[1])"),
                        "frames_per_gpu": F, "cube": [V, S, C], "angle_bins": A,
                        "sharding": f"frame-sharded x{world}, no collective",
-                       "schedule": "stages back to back on one stream, whole batch per launch" if detect else plan,
+                       "schedule": (f"{args.detect_path}: stages back to back on one stream, whole batch per launch") if detect else plan,
                        "device": info["name"], "arch": info["arch"]},
             "hip_event_ms_per_step_rank0": ev_ms / args.steps,
             "chain_hbm_frac_of_8TBs": value / world * algo / (HBM_PEAK_GBS * 1e9),
         }
         if not args.no_profile and detect:
-            fam = {k: ctx.profile_get(k) for k in ("rd", "rd64", "cfar", "compact", "plane_l1", "argmax")}
+            fam = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
+                                                   "plane_l1", "argmax")}
             out["kernels_ms_per_step"] = {k: ms / max(n, 1) * (2 if k == "argmax" else 1) for k, (ms, n) in fam.items() if n}
             rd_ms, rd_n = fam["rd"]
             if rd_n:

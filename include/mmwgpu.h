@@ -49,6 +49,10 @@ typedef struct mmw_ctx mmw_ctx;
 
 /* ---------------------------------------------------------------- lifecycle */
 const char *mmw_version(void);
+/* Bumped whenever an exported signature changes: a binding checks it at load (the argtypes of a ctypes binding are
+ * hard-coded, so a library of another revision would reinterpret ints as device pointers). */
+#define MMWGPU_ABI_VERSION 3
+int mmw_abi_version(void);
 const char *mmw_last_error(void);
 int mmw_device_count(int *count);
 /* Device name and gcnArchName into caller buffers (for fail-loud checks and reports). */
@@ -201,6 +205,29 @@ int mmw_compact2d(mmw_ctx *ctx, const uint8_t *d_mask, int32_t *d_dets, int32_t 
 int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_mag64, uint8_t *d_mask,
                      int32_t *d_dets, int32_t *d_counts, float *d_l1, int n_frames, int V, int S, int C, int cfar_kind,
                      int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap);
+
+/* mmw_detect_points: BASELINE configs[2] in one call -- range-Doppler of every antenna (float32, d_rd / d_l1 as above),
+ *   CFAR on antenna 0, ordered detections and the azimuth / elevation argmax bins of every detection
+ *   (range_doppler_detector.py:62-80, detectors/ca_cfar.py:85-155, point_cloud_generator.py:143-214), with the SAME
+ *   results as the float64 path of mmw_detect_batch + mmw_angle_argmax_exact: the CFAR decision is screened on the
+ *   float32 plane with a worst-case rounding-error band (mmw_detect.h); the few cells inside the band are decided from
+ *   float64 DFT sums of the input cube.  One kernel launch per frame batch behind the range-Doppler kernel instead of six.
+ *   d_mag32 (may be NULL): [F][S][C] float32 |RD| of antenna 0.  h_az / h_el: antenna lists (n == 0: that estimate
+ *   is skipped and its index buffer may be NULL); d_az_idx / d_el_idx [F][cap] int32.
+ *   d_counts[f] is the exact detection count (may exceed cap), or -1 for a frame the screening pass cannot decide
+ *   (non-finite samples in antenna 0, or more undecided cells than its list holds): run mmw_detect_batch +
+ *   mmw_angle_argmax_exact on such a frame.
+ *   h_stats (may be NULL; passing it synchronises): [0] frames with undecided cells, [1] undecided cells, [2] frames
+ *   returned with count -1, [3] / [4] azimuth / elevation detections re-evaluated in float64.
+ *   MMW_ERR_UNSUPPORTED (nothing launched) when mmw_detect_points_supported(...) == 0: CA-CFAR only, S * C float32
+ *   magnitudes must fit the LDS, at most 16 antennas per list. */
+int mmw_detect_points_supported(int S, int C, int cfar_kind, int train_r, int train_d, int guard_r, int guard_d,
+                                int n_az, int n_el);
+int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1, float *d_mag32, int32_t *d_dets,
+                      int32_t *d_counts, int32_t *d_az_idx, int32_t *d_el_idx, int n_frames, int V, int S, int C,
+                      int cfar_kind, int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap,
+                      const int *h_az, int n_az, int shift_az, const int *h_el, int n_el, int shift_el, int A,
+                      int *h_stats);
 
 /* ---------------------------------------------------------------- point cloud
  * mmw_angle_argmax: for each detection (r, v) of frame f gather rd[f][ant[i]][r][v], zero-pad to A,

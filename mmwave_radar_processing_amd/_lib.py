@@ -19,6 +19,8 @@ LIB_PATH = os.environ.get("MMWGPU_LIB") or os.path.join(_HERE, "csrc", "libmmwgp
 MMW_OK = 0
 MMW_ERR_INVALID = -1
 MMW_ERR_TRUNCATED = -4
+MMW_ERR_UNSUPPORTED = -5
+ABI_VERSION = 3          # include/mmwgpu.h MMWGPU_ABI_VERSION: the argtypes below are for exactly this revision
 CFAR_CA, CFAR_OS, CFAR_GO, CFAR_SO = 0, 1, 2, 3
 ANGLE_MAGNITUDE, ANGLE_NO_WINDOW, ANGLE_NO_SHIFT = 1, 2, 4
 
@@ -68,6 +70,9 @@ _SIGNATURES = {
     "mmw_cfar1d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i],
     "mmw_compact2d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_detect_batch": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i],
+    "mmw_detect_points_supported": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "mmw_detect_points": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i,
+                          _ip, _i, _i, _ip, _i, _i, _i, _ip],
     "mmw_angle_argmax": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i],
     "mmw_plane_l1": [_vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_angle_argmax_exact": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i, _ip],
@@ -83,7 +88,7 @@ _SIGNATURES = {
     "mmw_profile_get": [_vp, C.c_char_p, C.POINTER(_f), _ip],
     "mmw_profile_reset": [_vp],
 }
-EXPORTED = tuple(sorted(list(_SIGNATURES) + ["mmw_version", "mmw_last_error"]))
+EXPORTED = tuple(sorted(list(_SIGNATURES) + ["mmw_version", "mmw_last_error", "mmw_abi_version"]))
 
 
 def load_library():
@@ -100,6 +105,14 @@ def load_library():
             lib = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover - depends on the host
             raise MmwGpuError(f"cannot load {LIB_PATH}: {e}") from e
+        try:
+            lib.mmw_abi_version.restype = C.c_int
+            abi = lib.mmw_abi_version()
+        except AttributeError:
+            abi = None
+        if abi != ABI_VERSION:
+            raise MmwGpuError(f"{LIB_PATH} has ABI revision {abi}, this binding is written for {ABI_VERSION}: rebuild the "
+                              "library (make -C mmwave_radar_processing_amd/csrc) or unset MMWGPU_LIB")
         for name, args in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = args

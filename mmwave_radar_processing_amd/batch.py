@@ -162,57 +162,119 @@ class FramePipeline:
             return self.d_cube3d.download((A, S, C), np.float32, frame * A * S * C * 4)
         return self.d_cube3d.download((A, S, C), np.complex64, frame * A * S * C * 8)
 
-    def detect(self) -> List[np.ndarray]:
-        """RD (all antennas, fp32) + float64 |RD| of antenna 0 + CFAR + ordered compaction for every frame.
-
-        Returns the per-frame int64 ``(N, 2)`` [range_idx, doppler_idx] arrays (row-major order, == np.where)."""
-        F, V, S, C, cap = self.n_frames, self.V, self.S, self.C, self.cap
-        L, h = self.ctx.lib, self.ctx.handle
-        n = S * C
+    def _alloc_detect(self):
+        F, V, cap = self.n_frames, self.V, self.cap
         self.d_rd = self.bufs.get("rd", max(F, 1) * self.cube_bytes)
-        d_mag = self.bufs.get("mag64", max(F, 1) * n * 8)
-        d_mask = self.bufs.get("mask", max(F, 1) * n)
         self.d_dets = self.bufs.get("dets", max(F, 1) * cap * 8)
         self.d_cnt = self.bufs.get("counts", max(F, 1) * 4)
-        self.d_l1 = self.bufs.get("plane_l1", max(F, 1) * V * 4)     # error-bound scale for the exact argmax
-        (tr, td), (gr, gd) = self.cfar.num_train, self.cfar.num_guard
-        for f0 in range(0, F, 32768):       # grid limits of the per-frame launches
-            nf = min(32768, F - f0)
-            _lib.check(L.mmw_detect_batch(h, self.d_in.at(f0 * self.cube_bytes), self.d_rd.at(f0 * self.cube_bytes),
-                                          d_mag.at(f0 * n * 8), d_mask.at(f0 * n), self.d_dets.at(f0 * cap * 8),
-                                          self.d_cnt.at(f0 * 4), self.d_l1.at(f0 * V * 4), nf, V, S, C, self.cfar.kind, int(tr), int(td), int(gr),
-                                          int(gd), float(self.cfar._scale()), int(self.cfar._k_rank()), cap))
-        self.counts = self.d_cnt.download((F,), np.int32)
-        if np.any(self.counts > cap):
-            raise _lib.MmwGpuError(f"detection capacity {cap} exceeded (max count {int(self.counts.max())}): "
-                                   "raise det_capacity")
-        dets = self.d_dets.download((F, cap, 2), np.int32)
-        self.dets = [dets[f, :self.counts[f]].astype(np.int64) for f in range(F)]
-        return self.dets
+        self.d_l1 = self.bufs.get("plane_l1", max(F, 1) * V * 4)     # error-bound scale (CFAR screening, exact argmax)
 
-    def _argmax(self, ant, shift) -> np.ndarray:
-        """Exact (float64-equivalent) argmax bins of every detection: ``mmw_angle_argmax_exact``."""
-        F, cap = self.n_frames, self.cap
-        d_idx = self.bufs.get("angle_idx", max(F, 1) * cap * 4)
-        d_l1 = self.d_l1                    # filled by detect()
-        L, h = self.ctx.lib, self.ctx.handle
+    def _cfar_args(self):
+        (tr, td), (gr, gd) = self.cfar.num_train, self.cfar.num_guard
+        return self.cfar.kind, int(tr), int(td), int(gr), int(gd), float(self.cfar._scale()), int(self.cfar._k_rank())
+
+    def _detect_float64(self, f0: int, nf: int):
+        """The float64 path for frames [f0, f0 + nf): RD + float64 |RD| of antenna 0 + CFAR + ordered compaction."""
+        V, S, C, cap = self.V, self.S, self.C, self.cap
+        n = S * C
+        d_mag = self.bufs.get("mag64", max(self.n_frames, 1) * n * 8)
+        d_mask = self.bufs.get("mask", max(self.n_frames, 1) * n)
+        kind, tr, td, gr, gd, scale, k_rank = self._cfar_args()
+        _lib.check(self.ctx.lib.mmw_detect_batch(self.ctx.handle, self.d_in.at(f0 * self.cube_bytes), self.d_rd.at(f0 * self.cube_bytes),
+                                                 d_mag.at(f0 * n * 8), d_mask.at(f0 * n), self.d_dets.at(f0 * cap * 8),
+                                                 self.d_cnt.at(f0 * 4), self.d_l1.at(f0 * V * 4), nf, V, S, C, kind, tr, td, gr, gd,
+                                                 scale, k_rank, cap))
+
+    def _argmax_float64(self, d_idx, ant, shift, f0: int, nf: int):
+        cap = self.cap
         arr, n_ant = _lib.int_array(ant)
         n_ref = _lib.C.c_int(0)
+        _lib.check(self.ctx.lib.mmw_angle_argmax_exact(self.ctx.handle, self.d_in.at(f0 * self.cube_bytes), self.d_l1.at(f0 * self.V * 4),
+                                                       self.d_rd.at(f0 * self.cube_bytes), self.d_dets.at(f0 * cap * 8),
+                                                       self.d_cnt.at(f0 * 4), d_idx.at(f0 * cap * 4), nf, self.V, self.S, self.C,
+                                                       cap, arr, n_ant, self.A, int(shift), _lib.C.byref(n_ref)))
+        self.n_refined += n_ref.value
+
+    def _fused_supported(self, with_angles: bool) -> bool:
+        kind, tr, td, gr, gd, _, _ = self._cfar_args()
+        n_az, n_el = (len(self.az), len(self.el)) if with_angles else (0, 0)
+        return bool(self.ctx.lib.mmw_detect_points_supported(self.S, self.C, kind, tr, td, gr, gd, n_az, n_el))
+
+    def _detect_fused(self, with_angles: bool):
+        """``mmw_detect_points``: RD + screened CFAR (undecided cells settled in float64) + ordered compaction (+ the
+        azimuth / elevation argmax bins) in one pass; frames it hands back (count -1) go through the float64 path."""
+        F, V, S, C, cap = self.n_frames, self.V, self.S, self.C, self.cap
+        kind, tr, td, gr, gd, scale, k_rank = self._cfar_args()
+        az, n_az = _lib.int_array(self.az if with_angles else [])
+        el, n_el = _lib.int_array(self.el if with_angles else [])
+        self.d_az = self.bufs.get("az_idx", max(F, 1) * cap * 4) if n_az else None
+        self.d_el = self.bufs.get("el_idx", max(F, 1) * cap * 4) if n_el else None
+        stats = (_lib.C.c_int * 5)()
+        self.screen_stats = np.zeros(5, dtype=np.int64)
+        step = max(1, min(F, (2 ** 31 - 1) // max(cap, 1)))
+        for f0 in range(0, F, step):
+            nf = min(step, F - f0)
+            _lib.check(self.ctx.lib.mmw_detect_points(
+                self.ctx.handle, self.d_in.at(f0 * self.cube_bytes), self.d_rd.at(f0 * self.cube_bytes), self.d_l1.at(f0 * V * 4),
+                None, self.d_dets.at(f0 * cap * 8), self.d_cnt.at(f0 * 4), self.d_az.at(f0 * cap * 4) if n_az else None,
+                self.d_el.at(f0 * cap * 4) if n_el else None, nf, V, S, C, kind, tr, td, gr, gd, scale, k_rank, cap,
+                az, n_az, int(self.shift_az), el, n_el, int(self.shift_el), self.A, stats))
+            self.screen_stats += np.array(list(stats), dtype=np.int64)
+        self.n_refined += int(self.screen_stats[3] + self.screen_stats[4])
+        counts = self.d_cnt.download((F,), np.int32)
+        for f in np.nonzero(counts < 0)[0]:            # not decidable by the screening pass: the float64 path, frame by frame
+            self._detect_float64(int(f), 1)
+            if n_az:
+                self._argmax_float64(self.d_az, self.az, self.shift_az, int(f), 1)
+            if n_el:
+                self._argmax_float64(self.d_el, self.el, self.shift_el, int(f), 1)
+        if np.any(counts < 0):
+            counts = self.d_cnt.download((F,), np.int32)
+        return counts
+
+    def _fetch_dets(self, counts) -> List[np.ndarray]:
+        F, cap = self.n_frames, self.cap
+        self.counts = counts
+        if np.any(counts > cap):
+            raise _lib.MmwGpuError(f"detection capacity {cap} exceeded (max count {int(counts.max())}): "
+                                   "raise det_capacity")
+        dets = self.d_dets.download((F, cap, 2), np.int32)
+        self.dets = [dets[f, :counts[f]].astype(np.int64) for f in range(F)]
+        return self.dets
+
+    def detect(self) -> List[np.ndarray]:
+        """RD (all antennas, fp32) + CFAR on antenna 0 + ordered compaction for every frame.
+
+        Returns the per-frame int64 ``(N, 2)`` [range_idx, doppler_idx] arrays (row-major order, == np.where)."""
+        F = self.n_frames
+        self._alloc_detect()
+        if self._fused_supported(False):
+            return self._fetch_dets(self._detect_fused(False))
+        for f0 in range(0, F, 32768):       # grid limits of the per-frame launches
+            self._detect_float64(f0, min(32768, F - f0))
+        return self._fetch_dets(self.d_cnt.download((F,), np.int32))
+
+    def _argmax(self, ant, shift, name) -> np.ndarray:
+        """Exact (float64-equivalent) argmax bins of every detection: ``mmw_angle_argmax_exact``."""
+        F, cap = self.n_frames, self.cap
+        d_idx = self.bufs.get(name, max(F, 1) * cap * 4)
         for f0 in range(0, F, 32768):
-            nf = min(32768, F - f0)
-            _lib.check(L.mmw_angle_argmax_exact(h, self.d_in.at(f0 * self.cube_bytes), d_l1.at(f0 * self.V * 4),
-                                                self.d_rd.at(f0 * self.cube_bytes), self.d_dets.at(f0 * cap * 8),
-                                                self.d_cnt.at(f0 * 4), d_idx.at(f0 * cap * 4), nf, self.V, self.S, self.C,
-                                                cap, arr, n_ant, self.A, int(shift), _lib.C.byref(n_ref)))
-            self.n_refined += n_ref.value
+            self._argmax_float64(d_idx, ant, shift, f0, min(32768, F - f0))
         return d_idx.download((F, cap), np.int32)
 
     def point_clouds(self) -> List[np.ndarray]:
         """Per-frame float64 ``(N, 4)`` (x, y, z, velocity), FLU frame (point_cloud_generator.py:216-248)."""
-        dets = self.detect()
         self.n_refined = 0      # detections re-evaluated in float64 (near-ties of the float32 pass)
-        az_idx = self._argmax(self.az, self.shift_az) if self.az else None
-        el_idx = self._argmax(self.el, self.shift_el) if self.el else None
+        F, cap = self.n_frames, self.cap
+        self._alloc_detect()
+        if self._fused_supported(True):
+            dets = self._fetch_dets(self._detect_fused(True))
+            az_idx = self.d_az.download((F, cap), np.int32) if self.az else None
+            el_idx = self.d_el.download((F, cap), np.int32) if self.el else None
+        else:
+            dets = self.detect()
+            az_idx = self._argmax(self.az, self.shift_az, "az_idx") if self.az else None
+            el_idx = self._argmax(self.el, self.shift_el, "el_idx") if self.el else None
         out = []
         for f, d in enumerate(dets):
             n = d.shape[0]

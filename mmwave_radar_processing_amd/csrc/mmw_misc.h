@@ -345,27 +345,23 @@ struct ArgmaxRefine {
 // and flags the detection unless best - second > 2 B: the float64 argmax of an unflagged detection is the one found.
 // NA: antennas held in registers (the list is padded to it): 4 / 8 / 16 / 32 -- the gathers are cold, strided 8-byte
 // loads, so the kernel lives on the number of waves in flight, i.e. on a small register footprint.
+// gather of one detection's cells: x[i] = rd[f][ants.idx[i]][r][v] (zero beyond the list), sum_abs = sum |re| + |im|
 template <int NA>
-__global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const int32_t *dets, const int32_t *counts,
-                                                       int32_t *out_idx, int V, int S, int C, int cap,
-                                                       AntList ants, int A, int shift, const float2 *twA, ArgmaxRefine rf) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int f = blockIdx.y;
-    int n_det = counts[f];
-    if (n_det > cap) n_det = cap;
-    // grid.x covers the usual detection counts in one pass; a wave walks on for frames with more
-    for (int det = blockIdx.x * 4 + wave; det < n_det; det += gridDim.x * 4) {
-    const int r = dets[((long)f * cap + det) * 2], v = dets[((long)f * cap + det) * 2 + 1];
-    float2 x[NA];
-    float sum_abs = 0.f, sum_l1 = 0.f;
+__device__ __forceinline__ void argmax_gather(const float2 *rd, long f, int V, int S, int C, int r, int v, const AntList &ants,
+                                              float2 (&x)[NA], float &sum_abs) {
+    sum_abs = 0.f;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        x[i] = (i < ants.n) ? rd[(((long)f * V + ants.idx[i]) * S + r) * C + v] : make_float2(0.f, 0.f);
-        if (i < ants.n) {
-            sum_abs += fabsf(x[i].x) + fabsf(x[i].y);
-            if (rf.l1) sum_l1 += rf.l1[(long)f * V + ants.idx[i]];
-        }
+        x[i] = (i < ants.n) ? rd[((f * V + ants.idx[i]) * S + r) * C + v] : make_float2(0.f, 0.f);
+        if (i < ants.n) sum_abs += fabsf(x[i].x) + fabsf(x[i].y);
     }
+}
+
+// one wave: zero-padded A-point DFT of the n cells, |.|, wave-wide FIRST maximum (wb at bin wi) and the largest
+// magnitude among all other bins (ws2)
+template <int NA>
+__device__ __forceinline__ void argmax_eval(const float2 (&x)[NA], int n, int A, int shift, const float2 *twA, int lane,
+                                            float &wb, int &wi, float &ws2) {
     const float NEG = -__builtin_huge_valf();
     float best = NEG, second = NEG;
     int best_idx = 0x7fffffff;
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
         int t = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            if (i < ants.n) {
+            if (i < n) {
                 const float2 w = twA[t];
                 re += x[i].x * w.x - x[i].y * w.y;
                 im += x[i].x * w.y + x[i].y * w.x;
@@ -391,8 +387,8 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
         } else if (mag_gt(m, second)) second = m;
     }
     // wave-wide first maximum, then the largest magnitude among everything else
-    float wb = best;
-    int wi = best_idx;
+    wb = best;
+    wi = best_idx;
     for (int d = 32; d >= 1; d >>= 1) {
         const float ob = __shfl_xor(wb, d, 64);
         const int oi = __shfl_xor(wi, d, 64);
@@ -401,21 +397,45 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
             wi = oi;
         }
     }
-    float ws2 = (best_idx == wi) ? second : best;
+    ws2 = (best_idx == wi) ? second : best;
     for (int d = 32; d >= 1; d >>= 1) {
         const float o = __shfl_xor(ws2, d, 64);
         if (mag_gt(o, ws2)) ws2 = o;
     }
-    if (lane == 0) {
-        out_idx[(long)f * cap + det] = wi;
-        if (rf.l1) {
-            const float B = rf.k_fft * sum_l1 + rf.k_ang * sum_abs;
-            if (!(wb - ws2 > 2.f * B)) {       // also taken for NaN / inf magnitudes
-                const int pos = atomicAdd(rf.n_flag, 1);
-                if (pos < rf.list_cap) rf.list[pos] = f * cap + det;
-            }
-        }
+}
+
+// lane 0: append detection `id` to the refinement list unless best - second > 2 B (also taken for NaN / inf magnitudes)
+__device__ __forceinline__ void argmax_flag(const ArgmaxRefine &rf, float sum_l1, float sum_abs, float wb, float ws2, int id) {
+    const float B = rf.k_fft * sum_l1 + rf.k_ang * sum_abs;
+    if (!(wb - ws2 > 2.f * B)) {
+        const int pos = atomicAdd(rf.n_flag, 1);
+        if (pos < rf.list_cap) rf.list[pos] = id;
     }
+}
+
+template <int NA>
+__global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const int32_t *dets, const int32_t *counts,
+                                                       int32_t *out_idx, int V, int S, int C, int cap,
+                                                       AntList ants, int A, int shift, const float2 *twA, ArgmaxRefine rf) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.y;
+    int n_det = counts[f];
+    if (n_det > cap) n_det = cap;
+    float sum_l1 = 0.f;
+    if (rf.l1)
+        for (int i = 0; i < ants.n; ++i) sum_l1 += rf.l1[(long)f * V + ants.idx[i]];
+    // grid.x covers the usual detection counts in one pass; a wave walks on for frames with more
+    for (int det = blockIdx.x * 4 + wave; det < n_det; det += gridDim.x * 4) {
+        const int r = dets[((long)f * cap + det) * 2], v = dets[((long)f * cap + det) * 2 + 1];
+        float2 x[NA];
+        float sum_abs, wb, ws2;
+        int wi;
+        argmax_gather<NA>(rd, f, V, S, C, r, v, ants, x, sum_abs);
+        argmax_eval<NA>(x, ants.n, A, shift, twA, lane, wb, wi, ws2);
+        if (lane == 0) {
+            out_idx[(long)f * cap + det] = wi;
+            if (rf.l1) argmax_flag(rf, sum_l1, sum_abs, wb, ws2, f * cap + det);
+        }
     }
 }
 

@@ -5,6 +5,7 @@
 #include "mmw_misc.h"
 #include "mmw_czt.h"
 #include "mmw_beamform.h"
+#include "mmw_detect.h"
 
 #include <algorithm>
 #include <memory>
@@ -107,7 +108,8 @@ static void sync_slot_forget(mmw_ctx *ctx);
 
 extern "C" {
 
-const char *mmw_version(void) { return "mmwgpu 0.1 (gfx950)"; }
+const char *mmw_version(void) { return "mmwgpu 0.3 (gfx950)"; }
+int mmw_abi_version(void) { return MMWGPU_ABI_VERSION; }
 const char *mmw_last_error(void) { return g_last_error.c_str(); }
 
 int mmw_device_count(int *count) {
@@ -1350,6 +1352,85 @@ static int plane_l1_impl(mmw_ctx *ctx, const void *d_cubes, float *d_l1, int n_f
     return check_launch("plane_l1");
 }
 
+// Rounding-error budget of the float32 range-Doppler cell values, in units of eps = 2^-24 of the plane's L1 norm
+// (|rd32 - rd64| <= ulps * eps * sum |w x|), for whichever kernel range_doppler_impl runs on an S x C plane.
+//   windows: two products with table values, <= 8.
+//   structured transforms (k_rd_fused_256x128, k_rd_lds, k_rd_mixed_ct, k_rd_split2_ct: RegFFT / RegDFT levels): per
+//     prime factor p of the axis length one twiddle / inter-level product (complex FMA product + table value, <= 4) plus
+//     p == 2: the butterfly's add (inside the 4);  odd p: the real-symmetric form of RegDFT -- pair sums (1), a
+//     (p - 1) / 2-term FMA chain with literal coefficients ((p + 1) / 2), the +- i combine (1): <= (p + 7) / 2 + 1.
+//     The 127-point level of 63 x 127 / 127 x 32 / 254 x 50 is that form on MFMA tiles (64-term exact FMA chains).
+//   run-time mixed-radix kernel: its levels may be direct R-term chains: R per level on top.
+//   generic path: radix-2 levels (4 each) for powers of two, an N-term direct sum (N + 4) otherwise.
+static int rd_error_ulps(int S, int C) {
+    auto factors = [](int n) {
+        int u = 0;
+        for (int p = 2; n > 1; ++p)
+            while (n % p == 0) {
+                u += 4 + (p == 2 ? 0 : (p + 7) / 2 + 1);
+                n /= p;
+            }
+        return u;
+    };
+    const int structured = 8 + factors(S) + factors(C);
+    const bool no_fused = env_int("MMW_NO_FUSED_RD", 0), no_mixed = env_int("MMW_NO_MIXED_RD", 0);
+    if (!no_fused && (fused_rd_ok(S, C) || rd_lds_supported(S, C))) return structured;
+    if (!no_mixed && rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0)) return structured;
+    RdMixedPlan mp;
+    if (!no_mixed && rd_mixed_plan(S, C, sizeof(cplx<float>), &mp))
+        return structured + mp.s1 + mp.s2 + mp.c1 + mp.c2 + 2 * (mp.rad_s[0] + mp.rad_s[1] + mp.rad_c[0] + mp.rad_c[1]);
+    if (rd_split_ct_supported(S, C) && !env_int("MMW_NO_SPLIT_RD", 0)) return structured;
+    int ulps = 8;
+    for (int axis = 0; axis < 2; ++axis) {
+        const int n = axis ? C : S;
+        if (is_pow2(n)) ulps += 4 * ilog2(n);
+        else ulps += n + 4;
+    }
+    return ulps;
+}
+
+// float64 re-evaluation of the detections k_angle_argmax flagged (ra.n_flag / ra.list): fixed grids, the flagged count
+// stays on the device, workgroups beyond it leave at once.  ra.partial must hold n_split * REFINE_PARTS * ants.n entries.
+static int launch_argmax_refine(mmw_ctx *ctx, const RefineArgs &ra) {
+    if (ra.n_split > 0) {
+        const int units = std::min(ra.n_split, std::max(1, tune_int("MMW_REFINE_GRID", 256)));
+        hipLaunchKernelGGL(k_argmax_refine_part, dim3(REFINE_PARTS, units), dim3(256), 0, ctx->stream, ra);
+        MMW_TRY(check_launch("argmax_refine_part"));
+        hipLaunchKernelGGL(k_argmax_refine_finish, dim3(std::min((ra.n_split + 3) / 4, ctx->num_cu)), dim3(256), 0, ctx->stream, ra);
+        MMW_TRY(check_launch("argmax_refine_finish"));
+    }
+    if (ra.list_cap > ra.n_split) {
+        hipLaunchKernelGGL(k_argmax_refine_whole, dim3(ctx->num_cu), dim3(256), 0, ctx->stream, ra);
+        MMW_TRY(check_launch("argmax_refine_whole"));
+    }
+    return MMW_OK;
+}
+
+static int fill_refine_args(mmw_ctx *ctx, RefineArgs *ra, int S, int C, int A) {
+    const void *twA64, *twS64, *twC64, *ws64, *wc64;
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, A, &twA64));
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, S, &twS64));
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, C, &twC64));
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &ws64));
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &wc64));
+    ra->S = S;
+    ra->C = C;
+    ra->A = A;
+    ra->ws = (const double *)ws64;
+    ra->wc = (const double *)wc64;
+    ra->twS = (const cplx<double> *)twS64;
+    ra->twC = (const cplx<double> *)twC64;
+    ra->twA = (const cplx<double> *)twA64;
+    return MMW_OK;
+}
+
+// The worst-case bound assumes every rounding error of every partial sum lines up; measured float32 errors stay below
+// 1.2 % of it (tools/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).  The argmax kernels use
+// 1/8 of the worst case -- still ~10x above anything observed -- which cuts the float64 re-evaluations (each reads
+// the antennas' whole planes) from 1.8 % to 0.2 % of the detections; MMW_ARGMAX_BOUND_DIV=1 restores the full bound
+// (the CFAR screening of mmw_detect_points always uses the full bound).
+static float argmax_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 8)); }
+
 int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1, const void *d_rd, const int32_t *d_dets,
                            const int32_t *d_counts, int32_t *d_idx, int n_frames, int V, int S, int C, int cap,
                            const int *h_ant, int n_ant, int A, int shift, int *h_n_refined) {
@@ -1361,13 +1442,8 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     MMW_TRY(fill_ant_list(h_ant, n_ant, V, A, &ants));
     if (h_n_refined) *h_n_refined = 0;
     if (n_frames == 0 || cap == 0) return MMW_OK;
-    const void *twA = nullptr, *twA64, *twS64, *twC64, *ws64, *wc64;
+    const void *twA = nullptr;
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, A, &twA));
-    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, A, &twA64));
-    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, S, &twS64));
-    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, C, &twC64));
-    MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &ws64));
-    MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &wc64));
     const int list_cap = n_frames * cap;
     const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));   // flagged detections whose
                                                                                           // plane sums are split over workgroups
@@ -1376,33 +1452,15 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     MMW_TRY(ensure_scratch(ctx, list_bytes + part_bytes));
     int *d_nflag = (int *)ctx->scratch, *d_list = (int *)((char *)ctx->scratch + 256);
     MMW_HIP(hipMemsetAsync(d_nflag, 0, 256, ctx->stream));
-    // Error-bound constants of k_angle_argmax, in units of eps = 2^-24, for whichever kernel mmw_range_doppler runs on
-    // this plane.  Radix-2 register FFTs: per level one add and one twiddled difference, <= 3.5 eps of the running
-    // sum of |terms| (FMA complex product + table twiddle), 2 levels' worth for the two window factors; levels that
-    // evaluate an R-point DFT directly (mixed-radix kernel, direct-DFT fallback) add an R-term FMA chain, <= R eps.
-    const float eps = 5.9604645e-8f;
-    int ulps = 4 * 2;
-    for (int n = 1; n < S; n <<= 1) ulps += 4;
-    for (int n = 1; n < C; n <<= 1) ulps += 4;
-    if (!fused_rd_ok(S, C) && !rd_lds_supported(S, C)) {
-        RdMixedPlan mp;
-        if (rd_mixed_plan(S, C, sizeof(cplx<float>), &mp) && !env_int("MMW_NO_MIXED_RD", 0))
-            ulps += mp.s1 + mp.s2 + mp.c1 + mp.c2 + 2 * (mp.rad_s[0] + mp.rad_s[1] + mp.rad_c[0] + mp.rad_c[1]);
-        else
-            ulps += (is_pow2(S) ? 0 : S) + (is_pow2(C) ? 0 : C);
-    }
-    // The worst-case bound assumes every rounding error of every partial sum lines up; measured float32 errors stay below
-    // 1.2 % of it (tools/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).  The kernel uses
-    // 1/8 of the worst case -- still ~10x above anything observed -- which cuts the float64 re-evaluations (each reads
-    // the antennas' whole planes) from 1.8 % to 0.2 % of the detections; MMW_ARGMAX_BOUND_DIV=1 restores the full bound.
-    const float div = (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 8));
-    ArgmaxRefine rf{d_l1, d_nflag, d_list, list_cap, (float)ulps * eps / div, 4.f * (float)(n_ant + 4) * eps / div};
+    const float eps = 5.9604645e-8f, div = argmax_bound_div();
+    ArgmaxRefine rf{d_l1, d_nflag, d_list, list_cap, (float)rd_error_ulps(S, C) * eps / div, 4.f * (float)(n_ant + 4) * eps / div};
     ProfScope ps(ctx, "argmax");
     dim3 grid(std::min((cap + 3) / 4, 32), n_frames);      // 128 detections per frame in one pass, more by looping
     launch_angle_argmax(ctx, grid, (const float2 *)d_rd, d_dets, d_counts, d_idx, V, S, C, cap, ants, A, shift,
                         (const float2 *)twA, rf);
     MMW_TRY(check_launch("angle_argmax"));
     RefineArgs ra{};
+    MMW_TRY(fill_refine_args(ctx, &ra, S, C, A));
     ra.cubes = (const float2 *)d_cubes;
     ra.dets = d_dets;
     ra.n_flag = d_nflag;
@@ -1410,33 +1468,231 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     ra.list_cap = list_cap;
     ra.out_idx = d_idx;
     ra.V = V;
-    ra.S = S;
-    ra.C = C;
     ra.cap = cap;
     ra.ants = ants;
-    ra.A = A;
     ra.shift = shift;
-    ra.ws = (const double *)ws64;
-    ra.wc = (const double *)wc64;
-    ra.twS = (const cplx<double> *)twS64;
-    ra.twC = (const cplx<double> *)twC64;
-    ra.twA = (const cplx<double> *)twA64;
     ra.partial = (cplx<double> *)((char *)ctx->scratch + list_bytes);
     ra.n_split = n_split;
-    // grids are fixed (the flagged count stays on the device): workgroups beyond it leave at once
-    if (n_split > 0) {
-        hipLaunchKernelGGL(k_argmax_refine_part, dim3(REFINE_PARTS, std::min(n_split, 4 * ctx->num_cu)), dim3(256), 0, ctx->stream, ra);
-        MMW_TRY(check_launch("argmax_refine_part"));
-        hipLaunchKernelGGL(k_argmax_refine_finish, dim3(std::min((n_split + 3) / 4, 2 * ctx->num_cu)), dim3(256), 0, ctx->stream, ra);
-        MMW_TRY(check_launch("argmax_refine_finish"));
-    }
-    if (list_cap > n_split) {
-        hipLaunchKernelGGL(k_argmax_refine_whole, dim3(2 * ctx->num_cu), dim3(256), 0, ctx->stream, ra);
-        MMW_TRY(check_launch("argmax_refine_whole"));
-    }
+    MMW_TRY(launch_argmax_refine(ctx, ra));
     if (h_n_refined) {
         MMW_HIP(hipMemcpyAsync(h_n_refined, d_nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MMW_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MMW_OK;
+}
+
+// ------------------------------------------------------------------ fused detection + point-cloud indices (mmw_detect.h)
+namespace {
+struct DetectPlan {
+    bool ok;
+    int band_rows, words;
+    size_t lds_screen, lds_cell, lds_finish;
+};
+DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, int n_az, int n_el) {
+    DetectPlan p{};
+    const long n = (long)S * C;
+    const int hr = tr + gr, hd = td + gd;
+    if (kind != MMW_CFAR_CA || n_az > DET_MAX_ANT || n_el > DET_MAX_ANT || n > (1L << 20)) return p;
+    if (tune_int("MMW_NO_DETECT_SCREEN", 0)) return p;
+    p.words = (int)((n + 31) / 32);
+    const size_t lds_max = 160 * 1024, fixed = detect_screen_lds(S, C, 0);
+    if (fixed + 16 * (size_t)C > lds_max) return p;                   // the float32 plane must fit the LDS
+    int br = (int)((lds_max - fixed) / (16 * (size_t)C));
+    br = std::min(br, std::max(1, S - 2 * hr));
+    int unit = DET_NT;                                                // band cells a multiple of the workgroup size
+    for (int g = C; g % 2 == 0 && unit > 1; g /= 2) unit /= 2;        // unit = DET_NT / gcd(C, DET_NT)
+    if (br >= unit) br -= br % unit;
+    p.band_rows = br;
+    p.lds_screen = detect_screen_lds(S, C, br);
+    p.lds_cell = cell_exact_lds(C, 2 * hr + 1, 2 * hd + 1);
+    p.lds_finish = (((size_t)p.words * 4 + 15) & ~(size_t)15) + 96 * 4;
+    p.ok = p.lds_cell <= 64 * 1024 && p.lds_finish <= 64 * 1024;
+    return p;
+}
+int fill_det_ant(const int *h_ant, int n_ant, int V, int A, DetAnt *out, AntList *full) {
+    out->n = 0;
+    full->n = 0;
+    if (n_ant == 0) return MMW_OK;
+    MMW_TRY(fill_ant_list(h_ant, n_ant, V, A, full));
+    out->n = full->n;
+    for (int i = 0; i < full->n && i < DET_MAX_ANT; ++i) out->idx[i] = full->idx[i];
+    return MMW_OK;
+}
+}  // namespace
+
+int mmw_detect_points_supported(int S, int C, int cfar_kind, int train_r, int train_d, int guard_r, int guard_d, int n_az,
+                                int n_el) {
+    if (S <= 0 || C <= 0 || train_r < 0 || train_d < 0 || guard_r < 0 || guard_d < 0 || n_az < 0 || n_el < 0) return 0;
+    return detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el).ok ? 1 : 0;
+}
+
+int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1, float *d_mag32, int32_t *d_dets,
+                      int32_t *d_counts, int32_t *d_az_idx, int32_t *d_el_idx, int n_frames, int V, int S, int C, int cfar_kind,
+                      int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap, const int *h_az,
+                      int n_az, int shift_az, const int *h_el, int n_el, int shift_el, int A, int *h_stats) {
+    MMW_REQUIRE(ctx && d_cubes && d_rd && d_l1 && d_dets && d_counts, "null argument");
+    MMW_JOIN(ctx);
+    MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && cap >= 0 && A > 0, "bad shape");
+    MMW_REQUIRE(train_r >= 0 && train_d >= 0 && guard_r >= 0 && guard_d >= 0, "negative window size");
+    MMW_REQUIRE(n_az >= 0 && n_el >= 0 && (n_az == 0 || d_az_idx) && (n_el == 0 || d_el_idx), "antenna list without an index buffer");
+    MMW_REQUIRE((long)n_frames * std::max(cap, 1) < (1L << 31), "too many detection slots for one call");
+    const DetectPlan plan = detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el);
+    if (!plan.ok)
+        return set_error(MMW_ERR_UNSUPPORTED, "mmw_detect_points: no screening kernel for this request (CA-CFAR on planes whose "
+                         "float32 magnitudes fit the LDS, <= %d antennas per list): use mmw_detect_batch + mmw_angle_argmax_exact",
+                         DET_MAX_ANT);
+    const int hr = train_r + guard_r, hd = train_d + guard_d;
+    const long n_train = (long)(2 * hr + 1) * (2 * hd + 1) - (long)(2 * guard_r + 1) * (2 * guard_d + 1);
+    MMW_REQUIRE(n_train >= 1 && n_train < (1L << 30), "empty training window");
+    if (cfar_kind == MMW_CFAR_OS) MMW_REQUIRE(k_rank >= 1 && k_rank <= n_train, "k_rank must be between 1 and %ld, got %d", n_train, k_rank);
+    DetectArgs a{};
+    AntList az_full{}, el_full{};
+    MMW_TRY(fill_det_ant(h_az, n_az, V, A, &a.az, &az_full));
+    MMW_TRY(fill_det_ant(h_el, n_el, V, A, &a.el, &el_full));
+    if (h_stats)
+        for (int i = 0; i < 5; ++i) h_stats[i] = 0;
+    if (n_frames == 0) return MMW_OK;
+    const void *twA = nullptr, *ws64, *wc64, *twS64, *twC64;
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, A, &twA));
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, S, &twS64));
+    MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, C, &twC64));
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &ws64));
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &wc64));
+    // scratch: counters | flagged frames | undecided cells | bit masks | per list: flagged detections + partial sums
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int cell_cap = std::max(4096, 16 * n_frames);
+    const int list_cap = n_frames * cap;
+    const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));
+    const size_t b_ctl = up(DCTL_WORDS * sizeof(int)), b_ff = up((size_t)n_frames * sizeof(int)),
+                 b_cells = up((size_t)cell_cap * 2 * sizeof(int)), b_bits = up((size_t)n_frames * plan.words * sizeof(unsigned)),
+                 b_list = up((size_t)std::max(list_cap, 1) * sizeof(int));
+    const size_t b_part_az = up((size_t)n_split * REFINE_PARTS * std::max(n_az, 1) * sizeof(cplx<double>)),
+                 b_part_el = up((size_t)n_split * REFINE_PARTS * std::max(n_el, 1) * sizeof(cplx<double>));
+    size_t total = b_ctl + b_ff + b_cells + b_bits;
+    if (n_az) total += b_list + b_part_az;
+    if (n_el) total += b_list + b_part_el;
+    MMW_TRY(ensure_scratch(ctx, total));
+    char *base = (char *)ctx->scratch;
+    a.ctl = (int *)base;
+    a.flag_frames = (int *)(base + b_ctl);
+    a.cells = (int *)(base + b_ctl + b_ff);
+    a.bits = (unsigned *)(base + b_ctl + b_ff + b_cells);
+    char *next = base + b_ctl + b_ff + b_cells + b_bits;
+    int *list_az = nullptr, *list_el = nullptr;
+    cplx<double> *part_az = nullptr, *part_el = nullptr;
+    if (n_az) {
+        list_az = (int *)next;
+        part_az = (cplx<double> *)(next + b_list);
+        next += b_list + b_part_az;
+    }
+    if (n_el) {
+        list_el = (int *)next;
+        part_el = (cplx<double> *)(next + b_list);
+        next += b_list + b_part_el;
+    }
+    MMW_HIP(hipMemsetAsync(a.ctl, 0, DCTL_WORDS * sizeof(int), ctx->stream));
+    // range-Doppler of every antenna (float32) with the planes' L1 norms
+    MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
+    const float eps = 5.9604645e-8f, div = argmax_bound_div();
+    const int ulps = rd_error_ulps(S, C);
+    a.rd = (const float2 *)d_rd;
+    a.l1 = d_l1;
+    a.mag32 = d_mag32;
+    a.dets = d_dets;
+    a.counts = d_counts;
+    a.az_idx = d_az_idx;
+    a.el_idx = d_el_idx;
+    a.cell_cap = cell_cap;
+    a.V = V;
+    a.S = S;
+    a.C = C;
+    a.cap = cap;
+    a.words = plan.words;
+    a.band_rows = plan.band_rows;
+    a.kind = cfar_kind;
+    a.tr = train_r;
+    a.td = train_d;
+    a.gr = guard_r;
+    a.gd = guard_d;
+    a.n_train = (int)n_train;
+    a.k_rank = k_rank;
+    a.scale = scale;
+    // the screening band always uses the full worst-case bound (MMW_DETECT_BAND_MULT widens it: test hook that sends more
+    // cells through the float64 decision, or -- when huge -- whole frames back to the caller)
+    a.k_fft = (float)ulps * eps * (float)std::max(1, env_int("MMW_DETECT_BAND_MULT", 1));
+    a.A = A;
+    a.shift_az = shift_az;
+    a.shift_el = shift_el;
+    a.twA = (const float2 *)twA;
+    a.rf_az = ArgmaxRefine{d_l1, a.ctl + DCTL_AZ, list_az, list_cap, (float)ulps * eps / div, 4.f * (float)(n_az + 4) * eps / div};
+    a.rf_el = ArgmaxRefine{d_l1, a.ctl + DCTL_EL, list_el, list_cap, (float)ulps * eps / div, 4.f * (float)(n_el + 4) * eps / div};
+    {
+        ProfScope ps(ctx, "detect");
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_detect_screen), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)plan.lds_screen));
+        hipLaunchKernelGGL(k_detect_screen, dim3(n_frames), dim3(DET_NT), plan.lds_screen, ctx->stream, a);
+        MMW_TRY(check_launch("detect_screen"));
+    }
+    {
+        ProfScope ps(ctx, "detect_exact");
+        CellExactArgs ce{};
+        ce.cubes = (const float2 *)d_cubes;
+        ce.cells = a.cells;
+        ce.n_cells = a.ctl + DCTL_CELLS;
+        ce.cell_cap = cell_cap;
+        ce.bits = a.bits;
+        ce.V = V;
+        ce.S = S;
+        ce.C = C;
+        ce.words = plan.words;
+        ce.kind = cfar_kind;
+        ce.tr = train_r;
+        ce.td = train_d;
+        ce.gr = guard_r;
+        ce.gd = guard_d;
+        ce.n_train = (int)n_train;
+        ce.k_rank = k_rank;
+        ce.scale = scale;
+        ce.ws = (const double *)ws64;
+        ce.wc = (const double *)wc64;
+        ce.twS = (const cplx<double> *)twS64;
+        ce.twC = (const cplx<double> *)twC64;
+        hipLaunchKernelGGL(k_cfar_cell_exact, dim3(std::min(cell_cap, 2 * ctx->num_cu)), dim3(256), plan.lds_cell, ctx->stream, ce);
+        MMW_TRY(check_launch("cfar_cell_exact"));
+        hipLaunchKernelGGL(k_detect_finish, dim3(std::min(n_frames, ctx->num_cu)), dim3(DET_NT), plan.lds_finish, ctx->stream, a);
+        MMW_TRY(check_launch("detect_finish"));
+    }
+    if (cap > 0) {
+        ProfScope ps(ctx, "argmax_refine");
+        for (int which = 0; which < 2; ++which) {
+            const AntList &ants = which ? el_full : az_full;
+            if (ants.n == 0) continue;
+            RefineArgs ra{};
+            MMW_TRY(fill_refine_args(ctx, &ra, S, C, A));
+            ra.cubes = (const float2 *)d_cubes;
+            ra.dets = d_dets;
+            ra.n_flag = a.ctl + (which ? DCTL_EL : DCTL_AZ);
+            ra.list = which ? list_el : list_az;
+            ra.list_cap = list_cap;
+            ra.out_idx = which ? d_el_idx : d_az_idx;
+            ra.V = V;
+            ra.cap = cap;
+            ra.ants = ants;
+            ra.shift = which ? shift_el : shift_az;
+            ra.partial = which ? part_el : part_az;
+            ra.n_split = n_split;
+            MMW_TRY(launch_argmax_refine(ctx, ra));
+        }
+    }
+    if (h_stats) {
+        int h[DCTL_WORDS];
+        MMW_HIP(hipMemcpyAsync(h, a.ctl, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        MMW_HIP(hipStreamSynchronize(ctx->stream));
+        h_stats[0] = h[DCTL_FLAG_FRAMES];
+        h_stats[1] = h[DCTL_CELLS];
+        h_stats[2] = h[DCTL_FALLBACK];
+        h_stats[3] = h[DCTL_AZ];
+        h_stats[4] = h[DCTL_EL];
     }
     return MMW_OK;
 }

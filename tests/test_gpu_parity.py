@@ -1543,3 +1543,135 @@ def test_int16_iq_ingest_matches_the_complex64_raw_path():
     assert rel_err(b.fetch_chain3d(F - 1), O.fft3d_windowed(a.cubes(F - 1, F)[0])) <= SPEC_TOL
     with pytest.raises(ValueError):
         b.load_raw_i16(iq[..., 0], ntx)
+
+
+def _detect_points_raw(ctx, d_in, F, shape, cfar, cap, az, el, A=64):
+    """mmw_detect_points on resident cubes -> (counts, dets, az_idx, el_idx, stats)."""
+    V, S, C = shape
+    (tr, td), (gr, gd) = cfar.num_train, cfar.num_guard
+    d_rd, d_l1 = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * V * 4)
+    d_dets, d_cnt = ctx.alloc(F * cap * 8), ctx.alloc(F * 4)
+    d_az, d_el = ctx.alloc(F * cap * 4), ctx.alloc(F * cap * 4)
+    a_az, n_az = _lib.int_array(az)
+    a_el, n_el = _lib.int_array(el)
+    stats = (_lib.C.c_int * 5)()
+    _lib.check(ctx.lib.mmw_detect_points(ctx.handle, d_in.ptr, d_rd.ptr, d_l1.ptr, None, d_dets.ptr, d_cnt.ptr, d_az.ptr, d_el.ptr,
+                                         F, V, S, C, cfar.kind, int(tr), int(td), int(gr), int(gd), float(cfar._scale()),
+                                         int(cfar._k_rank()), cap, a_az, n_az, 1, a_el, n_el, 0, A, stats))
+    out = (d_cnt.download((F,), np.int32), d_dets.download((F, cap, 2), np.int32), d_az.download((F, cap), np.int32),
+           d_el.download((F, cap), np.int32), list(stats))
+    for b in (d_rd, d_l1, d_dets, d_cnt, d_az, d_el):
+        b.free()
+    return out
+
+
+def _detect_float64_raw(ctx, d_in, F, shape, cfar, cap, az, el, A=64):
+    """The float64 path (mmw_detect_batch + mmw_angle_argmax_exact) on the same cubes."""
+    V, S, C = shape
+    (tr, td), (gr, gd) = cfar.num_train, cfar.num_guard
+    n = S * C
+    d_rd, d_l1, d_mag, d_mask = ctx.alloc(F * V * n * 8), ctx.alloc(F * V * 4), ctx.alloc(F * n * 8), ctx.alloc(F * n)
+    d_dets, d_cnt = ctx.alloc(F * cap * 8), ctx.alloc(F * 4)
+    d_az, d_el = ctx.alloc(F * cap * 4), ctx.alloc(F * cap * 4)
+    _lib.check(ctx.lib.mmw_detect_batch(ctx.handle, d_in.ptr, d_rd.ptr, d_mag.ptr, d_mask.ptr, d_dets.ptr, d_cnt.ptr, d_l1.ptr, F, V,
+                                        S, C, cfar.kind, int(tr), int(td), int(gr), int(gd), float(cfar._scale()),
+                                        int(cfar._k_rank()), cap))
+    for ant, d_idx, shift in ((az, d_az, 1), (el, d_el, 0)):
+        arr, n_ant = _lib.int_array(ant)
+        _lib.check(ctx.lib.mmw_angle_argmax_exact(ctx.handle, d_in.ptr, d_l1.ptr, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, F, V, S,
+                                                  C, cap, arr, n_ant, A, shift, None))
+    out = (d_cnt.download((F,), np.int32), d_dets.download((F, cap, 2), np.int32), d_az.download((F, cap), np.int32),
+           d_el.download((F, cap), np.int32))
+    for b in (d_rd, d_l1, d_mag, d_mask, d_dets, d_cnt, d_az, d_el):
+        b.free()
+    return out
+
+
+def _same_points(got, ref):
+    cnt, dets, az, el = got[:4]
+    cnt_r, dets_r, az_r, el_r = ref[:4]
+    np.testing.assert_array_equal(cnt, cnt_r)
+    for f in range(cnt.shape[0]):
+        k = int(cnt[f])
+        np.testing.assert_array_equal(dets[f, :k], dets_r[f, :k])
+        np.testing.assert_array_equal(az[f, :k], az_r[f, :k])
+        np.testing.assert_array_equal(el[f, :k], el_r[f, :k])
+
+
+@pytest.mark.parametrize("shape,frames", [((12, 256, 128), 160), ((12, 63, 100), 400), ((8, 64, 32), 300), ((12, 254, 50), 64)])
+def test_detect_points_screening_equals_the_float64_path(shape, frames, monkeypatch):
+    """mmw_detect_points (float32 screening with the worst-case error band + float64 decision of the undecided cells)
+    against mmw_detect_batch + mmw_angle_argmax_exact on the same resident cubes: counts, detections (values and order)
+    and both argmax index arrays identical; then with the band widened 50x (many cells through k_cfar_cell_exact)."""
+    V, S, C = shape
+    ctx = _lib.default_context()
+    cfar = CaCFAR2D((4, 4), (2, 2), 1e-5)
+    az, el = list(range(min(8, V))), list(range(max(0, V - 4), V))
+    d_in = ctx.alloc(frames * V * S * C * 8)
+    _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, frames, V, S, C, 424242, 8, 30.0))
+    assert ctx.lib.mmw_detect_points_supported(S, C, cfar.kind, 4, 4, 2, 2, len(az), len(el)) == 1
+    ref = _detect_float64_raw(ctx, d_in, frames, shape, cfar, 1024, az, el)
+    got = _detect_points_raw(ctx, d_in, frames, shape, cfar, 1024, az, el)
+    _same_points(got, ref)
+    print(f"{shape}: {frames} frames, {int(ref[0].sum())} detections; screening left {got[4][1]} cells in {got[4][0]} frames "
+          f"undecided, {got[4][2]} frames handed back, {got[4][3]} + {got[4][4]} argmax evaluations refined")
+    assert got[4][2] == 0 and ref[0].sum() > frames
+    monkeypatch.setenv("MMW_DETECT_BAND_MULT", "50")
+    wide = _detect_points_raw(ctx, d_in, frames, shape, cfar, 1024, az, el)
+    handed_back = wide[0] < 0
+    assert wide[4][1] > got[4][1] and handed_back.sum() == wide[4][2]
+    keep = ~handed_back
+    _same_points(tuple(x[keep] for x in wide[:4]), tuple(x[keep] for x in ref))
+    print(f"  band x50: {wide[4][1]} undecided cells in {wide[4][0]} frames, {wide[4][2]} frames handed back")
+    d_in.free()
+
+
+def test_detect_points_edge_cases_and_pipeline_fallback(monkeypatch):
+    """Zero cubes, a window larger than the plane, a detection capacity that overflows, non-finite samples in antenna 0
+    (count -1 -> FramePipeline runs the frame through the float64 path) and a band so wide that every frame is handed back."""
+    from mmwave_radar_processing_amd.batch import FramePipeline
+    ctx = _lib.default_context()
+    shape = (12, 64, 32)
+    V, S, C = shape
+    cfar = CaCFAR2D((4, 4), (2, 2), 1e-3)
+    az, el = list(range(8)), [8, 9, 10, 11]
+    cubes = np.stack([synth.synth_cube(7100 + f, shape) for f in range(6)])
+    cubes[1] = 0
+    cubes[3, 0, 5, 7] = np.inf
+    cubes[4, 0, 9, 1] = np.nan
+    d_in = ctx.alloc(cubes.nbytes)
+    d_in.upload(cubes)
+    got = _detect_points_raw(ctx, d_in, 6, shape, cfar, 256, az, el)
+    assert got[0][1] == 0 and got[0][3] == -1 and got[0][4] == -1 and got[4][2] == 2
+    ref = _detect_float64_raw(ctx, d_in, 6, shape, cfar, 256, az, el)
+    keep = got[0] >= 0
+    _same_points(tuple(x[keep] for x in got[:4]), tuple(x[keep] for x in ref))
+    # capacity overflow: exact counts, the first cap detections in order
+    small = _detect_points_raw(ctx, d_in, 6, shape, cfar, 3, az, el)
+    np.testing.assert_array_equal(small[0][keep], ref[0][keep])
+    for f in np.nonzero(keep)[0]:
+        k = min(3, int(ref[0][f]))
+        np.testing.assert_array_equal(small[1][f, :k], ref[1][f, :k])
+        np.testing.assert_array_equal(small[2][f, :k], ref[2][f, :k])
+    # window larger than the plane: no detections, no error (ca_cfar.py:99-102)
+    big = CaCFAR2D((40, 4), (2, 2), 1e-3)
+    assert np.all(_detect_points_raw(ctx, d_in, 6, shape, big, 16, az, el)[0][[0, 1, 2, 5]] == 0)
+    d_in.free()
+    # the pipeline hands frames the screening cannot decide to the float64 path
+    cm = make_cm(synth.synth_cfg_text(num_samples=S, num_loops=C))
+    sc = O.cfg_scalars(synth.synth_cfg_text(num_samples=S, num_loops=C))
+    pipe = FramePipeline(cm, max_frames=6, shape=shape, cfar=cfar, az_antenna_idxs=az, el_antenna_idxs=el)
+    finite = cubes.copy()
+    finite[3, 0, 5, 7] = 0
+    finite[4, 0, 9, 1] = 0
+    monkeypatch.setenv("MMW_DETECT_BAND_MULT", "100000000")
+    pipe.load(finite)
+    pcs = pipe.point_clouds()
+    assert pipe.screen_stats[2] >= 4            # (the zero frame has a zero band: it is decided)
+    for f in range(6):
+        pc_ref, dets_ref, az_i, el_i = O.point_cloud(finite[f], sc, az, el, num_train=(4, 4), num_guard=(2, 2), pfa=1e-3)
+        np.testing.assert_array_equal(pipe.dets[f], dets_ref)
+        if dets_ref.shape[0]:
+            np.testing.assert_array_equal(pipe.az_idx[f], az_i)
+            np.testing.assert_array_equal(pipe.el_idx[f], el_i)
+            np.testing.assert_allclose(pcs[f], pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
