@@ -220,7 +220,7 @@ int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_ma
  *   h_stats (may be NULL; passing it synchronises): [0] frames with undecided cells, [1] undecided cells, [2] frames
  *   returned with count -1, [3] / [4] azimuth / elevation detections re-evaluated in float64.
  *   MMW_ERR_UNSUPPORTED (nothing launched) when mmw_detect_points_supported(...) == 0: CA-CFAR only, S * C float32
- *   magnitudes must fit the LDS, at most 16 antennas per list. */
+ *   magnitudes must fit the LDS, at most 8 antennas per list. */
 int mmw_detect_points_supported(int S, int C, int cfar_kind, int train_r, int train_d, int guard_r, int guard_d,
                                 int n_az, int n_el);
 int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1, float *d_mag32, int32_t *d_dets,

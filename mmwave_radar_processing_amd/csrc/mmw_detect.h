@@ -15,9 +15,12 @@
 //   T' = alpha * mean(X32 over the training cells), in float64   =>  |T' - T64| <= alpha * B   (CA)
 //   T' = alpha * (k-th smallest X32 of the training cells)       =>  |T' - T64| <= alpha * B   (OS: order statistics are
 //                                                                                               1-Lipschitz in the sup norm)
-//   d = X32 - T':   d >  band  => detection for certain,   d <= -band => certainly none,   band = (1 + alpha) B + 1e-7 (X32 + T')
+//   d = X32 - T':   d >  band  => detection for certain,   d <= -band => certainly none,   band = (1 + alpha) B + 3e-6 (X32 + T')
 //
-// (the 1e-7 term covers the rounding of |.| to float32 for the LDS plane).  Cells inside the band -- one frame in ~13 of
+// (the 3e-6 term covers the float32 evaluation of |.| = sqrt(fma(re, re, im * im)) -- three roundings, under 2e-7 relative for
+// planes whose L1 norm is within [1e-10, 1e18], anything else is handed back -- and the float32 window sums: they add
+// non-negative numbers only -- training rows of every window column plus guard rows of the columns outside the guard --
+// so at most 33 roundings of 2^-24 relative each).  Cells inside the band -- one frame in ~13 of
 // the synthetic workload has one -- are decided EXACTLY: k_cfar_cell_exact evaluates the (2 hr + 1) x (2 hd + 1) window
 // of float64 range-Doppler magnitudes around the cell as direct float64 DFT sums of the input cube and applies the
 // reference's float64 rule.  Frames with such cells skip compaction in the screening kernel and are finished by
@@ -34,8 +37,11 @@
 namespace mmw {
 
 constexpr int DET_NT = 1024;             // threads of the per-frame workgroup
-constexpr int DET_MAX_ANT = 16;          // antennas per list inside the fused kernels
-enum { DCTL_FLAG_FRAMES = 0, DCTL_CELLS = 1, DCTL_FALLBACK = 2, DCTL_AZ = 16, DCTL_EL = 32, DCTL_WORDS = 64 };
+constexpr int DET_MAX_ANT = 8;           // antennas per list inside the fused kernels (cells, twiddles and error scales of a
+                                         // list live in registers; lists of 9+ antennas take mmw_angle_argmax_exact)
+constexpr int DET_LIST2 = 16;            // first lane of the second list's cells
+enum { DCTL_FLAG_FRAMES = 0, DCTL_CELLS = 1, DCTL_FALLBACK = 2, DCTL_ARGMAX = 16, DCTL_EL = 32, DCTL_WORDS = 64 };   // ARGMAX: flagged
+                                                    // evaluations of both lists (the refinement list's length), EL: those of the second
 
 struct DetAnt {            // antenna list of one angle estimate (n == 0: not wanted)
     int n;
@@ -53,7 +59,7 @@ struct DetectArgs {
     int *flag_frames;          // [F] frames with undecided cells
     int *cells;                // [cell_cap][2] undecided cells: (frame, r * C + c)
     int cell_cap;
-    int V, S, C, cap, words, band_rows;
+    int V, S, C, cap, words, band_rows, band_pitch;   // band buffers: band_rows x band_pitch floats each
     int kind, tr, td, gr, gd, n_train, k_rank;
     double scale;
     float k_fft;               // ulps * 2^-24 of the RD kernel that ran
@@ -61,7 +67,12 @@ struct DetectArgs {
     int A, shift_az, shift_el;
     const float2 *twA;
     ArgmaxRefine rf_az, rf_el;
+    long long *clk;            // diagnostics (MMW_PHASE_CLOCKS=1): s_memtime at the phase boundaries of a mid-batch workgroup
 };
+
+__device__ __forceinline__ void det_mark(const DetectArgs &a, int i) {
+    if (a.clk && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) a.clk[i] = (long long)__builtin_amdgcn_s_memtime();
+}
 
 // exclusive prefix of v over the workgroup (thread order), total in *total; ws: 40 ints of LDS
 __device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total) {
@@ -90,74 +101,173 @@ __device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total) {
     return excl;
 }
 
-// antenna tables of the two lists in LDS (tab[0..16) azimuth, tab[16..32) elevation): constant kernel-argument indices
+// antenna tables of the two lists in LDS (tab[0..8) azimuth, tab[16..24) elevation): constant kernel-argument indices
 // here, lane-indexed reads later
 __device__ __forceinline__ void detect_ant_table(const DetectArgs &a, int *tab) {
     if (threadIdx.x == 0) {
         static_for<DET_MAX_ANT>([&](auto I) {
             constexpr int i = decltype(I)::value;
             tab[i] = a.az.idx[i];
-            tab[DET_MAX_ANT + i] = a.el.idx[i];
+            tab[DET_LIST2 + i] = a.el.idx[i];
         });
     }
 }
 
-// One wave, one detection, one antenna list whose cells sit in lanes [base, base + n) of xl: zero-padded A-point DFT,
-// |.|, first maximum -- k_angle_argmax's arithmetic with the cells read out of the lanes (v_readlane) instead of held
-// n-fold in every lane's registers.
-__device__ __forceinline__ void detect_argmax_lanes(const DetectArgs &a, float2 xl, int base, int n, int shift, int32_t *out_idx,
-                                                    const ArgmaxRefine &rf, float sum_l1, long slot, int lane) {
-    const float NEG = -__builtin_huge_valf();
+// Wave-wide reductions on the DPP network (row rotations inside the rows of 16 lanes, then row_bcast:15 / row_bcast:31
+// into the following rows: the total arrives in lane 63) -- a few clocks per step where a __shfl_xor butterfly is a
+// dependent chain of ds_bpermute round trips (24 of them per detection and list were half of the argmax phase).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned src) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, dpp_u32<0xB1, 0xf>(v, v));       // quad_perm [1,0,3,2]
+    v = max(v, dpp_u32<0x4E, 0xf>(v, v));       // quad_perm [2,3,0,1]
+    v = max(v, dpp_u32<0x124, 0xf>(v, v));      // row_ror:4
+    v = max(v, dpp_u32<0x128, 0xf>(v, v));      // row_ror:8
+    v = max(v, dpp_u32<0x142, 0xa>(v, v));      // row_bcast:15 into rows 1, 3
+    v = max(v, dpp_u32<0x143, 0xc>(v, v));      // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float wave_sum_f32(float x) {
+    auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
+    auto u = [](float v) { return __builtin_bit_cast(unsigned, v); };
+    x += f(dpp_u32<0xB1, 0xf>(0u, u(x)));
+    x += f(dpp_u32<0x4E, 0xf>(0u, u(x)));
+    x += f(dpp_u32<0x124, 0xf>(0u, u(x)));
+    x += f(dpp_u32<0x128, 0xf>(0u, u(x)));
+    x += f(dpp_u32<0x142, 0xa>(0u, u(x)));
+    x += f(dpp_u32<0x143, 0xc>(0u, u(x)));
+    return f((unsigned)__builtin_amdgcn_readlane((int)u(x), 63));
+}
+// order-preserving key of a magnitude (>= 0, or NaN: every NaN maps to the top key, as np.argmax treats them alike)
+__device__ __forceinline__ unsigned mag_key(float m) { return m != m ? 0xffffffffu : __builtin_bit_cast(unsigned, m); }
+__device__ __forceinline__ float key_mag(unsigned k) {
+    return k == 0xffffffffu ? __builtin_nanf("") : __builtin_bit_cast(float, k);
+}
+
+// One wave, one detection, one antenna list whose cells sit in lanes [base, base + n) of xl (lanes up to base + NMAX hold
+// zeros, l1v the L1 norm of the lane's antenna plane): zero-padded A-point DFT, |.|, first maximum -- k_angle_argmax's
+// arithmetic with the cells read out of the lanes (v_readlane: wave-uniform values) instead of held n-fold in every
+// lane's registers; tw = W_A^m table (LDS).
+//
+// Is the float32 winner the float64 one?  The cells carry errors |dx_i| <= e_i = k_fft l1_i (range-Doppler kernel), the
+// float32 evaluation of a bin's sum S_k another |eta| <= c = k_ang sum |x_i|.  k_angle_argmax asks for
+// m_1 - m_k > 2 (sum e_i + c), which treats the errors of the two bins as independent; they are not -- both come from
+// the SAME dx_i.  With u = S / |S| and convexity of |.|:   |S + d| - |S| = Re(u* d) + r,  0 <= r <= |d|^2 / (2 |S|), so
+//   (m_1 - m_k)(x + dx) - (m_1 - m_k)(x)  >=  - sum_i e_i |u_1* W^(i k_1) - u_k* W^(i k)|  -  Be^2 / (2 min(m_1, m_k)),   Be = sum e_i.
+// For the neighbours of the peak of a plane wave the bracket is ~0.1 instead of 2, so a detection is flagged (and read
+// again, whole planes, by the float64 kernels) an order of magnitude less often at the same e_i.  A bin passes if
+// either form of the bound clears its margin; any bin that does not flags the detection.
+template <int NMAX>
+__device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const float2 *tw, float2 xl, float l1v, int base, int n,
+                                                   int shift, int32_t *out_idx, const ArgmaxRefine &rf, long slot, int lane, int tag) {
     const int A = a.A;
-    float best = NEG, second = NEG;
-    int best_idx = 0x7fffffff;
-    for (int k = lane; k < A; k += 64) {
-        float re = 0.f, im = 0.f;
+    float xr[NMAX], xi[NMAX], e[NMAX], be = 0.f, sum_abs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+        xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xl.x), base + i));
+        xi[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xl.y), base + i));
+        e[i] = rf.k_fft * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l1v), base + i));
+        be += e[i];
+        sum_abs += fabsf(xr[i]) + fabsf(xi[i]);
+    }
+    // the bin's sum S_k and the twiddles it used
+    auto bin = [&](int k, float2 (&w)[NMAX], float &re, float &im) {
         int t = 0;
-        for (int i = 0; i < n; ++i) {
-            const float xr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xl.x), base + i));
-            const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xl.y), base + i));
-            const float2 w = a.twA[t];
-            re += xr * w.x - xi * w.y;
-            im += xr * w.y + xi * w.x;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) {        // W_A^(i k mod A); the table reads are issued before the first use
+            w[i] = tw[t];
             t += k;
             if (t >= A) t -= A;
         }
-        const float m = hypotf(re, im);
+        re = im = 0.f;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) {
+            re += xr[i] * w[i].x - xi[i] * w[i].y;
+            im += xr[i] * w[i].y + xi[i] * w[i].x;
+        }
+    };
+    float best = -__builtin_huge_valf(), best_re = 0.f, best_im = 0.f;
+    int best_idx = 0x7fffffff;
+    for (int k = lane; k < A; k += 64) {
+        float2 w[NMAX];
+        float re, im;
+        bin(k, w, re, im);
+        const float m = __fsqrt_rn(fmaf(re, re, im * im));       // (magnitudes near the float32 range end in the float64 pass)
         const int kk = shift ? (k + A / 2) % A : k;
         if (best_idx == 0x7fffffff || mag_better(m, kk, best, best_idx)) {
-            if (best_idx != 0x7fffffff) second = best;
             best = m;
             best_idx = kk;
-        } else if (mag_gt(m, second)) second = m;
-    }
-    float wb = best;
-    int wi = best_idx;
-    for (int d = 32; d >= 1; d >>= 1) {
-        const float ob = __shfl_xor(wb, d, 64);
-        const int oi = __shfl_xor(wi, d, 64);
-        if (oi != 0x7fffffff && (wi == 0x7fffffff || mag_better(ob, oi, wb, wi))) {
-            wb = ob;
-            wi = oi;
+            best_re = re;
+            best_im = im;
         }
     }
-    float ws2 = (best_idx == wi) ? second : best;
-    for (int d = 32; d >= 1; d >>= 1) {
-        const float o = __shfl_xor(ws2, d, 64);
-        if (mag_gt(o, ws2)) ws2 = o;
+    // first maximum over the wave: largest key, smallest bin index among its holders
+    const bool has = best_idx != 0x7fffffff;
+    const unsigned kb = has ? mag_key(best) : 0u;
+    const unsigned top = wave_max_u32(kb);
+    const int wi = (int)~wave_max_u32((has && kb == top) ? ~(unsigned)best_idx : 0u);
+    const int l1 = __ffsll((long long)__ballot(has && best_idx == wi)) - 1;
+    const float m1 = key_mag(top);
+    const float re1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_re), l1));
+    const float im1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_im), l1));
+    // every other bin against the winner
+    const float c_ang = rf.k_ang * sum_abs, two_b = 2.f * (be + c_ang), inv1 = 1.f / m1, u1x = re1 * inv1, u1y = im1 * inv1;
+    const int k1 = shift ? (wi + A - A / 2) % A : wi;
+    float2 t1[NMAX];                    // conj(u_1) W^(i k_1)
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) {
+            const float2 w = tw[t];
+            t1[i] = make_float2(u1x * w.x + u1y * w.y, u1x * w.y - u1y * w.x);
+            t += k1;
+            if (t >= A) t -= A;
+        }
     }
-    // sum |re| + |im| of the list's cells (scale of the angle-DFT term of the bound)
-    float sum_abs = (lane >= base && lane < base + n) ? fabsf(xl.x) + fabsf(xl.y) : 0.f;
-    for (int d = 32; d >= 1; d >>= 1) sum_abs += __shfl_xor(sum_abs, d, 64);
+    bool bad = !(m1 == m1) || !has;                              // NaN winner: the float64 pass decides
+    for (int k = lane; k < A; k += 64) {
+        const int kk = shift ? (k + A / 2) % A : k;
+        if (kk == wi) continue;
+        float2 w[NMAX];
+        float re, im;
+        bin(k, w, re, im);
+        const float m = __fsqrt_rn(fmaf(re, re, im * im)), margin = m1 - m;
+        bool ok = margin > two_b;
+        if (!ok && m > 0.f) {
+            const float inv = 1.f / m, ux = re * inv, uy = im * inv;
+            float lin = 0.f;
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) {
+                const float dx = t1[i].x - (ux * w[i].x + uy * w[i].y), dy = t1[i].y - (ux * w[i].y - uy * w[i].x);
+                lin += e[i] * __fsqrt_rn(fmaf(dx, dx, dy * dy));
+            }
+            ok = margin > 1.001f * (lin + be * be / (2.f * fminf(m1, m))) + 2.f * c_ang;
+        }
+        bad |= !ok;
+    }
+    const bool flag = __ballot(bad) != 0ull;
     if (lane == 0) {
         out_idx[slot] = wi;
-        argmax_flag(rf, sum_l1, sum_abs, wb, ws2, (int)slot);
+        if (flag) {                                 // both lists share one refinement list
+            const int pos = atomicAdd(rf.n_flag, 1);
+            if (pos < rf.list_cap) rf.list[pos] = (int)slot | tag;
+            if (tag) atomicAdd(a.ctl + DCTL_EL, 1);
+        }
     }
 }
 
+__device__ __forceinline__ void detect_argmax_lanes(const DetectArgs &a, const float2 *tw, float2 xl, float l1v, int base, int n,
+                                                    int shift, int32_t *out_idx, const ArgmaxRefine &rf, long slot, int lane,
+                                                    int tag) {
+    if (n <= 4) detect_argmax_list<4>(a, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag);
+    else detect_argmax_list<DET_MAX_ANT>(a, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag);
+}
+
 // Ordered compaction of the frame's bit mask (bit r * C + c, LDS) into dets / counts, then the angle argmax of every
-// detection.  ws: 96 ints of LDS ([48, 80) = antenna table).  Ends with every thread past its last use of bits / ws.
-__device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const unsigned *bits, int *ws) {
+// detection.  ws: 96 ints of LDS ([48, 80) = antenna table), tw: W_A^m in LDS.  Ends with every thread past its last
+// use of bits / ws.
+__device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const unsigned *bits, int *ws, const float2 *tw) {
     const int tid = threadIdx.x, C = a.C;
     int base = 0;
     for (int w0 = 0; w0 < a.words; w0 += DET_NT) {
@@ -178,120 +288,97 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
         base += total;
     }
     if (tid == 0) a.counts[f] = base;           // exact even beyond cap (MMW_ERR_TRUNCATED is the caller's check)
+    det_mark(a, 3);
     const int n_az = a.az.n, n_el = a.el.n;
     if (n_az == 0 && n_el == 0) return;
     __syncthreads();                            // the workgroup's own dets are visible to all of its waves
     const int n_det = base < a.cap ? base : a.cap;
     const int lane = tid & 63, wave = tid >> 6;
     const int *tab = ws + 48;
-    // lanes [0, n_az): azimuth list, lanes [16, 16 + n_el): elevation list
-    const bool mine = (lane < n_az) || (lane >= DET_MAX_ANT && lane < DET_MAX_ANT + n_el);
+    // lanes [0, n_az): azimuth list, lanes [DET_LIST2, DET_LIST2 + n_el): elevation list
+    const bool mine = (lane < n_az) || (lane >= DET_LIST2 && lane < DET_LIST2 + n_el);
     const long ant = mine ? tab[lane] : 0;
-    float l1v = mine ? a.l1[f * a.V + ant] : 0.f, l1_az = lane < DET_MAX_ANT ? l1v : 0.f, l1_el = lane >= DET_MAX_ANT ? l1v : 0.f;
-    for (int d = 32; d >= 1; d >>= 1) {
-        l1_az += __shfl_xor(l1_az, d, 64);
-        l1_el += __shfl_xor(l1_el, d, 64);
-    }
+    const float l1v = mine ? a.l1[f * a.V + ant] : 0.f;
     const float2 *plane = a.rd + (f * a.V + ant) * (long)a.S * C;
-    for (int det = wave; det < n_det; det += DET_NT / 64) {
-        const long slot = f * a.cap + det;
-        const int r = a.dets[slot * 2], c = a.dets[slot * 2 + 1];
-        const float2 xl = mine ? plane[(long)r * C + c] : make_float2(0.f, 0.f);
-        if (n_az) detect_argmax_lanes(a, xl, 0, n_az, a.shift_az, a.az_idx, a.rf_az, l1_az, slot, lane);
-        if (n_el) detect_argmax_lanes(a, xl, DET_MAX_ANT, n_el, a.shift_el, a.el_idx, a.rf_el, l1_el, slot, lane);
-    }
-}
-
-// LDS of k_detect_screen: float32 plane, two float64 band buffers, bit mask, 96 ints
-inline size_t detect_screen_lds(int S, int C, int band_rows) {
-    const size_t n = (size_t)S * C, words = (n + 31) / 32;
-    return ((n * 4 + 15) & ~(size_t)15) + 2 * (size_t)band_rows * C * 8 + ((words * 4 + 15) & ~(size_t)15) + 96 * 4;
-}
-
-__global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = a.S, C = a.C, n = S * C, tid = threadIdx.x;
-    const long f = blockIdx.x;
-    float *Xs = reinterpret_cast<float *>(smem);
-    size_t off = ((size_t)n * 4 + 15) & ~(size_t)15;
-    double *Vw = reinterpret_cast<double *>(smem + off);
-    off += (size_t)a.band_rows * C * 8;
-    double *Vg = reinterpret_cast<double *>(smem + off);
-    off += (size_t)a.band_rows * C * 8;
-    unsigned *bits = reinterpret_cast<unsigned *>(smem + off);
-    off += ((size_t)a.words * 4 + 15) & ~(size_t)15;
-    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow
-    if (tid < 2) ws[44 + tid] = 0;
-    detect_ant_table(a, ws + 48);
-    for (int w = tid; w < a.words; w += DET_NT) bits[w] = 0u;
-
-    // error band scale; 1.0001 covers the float32 summation of the L1 norm itself
-    const double Bf = (double)a.k_fft * (double)a.l1[f * a.V] * 1.0001;
-    const bool degenerate = !(Bf >= 0.0 && Bf <= 1e300);       // NaN / inf samples in antenna 0
-    // |RD| of antenna 0: float64 square root of the exact float64 sum of squares, rounded once to float32
-    {
-        const float2 *p = a.rd + f * a.V * n;
-        float *mg = a.mag32 ? a.mag32 + f * n : nullptr;
-        if ((n & 1) == 0) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            const f4 *p4 = reinterpret_cast<const f4 *>(p);
-            for (int i = tid; i < n / 2; i += DET_NT) {
-                const f4 v = p4[i];
-                const float m0 = (float)sqrt((double)v.x * v.x + (double)v.y * v.y);
-                const float m1 = (float)sqrt((double)v.z * v.z + (double)v.w * v.w);
-                *reinterpret_cast<float2 *>(Xs + 2 * i) = make_float2(m0, m1);
-                if (mg) *reinterpret_cast<float2 *>(mg + 2 * i) = make_float2(m0, m1);
-            }
-        } else {
-            for (int i = tid; i < n; i += DET_NT) {
-                const float2 v = p[i];
-                const float m = (float)sqrt((double)v.x * v.x + (double)v.y * v.y);
-                Xs[i] = m;
-                if (mg) mg[i] = m;
-            }
+    constexpr int NW = DET_NT / 64;
+    // the cells of the wave's next detection travel while it works on this one
+    auto fetch = [&](int det) {
+        float2 v = make_float2(0.f, 0.f);
+        if (det < n_det && mine) {
+            const long slot = f * a.cap + det;
+            v = plane[(long)a.dets[slot * 2] * C + a.dets[slot * 2 + 1]];
         }
+        return v;
+    };
+    float2 nxt = fetch(wave);
+    for (int det = wave; det < n_det; det += NW) {
+        const float2 xl = nxt;
+        nxt = fetch(det + NW);
+        const long slot = f * a.cap + det;
+        if (n_az) detect_argmax_lanes(a, tw, xl, l1v, 0, n_az, a.shift_az, a.az_idx, a.rf_az, slot, lane, 0);
+        if (n_el) detect_argmax_lanes(a, tw, xl, l1v, DET_LIST2, n_el, a.shift_el, a.el_idx, a.rf_el, slot, lane, REFINE_SECOND);
     }
-    __syncthreads();
+}
 
-    const int hr = a.tr + a.gr, hd = a.td + a.gd;
-    const int lane = tid & 63;
-    if (!degenerate && S > 2 * hr && C > 2 * hd) {
-        const double inv_n = 1.0 / (double)a.n_train, alpha = a.scale, band0 = (1.0 + fabs(alpha)) * Bf;
+// LDS of k_detect_screen: float32 plane, two float32 band buffers, bit mask, 96 ints, W_A^m table
+inline size_t detect_tail_lds(int words, int A) { return (((size_t)words * 4 + 15) & ~(size_t)15) + 96 * 4 + (size_t)A * 8; }
+inline size_t detect_screen_lds(int S, int C, int band_rows, int band_pitch, int A) {
+    const size_t n = (size_t)S * C, words = (n + 31) / 32;
+    return ((n * 4 + 15) & ~(size_t)15) + 2 * (((size_t)band_rows * band_pitch * 4 + 15) & ~(size_t)15) + detect_tail_lds((int)words, A);
+}
+
+// CFAR decision of every cell of the frame, band by band (run-time window, one cell per thread and pass): column sums
+// over the training / guard rows of the window into Vt / Vg, then the row-wise combination, the band test, detection bits
+// into `bits` and undecided cells into the global list (ws[44] / ws[45] = has undecided cells / list overflow).
+__device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const float *Xs, float *Vt, float *Vg, unsigned *bits,
+                                              int *ws, double Bf) {
+    const int S = a.S, C = a.C, tid = threadIdx.x, lane = tid & 63;
+    const int tr = a.tr, td = a.td, gr = a.gr, gd = a.gd, hr = tr + gr, hd = td + gd;
+    {
+        const float inv_n = (float)(1.0 / (double)a.n_train);
+        const double alpha = a.scale, band0 = (1.0 + fabs(alpha)) * Bf;
+        // cell i = tid, tid + NT, ... of a band as (row rr, column c) without a division per cell
+        const int rr_t = tid / C, c_t = tid - rr_t * C, dq = DET_NT / C, dm = DET_NT - dq * C;
+        const int g_lo = tr, g_hi = tr + 2 * gr;                // guard rows / columns inside the window
+        const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
+        const int gc_lo = td, gc_hi = td + 2 * gd;
         for (int r0 = hr; r0 < S - hr; r0 += a.band_rows) {
             const int nb = min(a.band_rows, S - hr - r0), cells = nb * C;
-            // column sums over the window rows (Vw) and over the guard rows (Vg), every column
-            for (int i = tid; i < cells; i += DET_NT) {
-                const int rr = i / C, c = i - rr * C;
-                const float *col = Xs + (r0 + rr - hr) * C + c;
-                double w = 0.0, g = 0.0;
-                for (int dr = 0; dr <= 2 * hr; ++dr) {
-                    const double v = (double)col[dr * C];
-                    w += v;
-                    if (dr >= a.tr && dr <= a.tr + 2 * a.gr) g += v;
+            {
+                int rr = rr_t, c = c_t;
+                for (int i = tid; i < cells; i += DET_NT) {
+                    const float *col = Xs + (r0 + rr - hr) * C + c;
+                    float t = 0.f, g = 0.f;
+                    for (int dr = 0; dr < g_lo; ++dr) t += col[dr * C];
+                    for (int dr = g_lo; dr <= g_hi; ++dr) g += col[dr * C];
+                    for (int dr = g_hi + 1; dr < Wr; ++dr) t += col[dr * C];
+                    Vt[i] = t;
+                    Vg[i] = g;
+                    c += dm;
+                    rr += dq;
+                    if (c >= C) {
+                        c -= C;
+                        ++rr;
+                    }
                 }
-                Vw[i] = w;
-                Vg[i] = g;
             }
             __syncthreads();
+            int rr = rr_t, c = c_t;
             for (int i0 = tid - lane; i0 < cells; i0 += DET_NT) {        // wave-uniform trip count (ballot below)
                 const int i = i0 + lane;
                 bool det = false, unc = false;
-                int r = 0, c = 0;
-                if (i < cells) {
-                    const int rr = i / C;
-                    c = i - rr * C;
-                    r = r0 + rr;
-                    if (c >= hd && c < C - hd) {
-                        double tot = 0.0;
-                        const double *pw = Vw + rr * C + c - hd;
-                        for (int dc = 0; dc <= 2 * hd; ++dc) tot += pw[dc];
-                        const double *pg = Vg + rr * C + c - a.gd;
-                        for (int dc = 0; dc <= 2 * a.gd; ++dc) tot -= pg[dc];
-                        const double X = (double)Xs[r * C + c], T = alpha * (tot * inv_n);
-                        const double d = X - T, band = band0 + 1.0e-7 * (X + fabs(T));
-                        det = d > band;
-                        unc = !det && !(d <= -band);
-                    }
+                const int r = r0 + rr;
+                if (i < cells && c >= hd && c < C - hd) {
+                    // training cells = training rows of every window column + guard rows of the columns outside the guard
+                    const float *pt = Vt + i - hd, *pg = Vg + i - hd;
+                    float tot = 0.f;
+                    for (int dc = 0; dc < gc_lo; ++dc) tot += pt[dc] + pg[dc];
+                    for (int dc = gc_lo; dc <= gc_hi; ++dc) tot += pt[dc];
+                    for (int dc = gc_hi + 1; dc < Wd; ++dc) tot += pt[dc] + pg[dc];
+                    const double X = (double)Xs[r * C + c], T = alpha * (double)(tot * inv_n);
+                    const double d = X - T, band = band0 + 3.0e-6 * (X + fabs(T));
+                    det = d > band;
+                    unc = !det && !(d <= -band);
                 }
                 const unsigned long long m = __ballot(det);
                 if (m && lane == 0) {
@@ -312,11 +399,189 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
                     } else
                         ws[45] = 1;
                 }
+                c += dm;
+                rr += dq;
+                if (c >= C) {
+                    c -= C;
+                    ++rr;
+                }
             }
             __syncthreads();
         }
     }
+}
+
+// The same with the window a compile-time constant.  The one-cell-per-thread form reads 13 + 21 LDS words per cell and is
+// bound by the LDS pipe (37 k clocks per 256 x 128 plane); here a thread owns FOUR consecutive rows of a column in the
+// first pass (WR + 3 reads for 4 column sums) and FOUR consecutive columns of a row in the second: its WD + 3 column sums
+// of either kind arrive as aligned 16-byte reads (consecutive lanes read consecutive 16 bytes: no bank conflicts; four
+// 4-byte reads at a 16-byte lane stride were 8-way conflicts and slower than the simple form).  Column c of a band row
+// sits at float offset HD + 4 + c of a row of pitch P (a multiple of 4): the read of cell group c0 = 4 g starts at
+// 4 g + 4, and reads past the row ends land in the padding (read, never used).  All sums still add non-negative numbers
+// only (no sliding differences).
+constexpr int det_band_pitch(int C, int hd) { return (C + 2 * hd + 4 + 4 + 3) / 4 * 4; }
+template <int TR, int TD, int GR, int GD>
+__device__ __forceinline__ void cfar_bands_ct(const DetectArgs &a, long f, const float *Xs, float *Vt, float *Vg, unsigned *bits,
+                                              int *ws, double Bf) {
+    constexpr int HR = TR + GR, HD = TD + GD, WR = 2 * HR + 1, WD = 2 * HD + 1, R = 4, OFF = HD + 4, NQ = (WD + R - 1 + 3) / 4;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int S = a.S, C = a.C, tid = threadIdx.x, P = a.band_pitch, cg_n = (C + R - 1) / R;
+    // the test itself in float32: alpha / N and the band are rounded once (and the band widened by 1e-6 for it), the
+    // product and the difference add two more roundings of T -- all inside the 3e-6 (X + |T|) term
+    const float alpha_n = (float)(a.scale / (double)a.n_train), band0 = (float)((1.0 + fabs(a.scale)) * Bf * 1.000001);
+    for (int r0 = HR; r0 < S - HR; r0 += a.band_rows) {
+        const int nb = min(a.band_rows, S - HR - r0);
+        for (int i = tid; i < ((nb + R - 1) / R) * C; i += DET_NT) {
+            const int rg = i / C, c = i - rg * C, top = r0 + R * rg - HR;       // first plane row this thread reads
+            const int last = S - 1 - top;                                       // rows of a ragged last group: re-read, unused
+            const float *col = Xs + top * C + c;
+            float v[WR + R - 1];
+#pragma unroll
+            for (int dr = 0; dr < WR + R - 1; ++dr) v[dr] = col[min(dr, last) * C];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                float t = 0.f, g = 0.f;
+#pragma unroll
+                for (int dr = 0; dr < WR; ++dr) {
+                    if (dr >= TR && dr <= TR + 2 * GR) g += v[j + dr];
+                    else t += v[j + dr];
+                }
+                Vt[(R * rg + j) * P + OFF + c] = t;
+                Vg[(R * rg + j) * P + OFF + c] = g;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nb * cg_n; i += DET_NT) {
+            const int rr = i / cg_n, c0 = R * (i - rr * cg_n), r = r0 + rr;
+            const f4 *pt = reinterpret_cast<const f4 *>(Vt + rr * P + OFF + c0 - HD);       // float offset 4 g + 4: aligned
+            const f4 *pg = reinterpret_cast<const f4 *>(Vg + rr * P + OFF + c0 - HD);
+            f4 qt[NQ], qg[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                qt[q] = pt[q];
+                qg[q] = pg[q];
+            }
+            float x[R];
+            if ((C & 3) == 0) {                 // one aligned 16-byte read (four 4-byte reads at this lane stride conflict)
+                const f4 q = *reinterpret_cast<const f4 *>(Xs + r * C + c0);
+#pragma unroll
+                for (int j = 0; j < R; ++j) x[j] = q[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; ++j) x[j] = c0 + j < C ? Xs[r * C + c0 + j] : 0.f;
+            }
+            unsigned nib = 0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int c = c0 + j;
+                // training cells = training rows of every window column + guard rows of the columns outside the guard
+                float tot = 0.f;
+#pragma unroll
+                for (int dc = 0; dc < WD; ++dc) {
+                    const int e = j + dc;
+                    tot += (dc < TD || dc > TD + 2 * GD) ? qt[e / 4][e % 4] + qg[e / 4][e % 4] : qt[e / 4][e % 4];
+                }
+                if (c >= HD && c < C - HD) {
+                    const float X = x[j], T = alpha_n * tot;
+                    const float d = X - T, band = band0 + 3.0e-6f * (X + fabsf(T));
+                    const bool det = d > band;
+                    if (det) nib |= 1u << j;
+                    else if (!(d <= -band)) {
+                        const int pos = atomicAdd(a.ctl + DCTL_CELLS, 1);
+                        if (pos < a.cell_cap) {
+                            a.cells[2 * pos] = (int)f;
+                            a.cells[2 * pos + 1] = r * C + c;
+                            ws[44] = 1;
+                        } else
+                            ws[45] = 1;
+                    }
+                }
+            }
+            if (nib) {
+                const long b0 = (long)r * C + c0;
+                const unsigned long long m = (unsigned long long)nib << (b0 & 31);
+                atomicOr(&bits[b0 >> 5], (unsigned)m);
+                if (m >> 32) atomicOr(&bits[(b0 >> 5) + 1], (unsigned)(m >> 32));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// TR, TD, GR, GD >= 0: the window is a compile-time constant (every loop over it unrolls: all of a cell's LDS reads are
+// issued before the first add); -1: taken from the arguments at run time.
+template <int TR, int TD, int GR, int GD>
+__global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
+    constexpr bool CT = TR >= 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = a.S, C = a.C, n = S * C, tid = threadIdx.x;
+    const long f = blockIdx.x;
+    float *Xs = reinterpret_cast<float *>(smem);
+    size_t off = ((size_t)n * 4 + 15) & ~(size_t)15;
+    const size_t band_bytes = ((size_t)a.band_rows * a.band_pitch * 4 + 15) & ~(size_t)15;
+    float *Vt = reinterpret_cast<float *>(smem + off);      // column sums over the training rows of the window
+    float *Vg = reinterpret_cast<float *>(smem + off + band_bytes);      // ... over its guard rows
+    off += 2 * band_bytes;
+    unsigned *bits = reinterpret_cast<unsigned *>(smem + off);
+    off += ((size_t)a.words * 4 + 15) & ~(size_t)15;
+    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, [48, 80) antennas
+    float2 *tw = reinterpret_cast<float2 *>(smem + off + 96 * 4);
+    det_mark(a, 0);
+    if (tid < 2) ws[44 + tid] = 0;
+    detect_ant_table(a, ws + 48);
+    for (int w = tid; w < a.words; w += DET_NT) bits[w] = 0u;
+    for (int i = tid; i < a.A; i += DET_NT) tw[i] = a.twA[i];
+
+    // error band scale; 1.0001 covers the float32 summation of the L1 norm itself
+    const double Bf = (double)a.k_fft * (double)a.l1[f * a.V] * 1.0001;
+    // NaN / inf samples in antenna 0, or a scale at which float32 squares over- / underflow (an all-zero plane is fine)
+    const float l1v = a.l1[f * a.V];
+    const bool degenerate = !(l1v == 0.f || (l1v >= 1e-10f && l1v <= 1e18f));
+    // |RD| of antenna 0 in float32
+    {
+        const float2 *p = a.rd + f * a.V * n;
+        float *mg = a.mag32 ? a.mag32 + f * n : nullptr;
+        if ((n & 1) == 0) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 *p4 = reinterpret_cast<const f4 *>(p);
+            constexpr int U = 16;                           // loads in flight per thread (the whole 256 x 128 plane)
+            for (int i0 = tid; i0 < n / 2; i0 += DET_NT * U) {
+                f4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * DET_NT;
+                    v[u] = i < n / 2 ? p4[i] : f4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * DET_NT;
+                    if (i < n / 2) {
+                        const float m0 = __fsqrt_rn(fmaf(v[u].x, v[u].x, v[u].y * v[u].y));
+                        const float m1 = __fsqrt_rn(fmaf(v[u].z, v[u].z, v[u].w * v[u].w));
+                        *reinterpret_cast<float2 *>(Xs + 2 * i) = make_float2(m0, m1);
+                        if (mg) *reinterpret_cast<float2 *>(mg + 2 * i) = make_float2(m0, m1);
+                    }
+                }
+            }
+        } else {
+            for (int i = tid; i < n; i += DET_NT) {
+                const float2 v = p[i];
+                const float m = __fsqrt_rn(fmaf(v.x, v.x, v.y * v.y));
+                Xs[i] = m;
+                if (mg) mg[i] = m;
+            }
+        }
+    }
     __syncthreads();
+    det_mark(a, 1);
+
+    const int hr = CT ? TR + GR : a.tr + a.gr, hd = CT ? TD + GD : a.td + a.gd;
+    if (!degenerate && S > 2 * hr && C > 2 * hd) {
+        if constexpr (CT) cfar_bands_ct<TR, TD, GR, GD>(a, f, Xs, Vt, Vg, bits, ws, Bf);
+        else cfar_bands_rt(a, f, Xs, Vt, Vg, bits, ws, Bf);
+    }
+    __syncthreads();
+    det_mark(a, 2);
     if (degenerate || ws[45]) {                  // the float64 path decides this frame
         if (tid == 0) {
             a.counts[f] = -1;
@@ -329,21 +594,25 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
         if (tid == 0) a.flag_frames[atomicAdd(a.ctl + DCTL_FLAG_FRAMES, 1)] = (int)f;
         return;
     }
-    detect_finish(a, f, bits, ws);
+    detect_finish(a, f, bits, ws, tw);
+    det_mark(a, 4);
 }
 
 // Frames whose masks were completed by k_cfar_cell_exact: compaction + argmax.  Persistent over the flagged list.
 __global__ __launch_bounds__(DET_NT) void k_detect_finish(DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned *bits = reinterpret_cast<unsigned *>(smem);
-    int *ws = reinterpret_cast<int *>(smem + (((size_t)a.words * 4 + 15) & ~(size_t)15));
+    const size_t off = ((size_t)a.words * 4 + 15) & ~(size_t)15;
+    int *ws = reinterpret_cast<int *>(smem + off);
+    float2 *tw = reinterpret_cast<float2 *>(smem + off + 96 * 4);
     const int n = a.ctl[DCTL_FLAG_FRAMES];
     detect_ant_table(a, ws + 48);
+    for (int i = threadIdx.x; i < a.A; i += DET_NT) tw[i] = a.twA[i];
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
         const long f = a.flag_frames[e];
         for (int w = threadIdx.x; w < a.words; w += DET_NT) bits[w] = a.bits[f * a.words + w];
         __syncthreads();
-        detect_finish(a, f, bits, ws);
+        detect_finish(a, f, bits, ws, tw);
         __syncthreads();
     }
 }
@@ -363,66 +632,134 @@ struct CellExactArgs {
     double scale;
     const double *ws, *wc;
     const cplx<double> *twS, *twC;
+    long long *clk;            // diagnostics (MMW_PHASE_CLOCKS=1)
 };
 
-inline size_t cell_exact_lds(int C, int Wr, int Wd) { return (size_t)Wr * C * 16 + (size_t)Wr * Wd * 8 + 64; }
+constexpr int CE_NT = 512, CE_RPT = 7, CE_SG = 8;      // threads per cell (256 registers each); range rows per pass; sample groups per chirp
+inline size_t cell_exact_lds(int S, int C, int Wr, int Wd) {
+    return ((size_t)Wr * C + S + C) * 16 + ((size_t)S + C + (size_t)Wr * Wd + 8) * 8;
+}
 
-__global__ __launch_bounds__(256) void k_cfar_cell_exact(CellExactArgs a) {
+// One workgroup per undecided cell; everything on its critical path is spread over the 512 threads (180 such cells per
+// 1250-frame batch run side by side, so the kernel lasts as long as ONE cell takes):
+//   step A  lane = (chirp, sample group): a thread asks for its 1 / CE_SG share of the chirp's samples in one go (cold HBM
+//           lines), accumulates CE_RPT range rows at a time, the sample groups are added up by lane shuffles (fixed order);
+//   step B  four lanes per window cell share its Doppler sum;  the CA sum / OS rank run on the whole workgroup.
+__global__ __launch_bounds__(CE_NT) void k_cfar_cell_exact(CellExactArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = a.S, C = a.C, hr = a.tr + a.gr, hd = a.td + a.gd, Wr = 2 * hr + 1, Wd = 2 * hd + 1, tid = threadIdx.x;
-    cplx<double> *Y = reinterpret_cast<cplx<double> *>(smem);
-    double *M = reinterpret_cast<double *>(smem + (size_t)Wr * C * 16);
-    double *res = M + Wr * Wd;          // [0] OS threshold cell
+    cplx<double> *Y = reinterpret_cast<cplx<double> *>(smem);        // [Wr][C]
+    cplx<double> *twS = Y + (size_t)Wr * C, *twC = twS + S;          // W_S^m, W_C^m
+    double *wsl = reinterpret_cast<double *>(twC + C), *wcl = wsl + S, *M = wcl + C, *res = M + Wr * Wd;
+    auto mark = [&](int i) {
+        if (a.clk && blockIdx.x == 0 && tid == 0) a.clk[i] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    mark(0);
     int n = *a.n_cells;
     if (n > a.cell_cap) n = a.cell_cap;
+    if ((int)blockIdx.x >= n) return;
+    for (int i = tid; i < S; i += CE_NT) {
+        twS[i] = a.twS[i];
+        wsl[i] = a.ws[i];
+    }
+    for (int i = tid; i < C; i += CE_NT) {
+        twC[i] = a.twC[i];
+        wcl[i] = a.wc[i];
+    }
+    __syncthreads();
+    mark(1);
+    // sample group sg of a chirp takes the samples s = sg, sg + CE_SG, ...: neighbouring lanes then read W_S^(k s) entries
+    // k apart (spread over the LDS banks for most k; with contiguous sample blocks all eight sat in one bank and the reads
+    // were 290 k of this kernel's 320 k clocks)
+    const int sg = tid & (CE_SG - 1);
+    auto guard = [&](int o) {
+        const int row = o / Wd, j = o - row * Wd;
+        return row >= a.tr && row <= a.tr + 2 * a.gr && j >= a.td && j <= a.td + 2 * a.gd;
+    };
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
         const long f = a.cells[2 * e];
         const int cell = a.cells[2 * e + 1], r = cell / C, c = cell - r * C;
         const float2 *x = a.cubes + f * a.V * S * C;                 // antenna 0
-        for (int o = tid; o < Wr * C; o += 256) {
-            const int row = o / C, ch = o - row * C;
-            int k = r - hr + row;                                   // range bin (inside the plane: valid region)
-            cplx<double> acc = cplx<double>{0.0, 0.0};
-            int idx = 0;
-            for (int s = 0; s < S; ++s) {
-                const float2 v = x[(long)s * C + ch];
-                const double w = a.ws[s];
-                acc = acc + cmul(cplx<double>{(double)v.x * w, (double)v.y * w}, a.twS[idx]);
-                idx += k;
-                if (idx >= S) idx -= S;
+        for (int ch0 = 0; ch0 < C; ch0 += CE_NT / CE_SG) {           // (uniform trip count: shuffles inside)
+            const int ch = ch0 + tid / CE_SG;
+            const bool live = ch < C;
+            for (int row0 = 0; row0 < Wr; row0 += CE_RPT) {
+                cplx<double> acc[CE_RPT];
+                int idx[CE_RPT], k[CE_RPT];
+#pragma unroll
+                for (int j = 0; j < CE_RPT; ++j) {
+                    acc[j] = cplx<double>{0.0, 0.0};
+                    k[j] = row0 + j < Wr ? r - hr + row0 + j : 0;    // range bin (inside the plane: valid region)
+                    idx[j] = (int)(((long)k[j] * sg) % S);
+                    k[j] = (int)(((long)k[j] * CE_SG) % S);           // twiddle-index step between a thread's samples
+                }
+                constexpr int U = 16;            // cold HBM lines: ask for 16 samples before using the first
+                for (int s0 = sg; s0 < S; s0 += U * CE_SG) {
+                    float2 xv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)       // (unconditional, clamped: a guarded load is followed by its own wait)
+                        xv[u] = x[(long)min(s0 + u * CE_SG, S - 1) * C + (live ? ch : 0)];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int sx = s0 + u * CE_SG;
+                        if (live && sx < S) {
+                            const double w = wsl[sx];
+                            const cplx<double> xw = cplx<double>{(double)xv[u].x * w, (double)xv[u].y * w};
+#pragma unroll
+                            for (int j = 0; j < CE_RPT; ++j) {
+                                acc[j] = acc[j] + cmul(xw, twS[idx[j]]);
+                                idx[j] += k[j];
+                                if (idx[j] >= S) idx[j] -= S;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < CE_RPT; ++j) {
+                    for (int d = 1; d < CE_SG; d <<= 1) {             // the sample groups of a chirp sit in adjacent lanes
+                        acc[j].x += __shfl_xor(acc[j].x, d, 64);
+                        acc[j].y += __shfl_xor(acc[j].y, d, 64);
+                    }
+                    if (live && sg == 0 && row0 + j < Wr) Y[(row0 + j) * C + ch] = acc[j] * wcl[ch];
+                }
             }
-            Y[o] = acc * a.wc[ch];
         }
         __syncthreads();
-        for (int o = tid; o < Wr * Wd; o += 256) {
-            const int row = o / Wd, j = o - row * Wd;
-            int k = c - hd + j - C / 2;                              // np.fft.fftshift: out[i] = X[(i - C//2) mod C]
-            if (k < 0) k += C;
+        mark(2);
+        for (int o0 = 0; o0 < Wr * Wd; o0 += CE_NT / 4) {            // four lanes per window cell
+            const int o = o0 + tid / 4, q = tid & 3;
             cplx<double> acc = cplx<double>{0.0, 0.0};
-            int idx = 0;
-            for (int ch = 0; ch < C; ++ch) {
-                acc = acc + cmul(Y[row * C + ch], a.twC[idx]);
-                idx += k;
-                if (idx >= C) idx -= C;
+            if (o < Wr * Wd) {
+                const int row = o / Wd, j = o - row * Wd;
+                int kd = c - hd + j - C / 2;                         // np.fft.fftshift: out[i] = X[(i - C//2) mod C]
+                if (kd < 0) kd += C;
+                const int per_c = (C + 3) / 4, c_lo = q * per_c, c_hi = min(C, c_lo + per_c);
+                int idx = (int)(((long)kd * c_lo) % C);
+                for (int ch = c_lo; ch < c_hi; ++ch) {
+                    acc = acc + cmul(Y[row * C + ch], twC[idx]);
+                    idx += kd;
+                    if (idx >= C) idx -= C;
+                }
             }
-            M[o] = hypot(acc.x, acc.y);
+            for (int d = 1; d < 4; d <<= 1) {
+                acc.x += __shfl_xor(acc.x, d, 64);
+                acc.y += __shfl_xor(acc.y, d, 64);
+            }
+            if (o < Wr * Wd && q == 0) M[o] = hypot(acc.x, acc.y);
         }
         __syncthreads();
-        auto guard = [&](int o) {
-            const int row = o / Wd, j = o - row * Wd;
-            return row >= a.tr && row <= a.tr + 2 * a.gr && j >= a.td && j <= a.td + 2 * a.gd;
-        };
-        bool det = false;
+        mark(3);
         const double X = M[hr * Wd + hd];
         if (a.kind == MMW_CFAR_CA) {
-            if (tid == 0) {
+            if (tid < 64) {                     // sum of the training cells (any order: float64, ~1e-16 of the threshold)
                 double tot = 0.0;
-                for (int o = 0; o < Wr * Wd; ++o) tot += guard(o) ? 0.0 : M[o];
-                det = X > a.scale * (tot / (double)a.n_train);
+                for (int o = tid; o < Wr * Wd; o += 64) tot += guard(o) ? 0.0 : M[o];
+                for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                if (tid == 0) res[0] = tot / (double)a.n_train;
             }
         } else {
             // k-th smallest training cell by rank counting (ties broken by position, as a stable sort would)
-            for (int o = tid; o < Wr * Wd; o += 256) {
+            for (int o = tid; o < Wr * Wd; o += CE_NT) {
                 if (guard(o)) continue;
                 const double v = M[o];
                 int rank = 0;
@@ -433,11 +770,11 @@ __global__ __launch_bounds__(256) void k_cfar_cell_exact(CellExactArgs a) {
                 }
                 if (rank == a.k_rank - 1) res[0] = v;
             }
-            __syncthreads();
-            if (tid == 0) det = X > a.scale * res[0];
         }
-        if (tid == 0 && det) atomicOr(a.bits + f * a.words + (cell >> 5), 1u << (cell & 31));
         __syncthreads();
+        if (tid == 0 && X > a.scale * res[0]) atomicOr(a.bits + f * a.words + (cell >> 5), 1u << (cell & 31));
+        __syncthreads();
+        mark(4);
     }
 }
 

@@ -352,7 +352,9 @@ __device__ __forceinline__ void argmax_gather(const float2 *rd, long f, int V, i
     sum_abs = 0.f;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        x[i] = (i < ants.n) ? rd[((f * V + ants.idx[i]) * S + r) * C + v] : make_float2(0.f, 0.f);
+        // unconditional (entries of the list past n are antenna 0): a guarded load would be followed by its own wait
+        x[i] = rd[((f * V + ants.idx[i]) * S + r) * C + v];
+        if (i >= ants.n) x[i] = make_float2(0.f, 0.f);
         if (i < ants.n) sum_abs += fabsf(x[i].x) + fabsf(x[i].y);
     }
 }
@@ -486,43 +488,83 @@ __global__ __launch_bounds__(256) void k_argmax64_cells(const cplx<double> *cell
 // slices, one workgroup each (a single workgroup per detection is latency-bound on its 32 trips to cold HBM lines):
 //   k_argmax_refine_part   partial[e][part][i] for the first `n_split` flagged detections; a thread walks cells
 //                          base + tid, + 256, ... keeping (s, c) and the two twiddle indices up to date incrementally and
-//                          uses each cell's window * phase factor for all antennas of the list;
+//                          uses each cell's window * phase factor for all antennas of the list (phase tables: see
+//                          refine_phases);
 //   k_argmax_refine_finish adds the slices in a fixed order and runs the float64 argmax (one wave per detection);
 //   k_argmax_refine_whole  whole planes in one workgroup: the (never yet seen) overflow beyond n_split detections.
+// One flagged list may serve TWO antenna lists (mmw_detect_points: azimuth and elevation): an entry with bit 31 set
+// belongs to the second (ants2 / shift2 / out_idx2).
 #ifndef MMW_REFINE_PARTS
 #define MMW_REFINE_PARTS 16
 #endif
-constexpr int REFINE_PARTS = MMW_REFINE_PARTS, REFINE_NA = 8;
+constexpr int REFINE_PARTS = MMW_REFINE_PARTS, REFINE_NA = 4;      // NA = 8 took 228 VGPRs: two workgroups per CU
+constexpr int REFINE_SECOND = (int)0x80000000;
 
 struct RefineArgs {
     const float2 *cubes;
     const int32_t *dets;
     const int *n_flag, *list;
     int list_cap;
-    int32_t *out_idx;
+    int32_t *out_idx, *out_idx2;
     int V, S, C, cap;
-    AntList ants;
-    int A, shift;
+    AntList ants, ants2;
+    int A, shift, shift2;
     const double *ws, *wc;
     const cplx<double> *twS, *twC, *twA;
-    cplx<double> *partial;      // [n_split][REFINE_PARTS][ants.n]
+    cplx<double> *partial;      // [n_split][parts][max(ants.n, ants2.n)]
     int n_split;
+    int parts;                  // slices a plane sum is cut into (<= REFINE_PARTS): few when many detections are expected
 };
 
-// sum over cells [cell_lo, cell_hi) of plane (f, ant) * window * phase, for antennas a0 .. a0 + NA - 1 of the list
+// Per flagged detection the factor of cell (s, c) splits into a range part and a Doppler part,
+//   w_s(s) W_S^(r s)  *  w_c(c) W_C^(kd c),
+// built once per task into two LDS tables (phS[S], phC[C]); the plane loop then reads phS[s] (one address per wave
+// row: broadcast) and phC[c] (consecutive lanes, consecutive entries).  Gathering W_C^(kd c mod C) per cell instead put
+// up to 64 lanes on one LDS bank (kd a multiple of 32) and the slowest task set the kernel's time.
+inline size_t refine_tabs_lds(int S, int C) { return ((size_t)S + C) * 16 + 2 * MAX_ANT * sizeof(int); }
+
+struct RefineTabs {
+    cplx<double> *phS, *phC;
+    int *ant;                   // ant[0..32) first list, ant[32..64) second
+};
+__device__ __forceinline__ RefineTabs refine_tabs(const RefineArgs &a, char *smem, int tid) {
+    RefineTabs t;
+    t.phS = reinterpret_cast<cplx<double> *>(smem);
+    t.phC = t.phS + a.S;
+    t.ant = reinterpret_cast<int *>(t.phC + a.C);
+    if (tid == 0) {
+        static_for<MAX_ANT>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            t.ant[i] = a.ants.idx[i];
+            t.ant[MAX_ANT + i] = a.ants2.idx[i];
+        });
+    }
+    return t;
+}
+// (every thread of the workgroup; ends with a barrier)
+__device__ __forceinline__ void refine_phases(const RefineArgs &a, const RefineTabs &t, int r, int kd, int tid, int nt) {
+    __syncthreads();            // the previous task's readers are done
+    for (int s = tid; s < a.S; s += nt) t.phS[s] = a.twS[(int)(((long)r * s) % a.S)] * a.ws[s];
+    for (int c = tid; c < a.C; c += nt) t.phC[c] = a.twC[(int)(((long)kd * c) % a.C)] * a.wc[c];
+    __syncthreads();
+}
+
+// sum over cells [cell_lo, cell_hi) of plane (f, ant[a0 + i]) * window * phase, i < NA (antennas beyond n_ant: zero)
 template <int NA>
-__device__ __forceinline__ void refine_accumulate(const RefineArgs &a, int f, int r, int kd, int a0, long cell_lo, long cell_hi,
-                                                  int tid, cplx<double> (&acc)[NA]) {
+__device__ __forceinline__ void refine_accumulate(const RefineArgs &a, const RefineTabs &t, const int *ant, int n_ant, int f, int a0,
+                                                  long cell_lo, long cell_hi, int tid, cplx<double> (&acc)[NA]) {
     const int S = a.S, C = a.C;
     const long plane_cells = (long)S * C;
     const int ds = 256 / C, dc = 256 - ds * C;         // advancing a cell index by 256: c += dc (carry into s), s += ds
-    const int is_ds = (int)(((long)r * ds) % S), is_1 = r % S, ic_dc = (int)(((long)kd * dc) % C);
+    const float2 *plane[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = cplx<double>{0.0, 0.0};
+    for (int i = 0; i < NA; ++i) {
+        acc[i] = cplx<double>{0.0, 0.0};
+        plane[i] = a.cubes + ((long)f * a.V + (a0 + i < n_ant ? ant[a0 + i] : 0)) * plane_cells;
+    }
     const long first = cell_lo + tid;
     int s = (int)(first / C), c = (int)(first - (long)s * C);
     if (s >= S) s = 0;
-    int is = (int)(((long)r * s) % S), ic = (int)(((long)kd * c) % C);
     constexpr int U = 4;        // four cells per trip: all of their (cold) samples are requested before any is used
     for (long cell0 = first; cell0 < cell_hi; cell0 += 256 * U) {
         float2 xv[U][NA];
@@ -530,31 +572,25 @@ __device__ __forceinline__ void refine_accumulate(const RefineArgs &a, int f, in
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
+                // unconditional, clamped (a guarded load is followed by its own wait: every one of these 16 loads cost a
+                // full trip to HBM); cells past the end are not used, antennas past the list read plane 0 and are dropped
                 const long cell = cell0 + 256 * u;
-                xv[u][i] = (a0 + i < a.ants.n && cell < cell_hi)
-                               ? a.cubes[((long)f * a.V + a.ants.idx[a0 + i]) * plane_cells + cell] : make_float2(0.f, 0.f);
+                xv[u][i] = plane[i][cell < cell_hi ? cell : cell_hi - 1];
             }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (cell0 + 256 * u < cell_hi) {
-                const double w = a.ws[s] * a.wc[c];
-                const cplx<double> ph = cmul(a.twS[is], a.twC[ic]) * w;
+                const cplx<double> ph = cmul(t.phS[s], t.phC[c]);
 #pragma unroll
                 for (int i = 0; i < NA; ++i) acc[i] = acc[i] + cmul(cplx<double>{(double)xv[u][i].x, (double)xv[u][i].y}, ph);
             }
             c += dc;
-            ic += ic_dc;
-            if (ic >= C) ic -= C;
-            if (c >= C) {               // kd * (c - C) == kd * c (mod C): ic unchanged
+            if (c >= C) {
                 c -= C;
                 ++s;
-                is += is_1;
-                if (is >= S) is -= S;
             }
             s += ds;
-            is += is_ds;
-            if (is >= S) is -= S;
-            if (s >= S) s = is = 0;     // past the plane (guarded above): keep the table indices in range
+            if (s >= S) s = 0;          // past the plane (guarded above): keep the table index in range
         }
     }
 }
@@ -576,32 +612,46 @@ __device__ __forceinline__ void refine_reduce(cplx<double> (&acc)[NA], cplx<doub
     __syncthreads();
 }
 
-__device__ __forceinline__ void refine_entry(const RefineArgs &a, int e, int *f, int *det, int *r, int *kd) {
-    const int id = a.list[e];
-    *f = id / a.cap;
-    *det = id - *f * a.cap;
-    *r = a.dets[((long)*f * a.cap + *det) * 2];
-    int k = a.dets[((long)*f * a.cap + *det) * 2 + 1] - a.C / 2;     // FFT bin behind the fftshifted Doppler index
+struct RefineEntry {
+    int f, det, r, kd, which, n_ant;
+};
+__device__ __forceinline__ RefineEntry refine_entry(const RefineArgs &a, int e) {
+    RefineEntry q;
+    int id = a.list[e];
+    q.which = id < 0 ? 1 : 0;
+    id &= 0x7fffffff;
+    q.n_ant = q.which ? a.ants2.n : a.ants.n;
+    q.f = id / a.cap;
+    q.det = id - q.f * a.cap;
+    q.r = a.dets[((long)q.f * a.cap + q.det) * 2];
+    int k = a.dets[((long)q.f * a.cap + q.det) * 2 + 1] - a.C / 2;     // FFT bin behind the fftshifted Doppler index
     if (k < 0) k += a.C;
-    *kd = k;
+    q.kd = k;
+    return q;
 }
+__device__ __forceinline__ int refine_stride(const RefineArgs &a) { return a.ants.n > a.ants2.n ? a.ants.n : a.ants2.n; }
 
-__global__ __launch_bounds__(256) void k_argmax_refine_part(RefineArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_argmax_refine_part(RefineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ cplx<double> red[4][REFINE_NA];
     int n = *a.n_flag;
     if (n > a.list_cap) n = a.list_cap;
     if (n > a.n_split) n = a.n_split;
+    if ((int)blockIdx.y >= n) return;
     const int part = blockIdx.x, tid = threadIdx.x;
+    const RefineTabs t = refine_tabs(a, smem, tid);
     const long plane_cells = (long)a.S * a.C;
-    const long per = ((plane_cells + REFINE_PARTS - 1) / REFINE_PARTS + 255) / 256 * 256;
+    const long per = ((plane_cells + a.parts - 1) / a.parts + 255) / 256 * 256;
     const long lo = (long)part * per, hi = lo + per < plane_cells ? lo + per : plane_cells;
+    const int stride = refine_stride(a);
     for (int e = blockIdx.y; e < n; e += gridDim.y) {
-        int f, det, r, kd;
-        refine_entry(a, e, &f, &det, &r, &kd);
-        for (int a0 = 0; a0 < a.ants.n; a0 += REFINE_NA) {
+        const RefineEntry q = refine_entry(a, e);
+        refine_phases(a, t, q.r, q.kd, tid, 256);
+        const int *al = t.ant + (q.which ? MAX_ANT : 0);
+        for (int a0 = 0; a0 < q.n_ant; a0 += REFINE_NA) {
             cplx<double> acc[REFINE_NA];
-            refine_accumulate<REFINE_NA>(a, f, r, kd, a0, lo < hi ? lo : hi, hi, tid, acc);
-            refine_reduce<REFINE_NA>(acc, red, tid, a.partial + ((long)e * REFINE_PARTS + part) * a.ants.n + a0, a.ants.n - a0);
+            refine_accumulate<REFINE_NA>(a, t, al, q.n_ant, q.f, a0, lo < hi ? lo : hi, hi, tid, acc);
+            refine_reduce<REFINE_NA>(acc, red, tid, a.partial + ((long)e * a.parts + part) * stride + a0, q.n_ant - a0);
         }
     }
 }
@@ -612,43 +662,48 @@ __global__ __launch_bounds__(256) void k_argmax_refine_finish(RefineArgs a) {
     if (n > a.list_cap) n = a.list_cap;
     if (n > a.n_split) n = a.n_split;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int stride = refine_stride(a);
     for (int e0 = blockIdx.x * 4; e0 < n; e0 += gridDim.x * 4) {
         const int e = e0 + wave;
+        RefineEntry q{};
         if (e < n) {
-            for (int i = lane; i < a.ants.n; i += 64) {
+            q = refine_entry(a, e);
+            for (int i = lane; i < q.n_ant; i += 64) {
                 cplx<double> s = cplx<double>{0.0, 0.0};
-                for (int p = 0; p < REFINE_PARTS; ++p) s = s + a.partial[((long)e * REFINE_PARTS + p) * a.ants.n + i];
+                for (int p = 0; p < a.parts; ++p) s = s + a.partial[((long)e * a.parts + p) * stride + i];
                 X[wave][i] = s;
             }
         }
         __syncthreads();
         if (e < n) {
-            int f, det, r, kd;
-            refine_entry(a, e, &f, &det, &r, &kd);
-            const int idx = argmax64_wave(X[wave], a.ants.n, a.A, a.shift, a.twA, lane);
-            if (lane == 0) a.out_idx[(long)f * a.cap + det] = idx;
+            const int idx = argmax64_wave(X[wave], q.n_ant, a.A, q.which ? a.shift2 : a.shift, a.twA, lane);
+            if (lane == 0) (q.which ? a.out_idx2 : a.out_idx)[(long)q.f * a.cap + q.det] = idx;
         }
         __syncthreads();
     }
 }
 
 __global__ __launch_bounds__(256) void k_argmax_refine_whole(RefineArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ cplx<double> red[4][REFINE_NA];
     __shared__ cplx<double> X[MAX_ANT];
     int n = *a.n_flag;
     if (n > a.list_cap) n = a.list_cap;
     const int tid = threadIdx.x;
+    if (a.n_split + (int)blockIdx.x >= n) return;
+    const RefineTabs t = refine_tabs(a, smem, tid);
     for (int e = a.n_split + blockIdx.x; e < n; e += gridDim.x) {
-        int f, det, r, kd;
-        refine_entry(a, e, &f, &det, &r, &kd);
-        for (int a0 = 0; a0 < a.ants.n; a0 += REFINE_NA) {
+        const RefineEntry q = refine_entry(a, e);
+        refine_phases(a, t, q.r, q.kd, tid, 256);
+        const int *al = t.ant + (q.which ? MAX_ANT : 0);
+        for (int a0 = 0; a0 < q.n_ant; a0 += REFINE_NA) {
             cplx<double> acc[REFINE_NA];
-            refine_accumulate<REFINE_NA>(a, f, r, kd, a0, 0, (long)a.S * a.C, tid, acc);
-            refine_reduce<REFINE_NA>(acc, red, tid, X + a0, a.ants.n - a0);
+            refine_accumulate<REFINE_NA>(a, t, al, q.n_ant, q.f, a0, 0, (long)a.S * a.C, tid, acc);
+            refine_reduce<REFINE_NA>(acc, red, tid, X + a0, q.n_ant - a0);
         }
         if (tid < 64) {
-            const int idx = argmax64_wave(X, a.ants.n, a.A, a.shift, a.twA, tid);
-            if (tid == 0) a.out_idx[(long)f * a.cap + det] = idx;
+            const int idx = argmax64_wave(X, q.n_ant, a.A, q.which ? a.shift2 : a.shift, a.twA, tid);
+            if (tid == 0) (q.which ? a.out_idx2 : a.out_idx)[(long)q.f * a.cap + q.det] = idx;
         }
         __syncthreads();
     }

@@ -1392,18 +1392,34 @@ static int rd_error_ulps(int S, int C) {
 // float64 re-evaluation of the detections k_angle_argmax flagged (ra.n_flag / ra.list): fixed grids, the flagged count
 // stays on the device, workgroups beyond it leave at once.  ra.partial must hold n_split * REFINE_PARTS * ants.n entries.
 static int launch_argmax_refine(mmw_ctx *ctx, const RefineArgs &ra) {
+    const size_t lds = refine_tabs_lds(ra.S, ra.C);
+    MMW_REQUIRE(lds <= 150 * 1024, "plane %d x %d too large for the refinement tables", ra.S, ra.C);
+    if (lds > 48 * 1024) {
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax_refine_part), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax_refine_whole), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (ra.n_split > 0) {
-        const int units = std::min(ra.n_split, std::max(1, tune_int("MMW_REFINE_GRID", 256)));
-        hipLaunchKernelGGL(k_argmax_refine_part, dim3(REFINE_PARTS, units), dim3(256), 0, ctx->stream, ra);
+        const int units = std::min(ra.n_split, std::max(1, tune_int("MMW_REFINE_GRID", 512)));
+        hipLaunchKernelGGL(k_argmax_refine_part, dim3(ra.parts, units), dim3(256), lds, ctx->stream, ra);
         MMW_TRY(check_launch("argmax_refine_part"));
         hipLaunchKernelGGL(k_argmax_refine_finish, dim3(std::min((ra.n_split + 3) / 4, ctx->num_cu)), dim3(256), 0, ctx->stream, ra);
         MMW_TRY(check_launch("argmax_refine_finish"));
     }
     if (ra.list_cap > ra.n_split) {
-        hipLaunchKernelGGL(k_argmax_refine_whole, dim3(ctx->num_cu), dim3(256), 0, ctx->stream, ra);
+        hipLaunchKernelGGL(k_argmax_refine_whole, dim3(ctx->num_cu), dim3(256), lds, ctx->stream, ra);
         MMW_TRY(check_launch("argmax_refine_whole"));
     }
     return MMW_OK;
+}
+
+// Slices per plane sum: a few flagged evaluations per hundred frames are expected, and ~1000 workgroups of the slice
+// kernel are resident at once: 16 slices (latency of the single task), fewer and longer ones for very large batches.
+static int refine_parts(int n_frames) {
+    const int want = tune_int("MMW_REFINE_PARTS_RT", 0);
+    if (want > 0) return std::min(want, (int)REFINE_PARTS);
+    int p = REFINE_PARTS;
+    while (p > 2 && (long)p * n_frames > 60000) p /= 2;
+    return p;
 }
 
 static int fill_refine_args(mmw_ctx *ctx, RefineArgs *ra, int S, int C, int A) {
@@ -1430,6 +1446,9 @@ static int fill_refine_args(mmw_ctx *ctx, RefineArgs *ra, int S, int C, int A) {
 // the antennas' whole planes) from 1.8 % to 0.2 % of the detections; MMW_ARGMAX_BOUND_DIV=1 restores the full bound
 // (the CFAR screening of mmw_detect_points always uses the full bound).
 static float argmax_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 8)); }
+// (mmw_detect_points tests every bin against the winner with the errors of the two treated as what they are -- the same
+//  cell errors seen through two steering vectors -- and flags ~10x fewer detections: it uses the worst-case bound itself)
+static float detect_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 1)); }
 
 int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1, const void *d_rd, const int32_t *d_dets,
                            const int32_t *d_counts, int32_t *d_idx, int n_frames, int V, int S, int C, int cap,
@@ -1473,6 +1492,7 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     ra.shift = shift;
     ra.partial = (cplx<double> *)((char *)ctx->scratch + list_bytes);
     ra.n_split = n_split;
+    ra.parts = refine_parts(n_frames);
     MMW_TRY(launch_argmax_refine(ctx, ra));
     if (h_n_refined) {
         MMW_HIP(hipMemcpyAsync(h_n_refined, d_nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1484,28 +1504,36 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
 // ------------------------------------------------------------------ fused detection + point-cloud indices (mmw_detect.h)
 namespace {
 struct DetectPlan {
-    bool ok;
-    int band_rows, words;
+    bool ok, ct_window;
+    int band_rows, band_pitch, words;
     size_t lds_screen, lds_cell, lds_finish;
 };
-DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, int n_az, int n_el) {
+DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, int n_az, int n_el, int A = 64) {
     DetectPlan p{};
     const long n = (long)S * C;
     const int hr = tr + gr, hd = td + gd;
-    if (kind != MMW_CFAR_CA || n_az > DET_MAX_ANT || n_el > DET_MAX_ANT || n > (1L << 20)) return p;
+    if (kind != MMW_CFAR_CA || n_az > DET_MAX_ANT || n_el > DET_MAX_ANT || n > (1L << 20) || A < 1 || A > 1024) return p;
     if (tune_int("MMW_NO_DETECT_SCREEN", 0)) return p;
     p.words = (int)((n + 31) / 32);
-    const size_t lds_max = 160 * 1024, fixed = detect_screen_lds(S, C, 0);
-    if (fixed + 16 * (size_t)C > lds_max) return p;                   // the float32 plane must fit the LDS
-    int br = (int)((lds_max - fixed) / (16 * (size_t)C));
-    br = std::min(br, std::max(1, S - 2 * hr));
-    int unit = DET_NT;                                                // band cells a multiple of the workgroup size
-    for (int g = C; g % 2 == 0 && unit > 1; g /= 2) unit /= 2;        // unit = DET_NT / gcd(C, DET_NT)
-    if (br >= unit) br -= br % unit;
+    // compile-time windows (the launch below knows the same two): four rows / columns per thread, padded band rows
+    p.ct_window = (tr == 4 && td == 4 && gr == 2 && gd == 2) || (tr == 5 && td == 5 && gr == 3 && gd == 2);
+    p.band_pitch = p.ct_window ? det_band_pitch(C, hd) : C;
+    const size_t lds_max = 160 * 1024, fixed = detect_screen_lds(S, C, 0, 0, A) + 32, row_bytes = 8 * (size_t)p.band_pitch;
+    if (fixed + (p.ct_window ? 4 : 1) * row_bytes > lds_max) return p;      // the float32 plane must fit the LDS
+    int br = (int)((lds_max - fixed) / row_bytes);
+    if (p.ct_window) {
+        br = std::min(br, (std::max(1, S - 2 * hr) + 3) / 4 * 4);
+        br -= br % 4;
+    } else {
+        br = std::min(br, std::max(1, S - 2 * hr));
+        int unit = DET_NT;                                            // band cells a multiple of the workgroup size
+        for (int g = C; g % 2 == 0 && unit > 1; g /= 2) unit /= 2;    // unit = DET_NT / gcd(C, DET_NT)
+        if (br >= unit) br -= br % unit;
+    }
     p.band_rows = br;
-    p.lds_screen = detect_screen_lds(S, C, br);
-    p.lds_cell = cell_exact_lds(C, 2 * hr + 1, 2 * hd + 1);
-    p.lds_finish = (((size_t)p.words * 4 + 15) & ~(size_t)15) + 96 * 4;
+    p.lds_screen = detect_screen_lds(S, C, br, p.band_pitch, A);
+    p.lds_cell = cell_exact_lds(S, C, 2 * hr + 1, 2 * hd + 1);
+    p.lds_finish = detect_tail_lds(p.words, A);
     p.ok = p.lds_cell <= 64 * 1024 && p.lds_finish <= 64 * 1024;
     return p;
 }
@@ -1536,7 +1564,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     MMW_REQUIRE(train_r >= 0 && train_d >= 0 && guard_r >= 0 && guard_d >= 0, "negative window size");
     MMW_REQUIRE(n_az >= 0 && n_el >= 0 && (n_az == 0 || d_az_idx) && (n_el == 0 || d_el_idx), "antenna list without an index buffer");
     MMW_REQUIRE((long)n_frames * std::max(cap, 1) < (1L << 31), "too many detection slots for one call");
-    const DetectPlan plan = detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el);
+    const DetectPlan plan = detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el, A);
     if (!plan.ok)
         return set_error(MMW_ERR_UNSUPPORTED, "mmw_detect_points: no screening kernel for this request (CA-CFAR on planes whose "
                          "float32 magnitudes fit the LDS, <= %d antennas per list): use mmw_detect_batch + mmw_angle_argmax_exact",
@@ -1558,19 +1586,19 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, C, &twC64));
     MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &ws64));
     MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &wc64));
-    // scratch: counters | flagged frames | undecided cells | bit masks | per list: flagged detections + partial sums
+    // scratch: counters | flagged frames | undecided cells | bit masks | flagged argmax evaluations + their partial sums
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const int cell_cap = std::max(4096, 16 * n_frames);
     const int list_cap = n_frames * cap;
     const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));
     const size_t b_ctl = up(DCTL_WORDS * sizeof(int)), b_ff = up((size_t)n_frames * sizeof(int)),
-                 b_cells = up((size_t)cell_cap * 2 * sizeof(int)), b_bits = up((size_t)n_frames * plan.words * sizeof(unsigned)),
-                 b_list = up((size_t)std::max(list_cap, 1) * sizeof(int));
-    const size_t b_part_az = up((size_t)n_split * REFINE_PARTS * std::max(n_az, 1) * sizeof(cplx<double>)),
-                 b_part_el = up((size_t)n_split * REFINE_PARTS * std::max(n_el, 1) * sizeof(cplx<double>));
+                 b_cells = up((size_t)cell_cap * 2 * sizeof(int)), b_bits = up((size_t)n_frames * plan.words * sizeof(unsigned));
+    const int list_cap2 = (int)std::min<long>(2L * list_cap, 0x7fffffffL);      // both lists flag into one
+    const int n_split2 = std::min(list_cap2, n_split);
+    const size_t b_list2 = up((size_t)std::max(list_cap2, 1) * sizeof(int));
+    const size_t b_part = up((size_t)n_split2 * REFINE_PARTS * std::max(std::max(n_az, n_el), 1) * sizeof(cplx<double>));
     size_t total = b_ctl + b_ff + b_cells + b_bits;
-    if (n_az) total += b_list + b_part_az;
-    if (n_el) total += b_list + b_part_el;
+    if (n_az || n_el) total += b_list2 + b_part;
     MMW_TRY(ensure_scratch(ctx, total));
     char *base = (char *)ctx->scratch;
     a.ctl = (int *)base;
@@ -1578,22 +1606,12 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.cells = (int *)(base + b_ctl + b_ff);
     a.bits = (unsigned *)(base + b_ctl + b_ff + b_cells);
     char *next = base + b_ctl + b_ff + b_cells + b_bits;
-    int *list_az = nullptr, *list_el = nullptr;
-    cplx<double> *part_az = nullptr, *part_el = nullptr;
-    if (n_az) {
-        list_az = (int *)next;
-        part_az = (cplx<double> *)(next + b_list);
-        next += b_list + b_part_az;
-    }
-    if (n_el) {
-        list_el = (int *)next;
-        part_el = (cplx<double> *)(next + b_list);
-        next += b_list + b_part_el;
-    }
+    int *list = (n_az || n_el) ? (int *)next : nullptr;
+    cplx<double> *part = (n_az || n_el) ? (cplx<double> *)(next + b_list2) : nullptr;
     MMW_HIP(hipMemsetAsync(a.ctl, 0, DCTL_WORDS * sizeof(int), ctx->stream));
     // range-Doppler of every antenna (float32) with the planes' L1 norms
     MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
-    const float eps = 5.9604645e-8f, div = argmax_bound_div();
+    const float eps = 5.9604645e-8f, div = detect_bound_div();
     const int ulps = rd_error_ulps(S, C);
     a.rd = (const float2 *)d_rd;
     a.l1 = d_l1;
@@ -1609,6 +1627,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.cap = cap;
     a.words = plan.words;
     a.band_rows = plan.band_rows;
+    a.band_pitch = plan.band_pitch;
     a.kind = cfar_kind;
     a.tr = train_r;
     a.td = train_d;
@@ -1624,13 +1643,35 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.shift_az = shift_az;
     a.shift_el = shift_el;
     a.twA = (const float2 *)twA;
-    a.rf_az = ArgmaxRefine{d_l1, a.ctl + DCTL_AZ, list_az, list_cap, (float)ulps * eps / div, 4.f * (float)(n_az + 4) * eps / div};
-    a.rf_el = ArgmaxRefine{d_l1, a.ctl + DCTL_EL, list_el, list_cap, (float)ulps * eps / div, 4.f * (float)(n_el + 4) * eps / div};
+    a.rf_az = ArgmaxRefine{d_l1, a.ctl + DCTL_ARGMAX, list, list_cap2, (float)ulps * eps / div, 4.f * (float)(n_az + 4) * eps / div};
+    a.rf_el = ArgmaxRefine{d_l1, a.ctl + DCTL_ARGMAX, list, list_cap2, (float)ulps * eps / div, 4.f * (float)(n_el + 4) * eps / div};
     {
         ProfScope ps(ctx, "detect");
-        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_detect_screen), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)plan.lds_screen));
-        hipLaunchKernelGGL(k_detect_screen, dim3(n_frames), dim3(DET_NT), plan.lds_screen, ctx->stream, a);
+        auto go = [&](auto kern) -> int {
+            MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_screen));
+            if (tune_int("MMW_PHASE_CLOCKS", 0)) {
+                // diagnostics: shader clocks of a mid-batch workgroup's phases (load + |.|, CFAR bands, compaction, argmax)
+                long long *d = nullptr, h[5] = {0};
+                MMW_HIP(hipMalloc((void **)&d, sizeof(h)));
+                MMW_HIP(hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
+                DetectArgs b = a;
+                b.clk = d;
+                hipLaunchKernelGGL(kern, dim3(n_frames), dim3(DET_NT), plan.lds_screen, ctx->stream, b);
+                MMW_HIP(hipStreamSynchronize(ctx->stream));
+                MMW_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+                MMW_HIP(hipFree(d));
+                std::fprintf(stderr, "detect_screen %dx%d clocks: load %lld cfar %lld compact %lld argmax %lld\n", S, C, h[1] - h[0],
+                             h[2] - h[1], h[3] - h[2], h[4] - h[3]);
+                return MMW_OK;
+            }
+            hipLaunchKernelGGL(kern, dim3(n_frames), dim3(DET_NT), plan.lds_screen, ctx->stream, a);
+            return MMW_OK;
+        };
+        // the windows of the reference's own configs as compile-time constants: (4,4)/(2,2) (tests/verify_processors.py:165,
+        // SURVEY.md 8d) and the GUI's (5,5)/(3,2) (gui_configs/processor_params.yaml:44-45); anything else at run time
+        if (train_r == 4 && train_d == 4 && guard_r == 2 && guard_d == 2) MMW_TRY(go(k_detect_screen<4, 4, 2, 2>));
+        else if (train_r == 5 && train_d == 5 && guard_r == 3 && guard_d == 2) MMW_TRY(go(k_detect_screen<5, 5, 3, 2>));
+        else MMW_TRY(go(k_detect_screen<-1, -1, -1, -1>));
         MMW_TRY(check_launch("detect_screen"));
     }
     {
@@ -1657,32 +1698,46 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         ce.wc = (const double *)wc64;
         ce.twS = (const cplx<double> *)twS64;
         ce.twC = (const cplx<double> *)twC64;
-        hipLaunchKernelGGL(k_cfar_cell_exact, dim3(std::min(cell_cap, 2 * ctx->num_cu)), dim3(256), plan.lds_cell, ctx->stream, ce);
+        long long *d_clk = nullptr;
+        if (tune_int("MMW_PHASE_CLOCKS", 0)) {
+            MMW_HIP(hipMalloc((void **)&d_clk, 5 * sizeof(long long)));
+            MMW_HIP(hipMemsetAsync(d_clk, 0, 5 * sizeof(long long), ctx->stream));
+            ce.clk = d_clk;
+        }
+        hipLaunchKernelGGL(k_cfar_cell_exact, dim3(std::min(cell_cap, 2 * ctx->num_cu)), dim3(CE_NT), plan.lds_cell, ctx->stream, ce);
+        if (d_clk) {
+            long long h[5] = {0};
+            MMW_HIP(hipStreamSynchronize(ctx->stream));
+            MMW_HIP(hipMemcpy(h, d_clk, sizeof(h), hipMemcpyDeviceToHost));
+            MMW_HIP(hipFree(d_clk));
+            std::fprintf(stderr, "cfar_cell_exact clocks: tables %lld range sums %lld doppler sums %lld decision %lld\n", h[1] - h[0], h[2] - h[1],
+                         h[3] - h[2], h[4] - h[3]);
+        }
         MMW_TRY(check_launch("cfar_cell_exact"));
         hipLaunchKernelGGL(k_detect_finish, dim3(std::min(n_frames, ctx->num_cu)), dim3(DET_NT), plan.lds_finish, ctx->stream, a);
         MMW_TRY(check_launch("detect_finish"));
     }
-    if (cap > 0) {
+    if (cap > 0 && (n_az || n_el)) {
         ProfScope ps(ctx, "argmax_refine");
-        for (int which = 0; which < 2; ++which) {
-            const AntList &ants = which ? el_full : az_full;
-            if (ants.n == 0) continue;
-            RefineArgs ra{};
-            MMW_TRY(fill_refine_args(ctx, &ra, S, C, A));
-            ra.cubes = (const float2 *)d_cubes;
-            ra.dets = d_dets;
-            ra.n_flag = a.ctl + (which ? DCTL_EL : DCTL_AZ);
-            ra.list = which ? list_el : list_az;
-            ra.list_cap = list_cap;
-            ra.out_idx = which ? d_el_idx : d_az_idx;
-            ra.V = V;
-            ra.cap = cap;
-            ra.ants = ants;
-            ra.shift = which ? shift_el : shift_az;
-            ra.partial = which ? part_el : part_az;
-            ra.n_split = n_split;
-            MMW_TRY(launch_argmax_refine(ctx, ra));
-        }
+        RefineArgs ra{};
+        MMW_TRY(fill_refine_args(ctx, &ra, S, C, A));
+        ra.cubes = (const float2 *)d_cubes;
+        ra.dets = d_dets;
+        ra.n_flag = a.ctl + DCTL_ARGMAX;
+        ra.list = list;
+        ra.list_cap = list_cap2;
+        ra.out_idx = d_az_idx;
+        ra.out_idx2 = d_el_idx;
+        ra.V = V;
+        ra.cap = cap;
+        ra.ants = az_full;
+        ra.ants2 = el_full;
+        ra.shift = shift_az;
+        ra.shift2 = shift_el;
+        ra.partial = part;
+        ra.n_split = n_split2;
+        ra.parts = refine_parts(n_frames);
+        MMW_TRY(launch_argmax_refine(ctx, ra));
     }
     if (h_stats) {
         int h[DCTL_WORDS];
@@ -1691,7 +1746,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         h_stats[0] = h[DCTL_FLAG_FRAMES];
         h_stats[1] = h[DCTL_CELLS];
         h_stats[2] = h[DCTL_FALLBACK];
-        h_stats[3] = h[DCTL_AZ];
+        h_stats[3] = h[DCTL_ARGMAX] - h[DCTL_EL];
         h_stats[4] = h[DCTL_EL];
     }
     return MMW_OK;
