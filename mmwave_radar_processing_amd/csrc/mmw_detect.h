@@ -1,5 +1,9 @@
 // Fused per-frame detection stage of the batch pipeline (BASELINE configs[2]): everything behind the range-Doppler
-// kernel in ONE launch, one 1024-thread workgroup per frame.
+// kernel in ONE launch, one 1024-thread workgroup per frame.  A plane whose float32 magnitudes do not fit the LDS is cut
+// into row tiles (one workgroup each); the tile that finishes LAST compacts the frame's detection mask and runs the angle
+// argmax.  (Measured on 256 x 128: 2 / 3 / 4 / 6 tiles of 512 threads -- two or three workgroups per CU instead of one --
+// are all slower than the whole plane in one workgroup, 0.41 - 0.72 ms against 0.32 ms per 1250 frames: the halo rows are
+// loaded twice and the last tile's compaction + argmax has half the waves.)
 //
 //   RangeDopplerDetector._compute_range_doppler_response   processors/range_doppler_detection/range_doppler_detector.py:62-80
 //   CaCFAR2D / OsCFAR2D .detect                             detectors/ca_cfar.py:85-155, os_cfar.py:97-195, base.py:208-230
@@ -36,10 +40,12 @@
 
 namespace mmw {
 
-constexpr int DET_NT = 1024;             // threads of the per-frame workgroup
+constexpr int DET_NT = 1024;             // threads of the per-frame (per-tile) workgroup
 constexpr int DET_MAX_ANT = 8;           // antennas per list inside the fused kernels (cells, twiddles and error scales of a
                                          // list live in registers; lists of 9+ antennas take mmw_angle_argmax_exact)
 constexpr int DET_LIST2 = 16;            // first lane of the second list's cells
+constexpr int DET_LINE = 32;             // ints per frame in the done / status arrays
+enum { DST_UNDECIDED = 1, DST_OVERFLOW = 2, DST_DEGENERATE = 4 };
 enum { DCTL_FLAG_FRAMES = 0, DCTL_CELLS = 1, DCTL_FALLBACK = 2, DCTL_ARGMAX = 16, DCTL_EL = 32, DCTL_WORDS = 64 };   // ARGMAX: flagged
                                                     // evaluations of both lists (the refinement list's length), EL: those of the second
 
@@ -60,6 +66,9 @@ struct DetectArgs {
     int *cells;                // [cell_cap][2] undecided cells: (frame, r * C + c)
     int cell_cap;
     int V, S, C, cap, words, band_rows, band_pitch;   // band buffers: band_rows x band_pitch floats each
+    int tiles, tile_rows;      // row tiles per frame; valid rows (cells under test) per tile
+    int *done, *status;        // [F][DET_LINE] (one 128-byte line per frame: device-scope atomics on neighbouring words of a line
+                               // serialise at one memory channel): tiles finished; DST_* bits of the frame
     int kind, tr, td, gr, gd, n_train, k_rank;
     double scale;
     float k_fft;               // ulps * 2^-24 of the RD kernel that ran
@@ -187,7 +196,8 @@ __device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const fl
             im += xr[i] * w[i].y + xi[i] * w[i].x;
         }
     };
-    float best = -__builtin_huge_valf(), best_re = 0.f, best_im = 0.f;
+    const float NEG = -__builtin_huge_valf();
+    float best = NEG, second = NEG, best_re = 0.f, best_im = 0.f;
     int best_idx = 0x7fffffff;
     for (int k = lane; k < A; k += 64) {
         float2 w[NMAX];
@@ -196,55 +206,62 @@ __device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const fl
         const float m = __fsqrt_rn(fmaf(re, re, im * im));       // (magnitudes near the float32 range end in the float64 pass)
         const int kk = shift ? (k + A / 2) % A : k;
         if (best_idx == 0x7fffffff || mag_better(m, kk, best, best_idx)) {
+            if (best_idx != 0x7fffffff) second = best;
             best = m;
             best_idx = kk;
             best_re = re;
             best_im = im;
-        }
+        } else if (mag_gt(m, second)) second = m;
     }
-    // first maximum over the wave: largest key, smallest bin index among its holders
+    // first maximum over the wave: largest key, smallest bin index among its holders; then the largest other magnitude
     const bool has = best_idx != 0x7fffffff;
     const unsigned kb = has ? mag_key(best) : 0u;
     const unsigned top = wave_max_u32(kb);
     const int wi = (int)~wave_max_u32((has && kb == top) ? ~(unsigned)best_idx : 0u);
-    const int l1 = __ffsll((long long)__ballot(has && best_idx == wi)) - 1;
     const float m1 = key_mag(top);
-    const float re1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_re), l1));
-    const float im1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_im), l1));
-    // every other bin against the winner
-    const float c_ang = rf.k_ang * sum_abs, two_b = 2.f * (be + c_ang), inv1 = 1.f / m1, u1x = re1 * inv1, u1y = im1 * inv1;
-    const int k1 = shift ? (wi + A - A / 2) % A : wi;
-    float2 t1[NMAX];                    // conj(u_1) W^(i k_1)
-    {
-        int t = 0;
-#pragma unroll
-        for (int i = 0; i < NMAX; ++i) {
-            const float2 w = tw[t];
-            t1[i] = make_float2(u1x * w.x + u1y * w.y, u1x * w.y - u1y * w.x);
-            t += k1;
-            if (t >= A) t -= A;
-        }
-    }
-    bool bad = !(m1 == m1) || !has;                              // NaN winner: the float64 pass decides
-    for (int k = lane; k < A; k += 64) {
-        const int kk = shift ? (k + A / 2) % A : k;
-        if (kk == wi) continue;
-        float2 w[NMAX];
-        float re, im;
-        bin(k, w, re, im);
-        const float m = __fsqrt_rn(fmaf(re, re, im * im)), margin = m1 - m;
-        bool ok = margin > two_b;
-        if (!ok && m > 0.f) {
-            const float inv = 1.f / m, ux = re * inv, uy = im * inv;
-            float lin = 0.f;
+    const float m2 = key_mag(wave_max_u32(!has ? 0u : (best_idx == wi ? (second == NEG ? 0u : mag_key(second)) : kb)));
+    const float c_ang = rf.k_ang * sum_abs, two_b = 2.f * (be + c_ang);
+    bool bad = !(m1 - m2 > two_b);                               // (also for a NaN winner)
+    if (bad && m1 == m1) {
+        // the runner-up is inside the independent-errors bound (2 % of the detections): every other bin against the
+        // winner with the correlated form
+        const int l1 = __ffsll((long long)__ballot(has && best_idx == wi)) - 1;
+        const float re1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_re), l1));
+        const float im1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_im), l1));
+        const float inv1 = 1.f / m1, u1x = re1 * inv1, u1y = im1 * inv1;
+        const int k1 = shift ? (wi + A - A / 2) % A : wi;
+        float2 t1[NMAX];                    // conj(u_1) W^(i k_1)
+        {
+            int t = 0;
 #pragma unroll
             for (int i = 0; i < NMAX; ++i) {
-                const float dx = t1[i].x - (ux * w[i].x + uy * w[i].y), dy = t1[i].y - (ux * w[i].y - uy * w[i].x);
-                lin += e[i] * __fsqrt_rn(fmaf(dx, dx, dy * dy));
+                const float2 w = tw[t];
+                t1[i] = make_float2(u1x * w.x + u1y * w.y, u1x * w.y - u1y * w.x);
+                t += k1;
+                if (t >= A) t -= A;
             }
-            ok = margin > 1.001f * (lin + be * be / (2.f * fminf(m1, m))) + 2.f * c_ang;
         }
-        bad |= !ok;
+        bad = false;
+        for (int k = lane; k < A; k += 64) {
+            const int kk = shift ? (k + A / 2) % A : k;
+            if (kk == wi) continue;
+            float2 w[NMAX];
+            float re, im;
+            bin(k, w, re, im);
+            const float m = __fsqrt_rn(fmaf(re, re, im * im)), margin = m1 - m;
+            bool ok = margin > two_b;
+            if (!ok && m > 0.f) {
+                const float inv = 1.f / m, ux = re * inv, uy = im * inv;
+                float lin = 0.f;
+#pragma unroll
+                for (int i = 0; i < NMAX; ++i) {
+                    const float dx = t1[i].x - (ux * w[i].x + uy * w[i].y), dy = t1[i].y - (ux * w[i].y - uy * w[i].x);
+                    lin += e[i] * __fsqrt_rn(fmaf(dx, dx, dy * dy));
+                }
+                ok = margin > 1.001f * (lin + be * be / (2.f * fminf(m1, m))) + 2.f * c_ang;
+            }
+            bad |= !ok;
+        }
     }
     const bool flag = __ballot(bad) != 0ull;
     if (lane == 0) {
@@ -320,85 +337,48 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
     }
 }
 
-// LDS of k_detect_screen: float32 plane, two float32 band buffers, bit mask, 96 ints, W_A^m table
-inline size_t detect_tail_lds(int words, int A) { return (((size_t)words * 4 + 15) & ~(size_t)15) + 96 * 4 + (size_t)A * 8; }
-inline size_t detect_screen_lds(int S, int C, int band_rows, int band_pitch, int A) {
-    const size_t n = (size_t)S * C, words = (n + 31) / 32;
-    return ((n * 4 + 15) & ~(size_t)15) + 2 * (((size_t)band_rows * band_pitch * 4 + 15) & ~(size_t)15) + detect_tail_lds((int)words, A);
+// A tile of a frame: cells under test in rows [r_lo, r_hi), magnitudes of rows [x_lo, x_hi) = [r_lo - hr, r_hi + hr) in LDS
+// (Xs row 0 = plane row x_lo), detection bit of cell (r, c) at tile bit (r - r_lo) * C + c.
+struct DetTile {
+    int r_lo, r_hi, x_lo, x_hi;
+};
+
+__device__ __forceinline__ void det_undecided(const DetectArgs &a, long f, int cell, int *ws) {
+    const int pos = atomicAdd(a.ctl + DCTL_CELLS, 1);
+    if (pos < a.cell_cap) {
+        a.cells[2 * pos] = (int)f;
+        a.cells[2 * pos + 1] = cell;
+        ws[44] = 1;
+    } else
+        ws[45] = 1;
 }
 
-// CFAR decision of every cell of the frame, band by band (run-time window, one cell per thread and pass): column sums
+// CFAR decision of every cell of the tile, band by band (run-time window, one cell per thread and pass): column sums
 // over the training / guard rows of the window into Vt / Vg, then the row-wise combination, the band test, detection bits
 // into `bits` and undecided cells into the global list (ws[44] / ws[45] = has undecided cells / list overflow).
-__device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const float *Xs, float *Vt, float *Vg, unsigned *bits,
-                                              int *ws, double Bf) {
-    const int S = a.S, C = a.C, tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const DetTile &tl, const float *Xs, float *Vt, float *Vg,
+                                              unsigned *bits, int *ws, double Bf) {
+    const int C = a.C, tid = threadIdx.x, lane = tid & 63;
     const int tr = a.tr, td = a.td, gr = a.gr, gd = a.gd, hr = tr + gr, hd = td + gd;
-    {
-        const float inv_n = (float)(1.0 / (double)a.n_train);
-        const double alpha = a.scale, band0 = (1.0 + fabs(alpha)) * Bf;
-        // cell i = tid, tid + NT, ... of a band as (row rr, column c) without a division per cell
-        const int rr_t = tid / C, c_t = tid - rr_t * C, dq = DET_NT / C, dm = DET_NT - dq * C;
-        const int g_lo = tr, g_hi = tr + 2 * gr;                // guard rows / columns inside the window
-        const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
-        const int gc_lo = td, gc_hi = td + 2 * gd;
-        for (int r0 = hr; r0 < S - hr; r0 += a.band_rows) {
-            const int nb = min(a.band_rows, S - hr - r0), cells = nb * C;
-            {
-                int rr = rr_t, c = c_t;
-                for (int i = tid; i < cells; i += DET_NT) {
-                    const float *col = Xs + (r0 + rr - hr) * C + c;
-                    float t = 0.f, g = 0.f;
-                    for (int dr = 0; dr < g_lo; ++dr) t += col[dr * C];
-                    for (int dr = g_lo; dr <= g_hi; ++dr) g += col[dr * C];
-                    for (int dr = g_hi + 1; dr < Wr; ++dr) t += col[dr * C];
-                    Vt[i] = t;
-                    Vg[i] = g;
-                    c += dm;
-                    rr += dq;
-                    if (c >= C) {
-                        c -= C;
-                        ++rr;
-                    }
-                }
-            }
-            __syncthreads();
+    const float inv_n = (float)(1.0 / (double)a.n_train);
+    const double alpha = a.scale, band0 = (1.0 + fabs(alpha)) * Bf;
+    // cell i = tid, tid + NT, ... of a band as (row rr, column c) without a division per cell
+    const int rr_t = tid / C, c_t = tid - rr_t * C, dq = DET_NT / C, dm = DET_NT - dq * C;
+    const int g_lo = tr, g_hi = tr + 2 * gr;                // guard rows / columns inside the window
+    const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
+    const int gc_lo = td, gc_hi = td + 2 * gd;
+    for (int r0 = tl.r_lo; r0 < tl.r_hi; r0 += a.band_rows) {
+        const int nb = min(a.band_rows, tl.r_hi - r0), cells = nb * C;
+        {
             int rr = rr_t, c = c_t;
-            for (int i0 = tid - lane; i0 < cells; i0 += DET_NT) {        // wave-uniform trip count (ballot below)
-                const int i = i0 + lane;
-                bool det = false, unc = false;
-                const int r = r0 + rr;
-                if (i < cells && c >= hd && c < C - hd) {
-                    // training cells = training rows of every window column + guard rows of the columns outside the guard
-                    const float *pt = Vt + i - hd, *pg = Vg + i - hd;
-                    float tot = 0.f;
-                    for (int dc = 0; dc < gc_lo; ++dc) tot += pt[dc] + pg[dc];
-                    for (int dc = gc_lo; dc <= gc_hi; ++dc) tot += pt[dc];
-                    for (int dc = gc_hi + 1; dc < Wd; ++dc) tot += pt[dc] + pg[dc];
-                    const double X = (double)Xs[r * C + c], T = alpha * (double)(tot * inv_n);
-                    const double d = X - T, band = band0 + 3.0e-6 * (X + fabs(T));
-                    det = d > band;
-                    unc = !det && !(d <= -band);
-                }
-                const unsigned long long m = __ballot(det);
-                if (m && lane == 0) {
-                    const long b0 = (long)r0 * C + i0;
-                    const int wd = (int)(b0 >> 5), sh = (int)(b0 & 31);
-                    const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
-                    const unsigned w0 = lo << sh, w1 = (sh ? lo >> (32 - sh) : 0u) | (hi << sh), w2 = sh ? hi >> (32 - sh) : 0u;
-                    if (w0) atomicOr(&bits[wd], w0);
-                    if (w1) atomicOr(&bits[wd + 1], w1);
-                    if (w2) atomicOr(&bits[wd + 2], w2);
-                }
-                if (unc) {
-                    const int pos = atomicAdd(a.ctl + DCTL_CELLS, 1);
-                    if (pos < a.cell_cap) {
-                        a.cells[2 * pos] = (int)f;
-                        a.cells[2 * pos + 1] = r * C + c;
-                        ws[44] = 1;
-                    } else
-                        ws[45] = 1;
-                }
+            for (int i = tid; i < cells; i += DET_NT) {
+                const float *col = Xs + (r0 + rr - hr - tl.x_lo) * C + c;
+                float t = 0.f, g = 0.f;
+                for (int dr = 0; dr < g_lo; ++dr) t += col[dr * C];
+                for (int dr = g_lo; dr <= g_hi; ++dr) g += col[dr * C];
+                for (int dr = g_hi + 1; dr < Wr; ++dr) t += col[dr * C];
+                Vt[i] = t;
+                Vg[i] = g;
                 c += dm;
                 rr += dq;
                 if (c >= C) {
@@ -406,8 +386,44 @@ __device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const
                     ++rr;
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
+        int rr = rr_t, c = c_t;
+        for (int i0 = tid - lane; i0 < cells; i0 += DET_NT) {        // wave-uniform trip count (ballot below)
+            const int i = i0 + lane;
+            bool det = false, unc = false;
+            const int r = r0 + rr;
+            if (i < cells && c >= hd && c < C - hd) {
+                // training cells = training rows of every window column + guard rows of the columns outside the guard
+                const float *pt = Vt + i - hd, *pg = Vg + i - hd;
+                float tot = 0.f;
+                for (int dc = 0; dc < gc_lo; ++dc) tot += pt[dc] + pg[dc];
+                for (int dc = gc_lo; dc <= gc_hi; ++dc) tot += pt[dc];
+                for (int dc = gc_hi + 1; dc < Wd; ++dc) tot += pt[dc] + pg[dc];
+                const double X = (double)Xs[(r - tl.x_lo) * C + c], T = alpha * (double)(tot * inv_n);
+                const double d = X - T, band = band0 + 3.0e-6 * (X + fabs(T));
+                det = d > band;
+                unc = !det && !(d <= -band);
+            }
+            const unsigned long long m = __ballot(det);
+            if (m && lane == 0) {
+                const long b0 = (long)(r0 - tl.r_lo) * C + i0;
+                const int wd = (int)(b0 >> 5), sh = (int)(b0 & 31);
+                const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+                const unsigned w0 = lo << sh, w1 = (sh ? lo >> (32 - sh) : 0u) | (hi << sh), w2 = sh ? hi >> (32 - sh) : 0u;
+                if (w0) atomicOr(&bits[wd], w0);
+                if (w1) atomicOr(&bits[wd + 1], w1);
+                if (w2) atomicOr(&bits[wd + 2], w2);
+            }
+            if (unc) det_undecided(a, f, r * C + c, ws);
+            c += dm;
+            rr += dq;
+            if (c >= C) {
+                c -= C;
+                ++rr;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -421,20 +437,20 @@ __device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const
 // only (no sliding differences).
 constexpr int det_band_pitch(int C, int hd) { return (C + 2 * hd + 4 + 4 + 3) / 4 * 4; }
 template <int TR, int TD, int GR, int GD>
-__device__ __forceinline__ void cfar_bands_ct(const DetectArgs &a, long f, const float *Xs, float *Vt, float *Vg, unsigned *bits,
-                                              int *ws, double Bf) {
+__device__ __forceinline__ void cfar_bands_ct(const DetectArgs &a, long f, const DetTile &tl, const float *Xs, float *Vt, float *Vg,
+                                              unsigned *bits, int *ws, double Bf) {
     constexpr int HR = TR + GR, HD = TD + GD, WR = 2 * HR + 1, WD = 2 * HD + 1, R = 4, OFF = HD + 4, NQ = (WD + R - 1 + 3) / 4;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int S = a.S, C = a.C, tid = threadIdx.x, P = a.band_pitch, cg_n = (C + R - 1) / R;
+    const int C = a.C, tid = threadIdx.x, P = a.band_pitch, cg_n = (C + R - 1) / R;
     // the test itself in float32: alpha / N and the band are rounded once (and the band widened by 1e-6 for it), the
     // product and the difference add two more roundings of T -- all inside the 3e-6 (X + |T|) term
     const float alpha_n = (float)(a.scale / (double)a.n_train), band0 = (float)((1.0 + fabs(a.scale)) * Bf * 1.000001);
-    for (int r0 = HR; r0 < S - HR; r0 += a.band_rows) {
-        const int nb = min(a.band_rows, S - HR - r0);
+    for (int r0 = tl.r_lo; r0 < tl.r_hi; r0 += a.band_rows) {
+        const int nb = min(a.band_rows, tl.r_hi - r0);
         for (int i = tid; i < ((nb + R - 1) / R) * C; i += DET_NT) {
             const int rg = i / C, c = i - rg * C, top = r0 + R * rg - HR;       // first plane row this thread reads
-            const int last = S - 1 - top;                                       // rows of a ragged last group: re-read, unused
-            const float *col = Xs + top * C + c;
+            const int last = tl.x_hi - 1 - top;                                 // rows of a ragged last group: re-read, unused
+            const float *col = Xs + (top - tl.x_lo) * C + c;
             float v[WR + R - 1];
 #pragma unroll
             for (int dr = 0; dr < WR + R - 1; ++dr) v[dr] = col[min(dr, last) * C];
@@ -462,13 +478,14 @@ __device__ __forceinline__ void cfar_bands_ct(const DetectArgs &a, long f, const
                 qg[q] = pg[q];
             }
             float x[R];
+            const float *xrow = Xs + (r - tl.x_lo) * C + c0;
             if ((C & 3) == 0) {                 // one aligned 16-byte read (four 4-byte reads at this lane stride conflict)
-                const f4 q = *reinterpret_cast<const f4 *>(Xs + r * C + c0);
+                const f4 q = *reinterpret_cast<const f4 *>(xrow);
 #pragma unroll
                 for (int j = 0; j < R; ++j) x[j] = q[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < R; ++j) x[j] = c0 + j < C ? Xs[r * C + c0 + j] : 0.f;
+                for (int j = 0; j < R; ++j) x[j] = c0 + j < C ? xrow[j] : 0.f;
             }
             unsigned nib = 0;
 #pragma unroll
@@ -484,21 +501,12 @@ __device__ __forceinline__ void cfar_bands_ct(const DetectArgs &a, long f, const
                 if (c >= HD && c < C - HD) {
                     const float X = x[j], T = alpha_n * tot;
                     const float d = X - T, band = band0 + 3.0e-6f * (X + fabsf(T));
-                    const bool det = d > band;
-                    if (det) nib |= 1u << j;
-                    else if (!(d <= -band)) {
-                        const int pos = atomicAdd(a.ctl + DCTL_CELLS, 1);
-                        if (pos < a.cell_cap) {
-                            a.cells[2 * pos] = (int)f;
-                            a.cells[2 * pos + 1] = r * C + c;
-                            ws[44] = 1;
-                        } else
-                            ws[45] = 1;
-                    }
+                    if (d > band) nib |= 1u << j;
+                    else if (!(d <= -band)) det_undecided(a, f, r * C + c, ws);
                 }
             }
             if (nib) {
-                const long b0 = (long)r * C + c0;
+                const long b0 = (long)(r - tl.r_lo) * C + c0;
                 const unsigned long long m = (unsigned long long)nib << (b0 & 31);
                 atomicOr(&bits[b0 >> 5], (unsigned)m);
                 if (m >> 32) atomicOr(&bits[(b0 >> 5) + 1], (unsigned)(m >> 32));
@@ -508,58 +516,74 @@ __device__ __forceinline__ void cfar_bands_ct(const DetectArgs &a, long f, const
     }
 }
 
+// LDS of k_detect_screen: float32 magnitudes of the tile's rows + halo, two float32 band buffers, the tile's bit mask
+// (the whole frame's when the tile turns out to be the last one), 96 ints, W_A^m table
+inline size_t detect_tail_lds(int words, int A) { return (((size_t)words * 4 + 15) & ~(size_t)15) + 96 * 4 + (size_t)A * 8; }
+inline size_t detect_screen_lds(int x_rows, int C, int band_rows, int band_pitch, int words, int A) {
+    return (((size_t)x_rows * C * 4 + 15) & ~(size_t)15) + 2 * (((size_t)band_rows * band_pitch * 4 + 15) & ~(size_t)15) +
+           detect_tail_lds(words, A);
+}
+
 // TR, TD, GR, GD >= 0: the window is a compile-time constant (every loop over it unrolls: all of a cell's LDS reads are
 // issued before the first add); -1: taken from the arguments at run time.
 template <int TR, int TD, int GR, int GD>
 __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
     constexpr bool CT = TR >= 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = a.S, C = a.C, n = S * C, tid = threadIdx.x;
-    const long f = blockIdx.x;
+    const int S = a.S, C = a.C, tid = threadIdx.x;
+    const long f = blockIdx.x / a.tiles;
+    const int t = blockIdx.x - (int)f * a.tiles;
+    const int hr = CT ? TR + GR : a.tr + a.gr, hd = CT ? TD + GD : a.td + a.gd;
+    const bool window_fits = S > 2 * hr && C > 2 * hd;
+    DetTile tl;
+    tl.r_lo = window_fits ? hr + t * a.tile_rows : 0;
+    tl.r_hi = window_fits ? min(tl.r_lo + a.tile_rows, S - hr) : 0;
+    tl.x_lo = window_fits ? tl.r_lo - hr : 0;
+    tl.x_hi = window_fits ? tl.r_hi + hr : S;                   // (no valid cell: one tile that only writes the magnitudes)
+    const int x_rows_max = a.tile_rows + 2 * hr;
     float *Xs = reinterpret_cast<float *>(smem);
-    size_t off = ((size_t)n * 4 + 15) & ~(size_t)15;
+    size_t off = ((size_t)(window_fits ? x_rows_max : 0) * C * 4 + 15) & ~(size_t)15;
     const size_t band_bytes = ((size_t)a.band_rows * a.band_pitch * 4 + 15) & ~(size_t)15;
     float *Vt = reinterpret_cast<float *>(smem + off);      // column sums over the training rows of the window
     float *Vg = reinterpret_cast<float *>(smem + off + band_bytes);      // ... over its guard rows
     off += 2 * band_bytes;
-    unsigned *bits = reinterpret_cast<unsigned *>(smem + off);
+    unsigned *bits = reinterpret_cast<unsigned *>(smem + off);     // a.words words: tile mask now, frame mask in the last tile
     off += ((size_t)a.words * 4 + 15) & ~(size_t)15;
-    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, [48, 80) antennas
+    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, 46 ticket, [48, 80) antennas
     float2 *tw = reinterpret_cast<float2 *>(smem + off + 96 * 4);
     det_mark(a, 0);
     if (tid < 2) ws[44 + tid] = 0;
-    detect_ant_table(a, ws + 48);
-    for (int w = tid; w < a.words; w += DET_NT) bits[w] = 0u;
-    for (int i = tid; i < a.A; i += DET_NT) tw[i] = a.twA[i];
+    const int t_cells = (tl.r_hi - tl.r_lo) * C, t_words = (t_cells + 31) / 32;
+    for (int w = tid; w < t_words + 1 && w < a.words; w += DET_NT) bits[w] = 0u;
 
     // error band scale; 1.0001 covers the float32 summation of the L1 norm itself
-    const double Bf = (double)a.k_fft * (double)a.l1[f * a.V] * 1.0001;
-    // NaN / inf samples in antenna 0, or a scale at which float32 squares over- / underflow (an all-zero plane is fine)
     const float l1v = a.l1[f * a.V];
+    const double Bf = (double)a.k_fft * (double)l1v * 1.0001;
+    // NaN / inf samples in antenna 0, or a scale at which float32 squares over- / underflow (an all-zero plane is fine)
     const bool degenerate = !(l1v == 0.f || (l1v >= 1e-10f && l1v <= 1e18f));
-    // |RD| of antenna 0 in float32
+    // |RD| of antenna 0 in float32: rows [x_lo, x_hi) into the LDS, and out to mag32 the rows this tile owns
     {
-        const float2 *p = a.rd + f * a.V * n;
-        float *mg = a.mag32 ? a.mag32 + f * n : nullptr;
-        if ((n & 1) == 0) {
+        const int own_lo = t == 0 ? 0 : tl.r_lo, own_hi = t == a.tiles - 1 ? S : tl.r_hi;
+        const long n_plane = (long)S * C;
+        const float2 *p = a.rd + f * a.V * n_plane + (long)tl.x_lo * C;
+        float *mg = a.mag32 ? a.mag32 + f * n_plane + (long)tl.x_lo * C : nullptr;
+        const int n = (tl.x_hi - tl.x_lo) * C, keep_lo = (own_lo - tl.x_lo) * C, keep_hi = (own_hi - tl.x_lo) * C;
+        if ((C & 1) == 0) {
             typedef float f4 __attribute__((ext_vector_type(4)));
             const f4 *p4 = reinterpret_cast<const f4 *>(p);
-            constexpr int U = 16;                           // loads in flight per thread (the whole 256 x 128 plane)
+            constexpr int U = 16;                           // loads in flight per thread (a whole 256 x 128 plane in one trip)
             for (int i0 = tid; i0 < n / 2; i0 += DET_NT * U) {
                 f4 v[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * DET_NT;
-                    v[u] = i < n / 2 ? p4[i] : f4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int u = 0; u < U; ++u) v[u] = p4[min(i0 + u * DET_NT, n / 2 - 1)];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = i0 + u * DET_NT;
                     if (i < n / 2) {
                         const float m0 = __fsqrt_rn(fmaf(v[u].x, v[u].x, v[u].y * v[u].y));
                         const float m1 = __fsqrt_rn(fmaf(v[u].z, v[u].z, v[u].w * v[u].w));
-                        *reinterpret_cast<float2 *>(Xs + 2 * i) = make_float2(m0, m1);
-                        if (mg) *reinterpret_cast<float2 *>(mg + 2 * i) = make_float2(m0, m1);
+                        if (window_fits) *reinterpret_cast<float2 *>(Xs + 2 * i) = make_float2(m0, m1);
+                        if (mg && 2 * i >= keep_lo && 2 * i < keep_hi) *reinterpret_cast<float2 *>(mg + 2 * i) = make_float2(m0, m1);
                     }
                 }
             }
@@ -567,33 +591,62 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
             for (int i = tid; i < n; i += DET_NT) {
                 const float2 v = p[i];
                 const float m = __fsqrt_rn(fmaf(v.x, v.x, v.y * v.y));
-                Xs[i] = m;
-                if (mg) mg[i] = m;
+                if (window_fits) Xs[i] = m;
+                if (mg && i >= keep_lo && i < keep_hi) mg[i] = m;
             }
         }
     }
     __syncthreads();
     det_mark(a, 1);
 
-    const int hr = CT ? TR + GR : a.tr + a.gr, hd = CT ? TD + GD : a.td + a.gd;
-    if (!degenerate && S > 2 * hr && C > 2 * hd) {
-        if constexpr (CT) cfar_bands_ct<TR, TD, GR, GD>(a, f, Xs, Vt, Vg, bits, ws, Bf);
-        else cfar_bands_rt(a, f, Xs, Vt, Vg, bits, ws, Bf);
+    if (!degenerate && window_fits) {
+        if constexpr (CT) cfar_bands_ct<TR, TD, GR, GD>(a, f, tl, Xs, Vt, Vg, bits, ws, Bf);
+        else cfar_bands_rt(a, f, tl, Xs, Vt, Vg, bits, ws, Bf);
     }
     __syncthreads();
     det_mark(a, 2);
-    if (degenerate || ws[45]) {                  // the float64 path decides this frame
+    // the tile's bits into the frame's mask (zeroed before the launch); tiles need not start on a word boundary
+    {
+        const long b0 = (long)tl.r_lo * C;
+        const int sh = (int)(b0 & 31);
+        unsigned *dst = a.bits + f * a.words + (b0 >> 5);
+        for (int w = tid; w < t_words; w += DET_NT) {
+            const unsigned v = bits[w];
+            if (v) {
+                atomicOr(dst + w, v << sh);
+                if (sh && (v >> (32 - sh))) atomicOr(dst + w + 1, v >> (32 - sh));
+            }
+        }
+    }
+    if (tid == 0) {
+        const int st = (degenerate ? DST_DEGENERATE : 0) | (ws[45] ? DST_OVERFLOW : 0) | (ws[44] ? DST_UNDECIDED : 0);
+        if (st) atomicOr(a.status + f * DET_LINE, st);
+    }
+    // The last tile of the frame to get here finishes the frame.  Everything tiles tell each other travels in device-scope
+    // atomics (mask words, status, ticket) and is read back with coherent loads; a thread's atomics are complete before it
+    // passes the barrier (the barrier waits for vmcnt(0)), and thread 0 draws the ticket after the barrier.  No
+    // __threadfence(): on this multi-XCD part a device-scope release writes the XCD's whole L2 back -- with one per tile
+    // the kernel took 4.3 ms instead of 0.3.
+    __syncthreads();
+    if (tid == 0) ws[46] = atomicAdd(a.done + f * DET_LINE, 1);
+    __syncthreads();
+    if (ws[46] != a.tiles - 1) return;
+    const int st = __atomic_load_n(a.status + f * DET_LINE, __ATOMIC_RELAXED);
+    if (st & (DST_DEGENERATE | DST_OVERFLOW)) {                 // the float64 path decides this frame
         if (tid == 0) {
             a.counts[f] = -1;
             atomicAdd(a.ctl + DCTL_FALLBACK, 1);
         }
         return;
     }
-    if (ws[44]) {                                // undecided cells: mask out, compaction after k_cfar_cell_exact
-        for (int w = tid; w < a.words; w += DET_NT) a.bits[f * a.words + w] = bits[w];
+    if (st & DST_UNDECIDED) {                                   // compaction after k_cfar_cell_exact
         if (tid == 0) a.flag_frames[atomicAdd(a.ctl + DCTL_FLAG_FRAMES, 1)] = (int)f;
         return;
     }
+    detect_ant_table(a, ws + 48);
+    for (int i = tid; i < a.A; i += DET_NT) tw[i] = a.twA[i];
+    for (int w = tid; w < a.words; w += DET_NT) bits[w] = __atomic_load_n(a.bits + f * a.words + w, __ATOMIC_RELAXED);
+    __syncthreads();
     detect_finish(a, f, bits, ws, tw);
     det_mark(a, 4);
 }
@@ -635,12 +688,12 @@ struct CellExactArgs {
     long long *clk;            // diagnostics (MMW_PHASE_CLOCKS=1)
 };
 
-constexpr int CE_NT = 512, CE_RPT = 7, CE_SG = 8;      // threads per cell (256 registers each); range rows per pass; sample groups per chirp
+constexpr int CE_NT = 1024, CE_RPT = 7, CE_SG = 8;     // threads per cell; range rows per pass; sample groups per chirp
 inline size_t cell_exact_lds(int S, int C, int Wr, int Wd) {
     return ((size_t)Wr * C + S + C) * 16 + ((size_t)S + C + (size_t)Wr * Wd + 8) * 8;
 }
 
-// One workgroup per undecided cell; everything on its critical path is spread over the 512 threads (180 such cells per
+// One workgroup per undecided cell; everything on its critical path is spread over the 1024 threads (180 such cells per
 // 1250-frame batch run side by side, so the kernel lasts as long as ONE cell takes):
 //   step A  lane = (chirp, sample group): a thread asks for its 1 / CE_SG share of the chirp's samples in one go (cold HBM
 //           lines), accumulates CE_RPT range rows at a time, the sample groups are added up by lane shuffles (fixed order);
@@ -684,15 +737,15 @@ __global__ __launch_bounds__(CE_NT) void k_cfar_cell_exact(CellExactArgs a) {
             const int ch = ch0 + tid / CE_SG;
             const bool live = ch < C;
             for (int row0 = 0; row0 < Wr; row0 += CE_RPT) {
+                // the pass's range bins are consecutive, k0 + j:  W^((k0 + j) s) = W^(k0 s) (W^s)^j -- two table reads per
+                // sample and a float64 recurrence over the rows (a table read per row and sample kept this loop waiting on
+                // the LDS: 140 k of the kernel's 160 k clocks)
                 cplx<double> acc[CE_RPT];
-                int idx[CE_RPT], k[CE_RPT];
 #pragma unroll
-                for (int j = 0; j < CE_RPT; ++j) {
-                    acc[j] = cplx<double>{0.0, 0.0};
-                    k[j] = row0 + j < Wr ? r - hr + row0 + j : 0;    // range bin (inside the plane: valid region)
-                    idx[j] = (int)(((long)k[j] * sg) % S);
-                    k[j] = (int)(((long)k[j] * CE_SG) % S);           // twiddle-index step between a thread's samples
-                }
+                for (int j = 0; j < CE_RPT; ++j) acc[j] = cplx<double>{0.0, 0.0};
+                const int k0 = r - hr + row0;                         // first range bin (inside the plane: valid region)
+                int idx0 = (int)(((long)k0 * sg) % S), idx1 = sg % S;
+                const int step0 = (int)(((long)k0 * CE_SG) % S), step1 = CE_SG % S;
                 constexpr int U = 16;            // cold HBM lines: ask for 16 samples before using the first
                 for (int s0 = sg; s0 < S; s0 += U * CE_SG) {
                     float2 xv[U];
@@ -704,13 +757,17 @@ __global__ __launch_bounds__(CE_NT) void k_cfar_cell_exact(CellExactArgs a) {
                         const int sx = s0 + u * CE_SG;
                         if (live && sx < S) {
                             const double w = wsl[sx];
-                            const cplx<double> xw = cplx<double>{(double)xv[u].x * w, (double)xv[u].y * w};
+                            const cplx<double> xw = cplx<double>{(double)xv[u].x * w, (double)xv[u].y * w}, w1 = twS[idx1];
+                            cplx<double> t = twS[idx0];
 #pragma unroll
                             for (int j = 0; j < CE_RPT; ++j) {
-                                acc[j] = acc[j] + cmul(xw, twS[idx[j]]);
-                                idx[j] += k[j];
-                                if (idx[j] >= S) idx[j] -= S;
+                                acc[j] = acc[j] + cmul(xw, t);
+                                if (j + 1 < CE_RPT) t = cmul(t, w1);
                             }
+                            idx0 += step0;
+                            if (idx0 >= S) idx0 -= S;
+                            idx1 += step1;
+                            if (idx1 >= S) idx1 -= S;
                         }
                     }
                 }

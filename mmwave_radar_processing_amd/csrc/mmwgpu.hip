@@ -1505,7 +1505,7 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
 namespace {
 struct DetectPlan {
     bool ok, ct_window;
-    int band_rows, band_pitch, words;
+    int band_rows, band_pitch, words, tiles, tile_rows;
     size_t lds_screen, lds_cell, lds_finish;
 };
 DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, int n_az, int n_el, int A = 64) {
@@ -1515,26 +1515,49 @@ DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, i
     if (kind != MMW_CFAR_CA || n_az > DET_MAX_ANT || n_el > DET_MAX_ANT || n > (1L << 20) || A < 1 || A > 1024) return p;
     if (tune_int("MMW_NO_DETECT_SCREEN", 0)) return p;
     p.words = (int)((n + 31) / 32);
+    p.lds_cell = cell_exact_lds(S, C, 2 * hr + 1, 2 * hd + 1);
+    p.lds_finish = detect_tail_lds(p.words, A);
+    if (p.lds_cell > 64 * 1024 || p.lds_finish > 64 * 1024) return p;
     // compile-time windows (the launch below knows the same two): four rows / columns per thread, padded band rows
     p.ct_window = (tr == 4 && td == 4 && gr == 2 && gd == 2) || (tr == 5 && td == 5 && gr == 3 && gd == 2);
     p.band_pitch = p.ct_window ? det_band_pitch(C, hd) : C;
-    const size_t lds_max = 160 * 1024, fixed = detect_screen_lds(S, C, 0, 0, A) + 32, row_bytes = 8 * (size_t)p.band_pitch;
-    if (fixed + (p.ct_window ? 4 : 1) * row_bytes > lds_max) return p;      // the float32 plane must fit the LDS
-    int br = (int)((lds_max - fixed) / row_bytes);
-    if (p.ct_window) {
-        br = std::min(br, (std::max(1, S - 2 * hr) + 3) / 4 * 4);
-        br -= br % 4;
-    } else {
-        br = std::min(br, std::max(1, S - 2 * hr));
-        int unit = DET_NT;                                            // band cells a multiple of the workgroup size
-        for (int g = C; g % 2 == 0 && unit > 1; g /= 2) unit /= 2;    // unit = DET_NT / gcd(C, DET_NT)
-        if (br >= unit) br -= br % unit;
+    const int valid = S - 2 * hr;
+    if (valid <= 0 || C <= 2 * hd) {            // window larger than the plane: no cell under test, magnitudes only
+        p.tiles = 1;
+        p.tile_rows = 0;
+        p.band_rows = p.ct_window ? 4 : 1;
+        p.lds_screen = detect_screen_lds(0, C, p.band_rows, p.band_pitch, p.words, A);
+        p.ok = p.lds_screen <= 160 * 1024;
+        return p;
     }
-    p.band_rows = br;
-    p.lds_screen = detect_screen_lds(S, C, br, p.band_pitch, A);
-    p.lds_cell = cell_exact_lds(S, C, 2 * hr + 1, 2 * hd + 1);
-    p.lds_finish = detect_tail_lds(p.words, A);
-    p.ok = p.lds_cell <= 64 * 1024 && p.lds_finish <= 64 * 1024;
+    // Row tiles: as few as fit the LDS (one for every shipped shape; MMW_DETECT_TILES / MMW_DETECT_BAND: experiments).
+    const int band_want = std::max(1, tune_int("MMW_DETECT_BAND", 20)), force_tiles = tune_int("MMW_DETECT_TILES", 0);
+    const size_t lds_goal = 160 * 1024;
+    size_t best_lds = ~(size_t)0;
+    for (int tiles = 1; tiles <= 64 && tiles <= valid; ++tiles) {
+        int rows = (valid + tiles - 1) / tiles;
+        if (p.ct_window) rows = (rows + 3) / 4 * 4;
+        int band = std::min(band_want, rows);
+        if (p.ct_window) band = std::max(4, band / 4 * 4);
+        const size_t lds = detect_screen_lds(rows + 2 * hr, C, band, p.band_pitch, p.words, A);
+        const bool take = force_tiles > 0 ? tiles == force_tiles : (lds <= lds_goal || (tiles == 64 || tiles == valid));
+        if (lds < best_lds && (force_tiles <= 0 || tiles <= force_tiles)) {
+            best_lds = lds;
+            p.tile_rows = rows;
+            p.band_rows = band;
+            p.lds_screen = lds;
+        }
+        if (take && lds <= 160 * 1024) {
+            p.tile_rows = rows;
+            p.band_rows = band;
+            p.lds_screen = lds;
+            break;
+        }
+    }
+    if (p.lds_screen == 0 || p.lds_screen > 160 * 1024) return p;
+    p.tiles = (valid + p.tile_rows - 1) / p.tile_rows;
+    p.lds_screen += (size_t)std::max(0, tune_int("MMW_DETECT_LDS_PAD", 0));     // experiment: fewer workgroups per CU
+    p.ok = true;
     return p;
 }
 int fill_det_ant(const int *h_ant, int n_ant, int V, int A, DetAnt *out, AntList *full) {
@@ -1563,7 +1586,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && cap >= 0 && A > 0, "bad shape");
     MMW_REQUIRE(train_r >= 0 && train_d >= 0 && guard_r >= 0 && guard_d >= 0, "negative window size");
     MMW_REQUIRE(n_az >= 0 && n_el >= 0 && (n_az == 0 || d_az_idx) && (n_el == 0 || d_el_idx), "antenna list without an index buffer");
-    MMW_REQUIRE((long)n_frames * std::max(cap, 1) < (1L << 31), "too many detection slots for one call");
+    MMW_REQUIRE((long)n_frames * std::max(cap, 1) < (1L << 31) && (long)n_frames * 64 < (1L << 31), "too many detection slots for one call");
     const DetectPlan plan = detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el, A);
     if (!plan.ok)
         return set_error(MMW_ERR_UNSUPPORTED, "mmw_detect_points: no screening kernel for this request (CA-CFAR on planes whose "
@@ -1591,7 +1614,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     const int cell_cap = std::max(4096, 16 * n_frames);
     const int list_cap = n_frames * cap;
     const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));
-    const size_t b_ctl = up(DCTL_WORDS * sizeof(int)), b_ff = up((size_t)n_frames * sizeof(int)),
+    const size_t b_ctl = up((DCTL_WORDS + 2 * (size_t)n_frames * DET_LINE) * sizeof(int)), b_ff = up((size_t)n_frames * sizeof(int)),
                  b_cells = up((size_t)cell_cap * 2 * sizeof(int)), b_bits = up((size_t)n_frames * plan.words * sizeof(unsigned));
     const int list_cap2 = (int)std::min<long>(2L * list_cap, 0x7fffffffL);      // both lists flag into one
     const int n_split2 = std::min(list_cap2, n_split);
@@ -1608,7 +1631,10 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     char *next = base + b_ctl + b_ff + b_cells + b_bits;
     int *list = (n_az || n_el) ? (int *)next : nullptr;
     cplx<double> *part = (n_az || n_el) ? (cplx<double> *)(next + b_list2) : nullptr;
-    MMW_HIP(hipMemsetAsync(a.ctl, 0, DCTL_WORDS * sizeof(int), ctx->stream));
+    a.done = a.ctl + DCTL_WORDS;
+    a.status = a.done + (size_t)n_frames * DET_LINE;
+    MMW_HIP(hipMemsetAsync(a.ctl, 0, (DCTL_WORDS + 2 * (size_t)n_frames * DET_LINE) * sizeof(int), ctx->stream));      // counters, done, status
+    MMW_HIP(hipMemsetAsync(a.bits, 0, (size_t)n_frames * plan.words * sizeof(unsigned), ctx->stream));       // tiles OR their bits in
     // range-Doppler of every antenna (float32) with the planes' L1 norms
     MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
     const float eps = 5.9604645e-8f, div = detect_bound_div();
@@ -1628,6 +1654,8 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.words = plan.words;
     a.band_rows = plan.band_rows;
     a.band_pitch = plan.band_pitch;
+    a.tiles = plan.tiles;
+    a.tile_rows = plan.tile_rows;
     a.kind = cfar_kind;
     a.tr = train_r;
     a.td = train_d;
@@ -1656,7 +1684,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
                 MMW_HIP(hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
                 DetectArgs b = a;
                 b.clk = d;
-                hipLaunchKernelGGL(kern, dim3(n_frames), dim3(DET_NT), plan.lds_screen, ctx->stream, b);
+                hipLaunchKernelGGL(kern, dim3((unsigned)n_frames * plan.tiles), dim3(DET_NT), plan.lds_screen, ctx->stream, b);
                 MMW_HIP(hipStreamSynchronize(ctx->stream));
                 MMW_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
                 MMW_HIP(hipFree(d));
@@ -1664,7 +1692,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
                              h[2] - h[1], h[3] - h[2], h[4] - h[3]);
                 return MMW_OK;
             }
-            hipLaunchKernelGGL(kern, dim3(n_frames), dim3(DET_NT), plan.lds_screen, ctx->stream, a);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_frames * plan.tiles), dim3(DET_NT), plan.lds_screen, ctx->stream, a);
             return MMW_OK;
         };
         // the windows of the reference's own configs as compile-time constants: (4,4)/(2,2) (tests/verify_processors.py:165,
