@@ -254,6 +254,8 @@ def main():
                          "point-cloud angle argmax (configs[2])")
     ap.add_argument("--detect-path", choices=("fused", "float64"), default="fused",
                     help="detect workload: mmw_detect_points (default) or round 2's mmw_detect_batch + mmw_angle_argmax_exact")
+    ap.add_argument("--no-detect-record", action="store_true",
+                    help="chain workload: skip the `detect` sub-record (BASELINE configs[2] timed after the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--profile-every", type=int, default=0,
@@ -278,6 +280,10 @@ def main():
 
     from mmwave_radar_processing_amd import _lib
     ndev = _lib.device_count()
+    if world > ndev and not os.environ.get("MMW_BENCH_SHARE_DEVICES"):
+        # two ranks on one device would also starve each other's device-synchronised chain
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} visible device(s): one process per GPU is the contract "
+                         "(set MMW_BENCH_SHARE_DEVICES=1 to rehearse on fewer devices; the figures are then meaningless)")
     ctx = _lib.Context(local_rank % ndev)
     info = _lib.device_info(ctx.device)
     F = args.frames
@@ -302,27 +308,64 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    if not args.no_profile:
-        ctx.profile_reset()
-        ctx.profile_enable(args.profile_every if args.profile_every > 0 else (1 if n_launch == 1 else 7))
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        step()
-    ev_ms = ctx.timer_stop()
-    ctx.sync()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    ctx.profile_enable(False)
+    def timed(step_fn, profile_every):
+        """W untimed + exactly K timed steps between barriers; (max-over-ranks wall seconds, rank-local HIP-event ms)."""
+        for _ in range(args.warmup):
+            step_fn()
+        barrier()
+        if not args.no_profile:
+            ctx.profile_reset()
+            ctx.profile_enable(profile_every)
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(args.steps):
+            step_fn()
+        ev = ctx.timer_stop()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        barrier()
+        ctx.profile_enable(False)
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ev
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, ev_ms = timed(step, args.profile_every if args.profile_every > 0 else (1 if n_launch == 1 else 7))
+    prof = {k: ctx.profile_get(k) for k in ("rd", "angle", "detect", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
+                                            "plane_l1", "argmax")} if not args.no_profile else {}
+    # BASELINE configs[2] beside the headline: the detection pipeline on the same resident frames, same K / W
+    det_extra = None
+    if not detect and not args.no_detect_record:
+        work = DetectWorkload(ctx, F, args.detect_path)
+        det_elapsed, det_ev = timed(lambda: work.step(d_in), 1)
+        det_prof = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
+                                                    "plane_l1", "argmax")} if not args.no_profile else {}
+        det_extra = (det_elapsed, det_ev, det_prof)
+
+    def detect_fields(dt, ev, fam):
+        """frames/s, per-stage ms and the roofline of the range-Doppler stage of the detection pipeline."""
+        v = world * F * args.steps / dt
+        rec = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps, "hip_event_ms_per_step_rank0": ev / args.steps,
+               "algorithmic_bytes_per_frame": DET_BYTES_PER_FRAME,
+               "hbm_frac_of_8TBs": v / world * DET_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),
+               "path": args.detect_path,
+               "workload": "range-Doppler of all antennas (float32) + CA-CFAR((4,4),(2,2),1e-5) on antenna 0 (float32 screening "
+                           "with the worst-case error band, undecided cells in float64) + ordered detections + 8-antenna azimuth / "
+                           "4-antenna elevation argmax, float64-exact (BASELINE configs[2])"}
+        if fam:
+            rec["kernels_ms_per_step"] = {k: ms / max(n, 1) * (2 if k == "argmax" else 1) for k, (ms, n) in fam.items() if n}
+            rd_ms, rd_n = fam.get("rd", (0.0, 0))
+            if rd_n:
+                avg_s = rd_ms * 1e-3 / rd_n
+                achieved = F * 2 * CUBE_BYTES / avg_s / 1e9
+                rec["roofline"] = {"bound": "hbm", "kernel": "k_rd_fused_256x128_persist (range-Doppler of all 12 planes: the "
+                                   "largest stage of the pipeline)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                                   "launches": rd_n, "frames_per_launch": F,
+                                   "algorithmic_bytes_per_launch": F * 2 * CUBE_BYTES}
+        return rec
 
     if rank == 0:
         total_frames = world * F * args.steps
@@ -334,33 +377,27 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("IWR1843 synthetic 256x128x(4Rx x 3Tx) cube: range-Doppler of all antennas (float32) + "
-                                    "float64 |RD| of antenna 0 + CA-CFAR((4,4),(2,2),1e-5) + ordered detections + exact "
+                                    "CA-CFAR((4,4),(2,2),1e-5) on antenna 0 + ordered detections + float64-exact "
                                     "8-antenna azimuth / 4-antenna elevation argmax (BASELINE configs[2])") if detect else
                                    ("IWR1843 synthetic 256x128x(4Rx x 3Tx) cube: Hann range FFT + Doppler FFT + "
                                     "64-bin angle FFT -> complex64 [64,256,128] (BASELINE configs[1])"),
                        "frames_per_gpu": F, "cube": [V, S, C], "angle_bins": A,
                        "sharding": f"frame-sharded x{world}, no collective",
                        "schedule": (f"{args.detect_path}: stages back to back on one stream, whole batch per launch") if detect else plan,
-                       "device": info["name"], "arch": info["arch"]},
+                       "device": info["name"] or "AMD Instinct MI355X (hipDeviceProp name empty)", "arch": info["arch"]},
             "hip_event_ms_per_step_rank0": ev_ms / args.steps,
             "chain_hbm_frac_of_8TBs": value / world * algo / (HBM_PEAK_GBS * 1e9),
         }
-        if not args.no_profile and detect:
-            fam = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
-                                                   "plane_l1", "argmax")}
-            out["kernels_ms_per_step"] = {k: ms / max(n, 1) * (2 if k == "argmax" else 1) for k, (ms, n) in fam.items() if n}
-            rd_ms, rd_n = fam["rd"]
-            if rd_n:
-                avg_s = rd_ms * 1e-3 / rd_n
-                achieved = F * 2 * CUBE_BYTES / avg_s / 1e9
-                out["roofline"] = {"bound": "hbm", "kernel": "k_rd_fused_256x128_persist (range-Doppler of all 12 planes: the "
-                                   "largest stage of the pipeline)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
-                                   "launches": rd_n, "frames_per_launch": F,
-                                   "algorithmic_bytes_per_launch": F * 2 * CUBE_BYTES}
+        if detect:
+            rec = detect_fields(elapsed, ev_ms, {k: v for k, v in prof.items() if k not in ("angle",)})
+            for k in ("kernels_ms_per_step", "roofline"):
+                if k in rec:
+                    out[k] = rec[k]
+        elif det_extra is not None:
+            out["detect"] = detect_fields(*det_extra)
         if not args.no_profile and not detect:
-            ang_ms, ang_n = ctx.profile_get("angle")
-            rd_ms, rd_n = ctx.profile_get("rd")
+            ang_ms, ang_n = prof["angle"]
+            rd_ms, rd_n = prof["rd"]
             if ang_n:
                 # sampled launches: full chunks and the tail chunk are hit in proportion
                 frames_per_launch = F / n_launch
@@ -403,10 +440,18 @@ def main():
                 out["roofline"]["insitu_streaming_ceiling"] = insitu_ceiling(ctx, d_out, F * OUT_BYTES)
             out["parity_max_rel_err"] = parity_check(saved)
             parity_ok = max(out["parity_max_rel_err"].values()) <= 1e-5
+            if det_extra is not None:       # detections and argmax bins of three frames of the detect run against the oracle
+                dpar, total_dets = work.parity(d_in, sorted({0, F // 2, F - 1}))
+                out["detect"]["parity"] = dpar
+                out["detect"]["detections_per_frame"] = total_dets / F
+                parity_ok = parity_ok and all(v["detection_indices_identical"] and not v["argmax_index_differences"]
+                                              for v in dpar.values())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_detect() if detect else cpu_baseline()
             if not detect:
                 out["cpu_baseline_all_cores"] = cpu_baseline_pool()
+                if det_extra is not None:
+                    out["detect"]["cpu_baseline"] = cpu_baseline_detect(6.0)
         print(json.dumps(out))
         if not parity_ok:
             sys.exit("bench.py: GPU output differs from the oracle (spectra beyond 1e-5 / any index) -- the figure above is invalid")
