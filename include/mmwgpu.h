@@ -293,7 +293,8 @@ int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]);
  * plan[0] = 1 overlapped (range-Doppler || angle on two queues) / 0 serial, plan[1] = frames per kernel launch,
  * plan[2] = ring depth of range-Doppler chunks in flight, plan[3] = CUs of the range-Doppler queue (0 = unmasked),
  * plan[4] = range-Doppler planes transformed per frame (V, or V - 2 when the zero-weight end antennas of the
- * Hann(V) window are skipped), plan[5] = 0 (reserved), plan[6] = 1 for the device-synchronised form (ONE range-Doppler
+ * Hann(V) window are skipped), plan[5] = chain calls of this context re-run on the event schedule after a
+ * hand-off timeout so far, plan[6] = 1 for the device-synchronised form (ONE range-Doppler
  * launch and ONE angle launch per call, handing frames over through counters in device memory; plan[1] is then the
  * whole batch), plan[7] = frames in its ring of range-Doppler cubes.  bench.py derives its bytes-per-launch from
  * this instead of restating the rule. */

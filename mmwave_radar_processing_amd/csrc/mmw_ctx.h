@@ -65,6 +65,13 @@ struct CztPlan {
     void *d_segs = nullptr, *d_tabs = nullptr;
 };
 
+// a device-synchronised chain call whose hand-off has not been checked yet (mmw_chain_settle re-runs it if it was aborted)
+struct ChainCall {
+    const void *d_cubes;
+    void *d_out;
+    int ntx, nrx, n_frames, V, S, C, A, flags;
+};
+
 struct PendingSpan {
     const char *family;
     hipEvent_t e0, e1;
@@ -91,6 +98,9 @@ struct mmw_ctx {
     unsigned chain_rd_base = 0, chain_ang_base = 0;
     long chain_layout[6] = {0, 0, 0, 0, 0, 0};   // V, S*C, vskip, ring, tiles, ring base address
     bool chain_dirty = false;                // sync-mode work was enqueued since the abort word was last checked
+    std::vector<mmw::ChainCall> chain_calls; // ... these calls
+    int chain_fallbacks = 0;                 // calls re-run on the event schedule after a hand-off timeout
+    bool chain_settling = false;             // inside mmw_chain_settle (its own entry-point calls must not recurse)
     bool rd_attr_set = false;    // hipFuncSetAttribute(max dynamic LDS) done for this context's device
     bool pipe_pending = false;   // chain work in flight on q_rd/q_ang that the context stream has not joined yet
     hipEvent_t t0 = nullptr, t1 = nullptr;      // mmw_timer_*
@@ -170,12 +180,17 @@ template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **
 // Order the context stream after any overlapped-chain work still running on the two chain queues.  The
 // chain does not do this itself so that back-to-back mmw_chain3d calls keep the RD || angle pipeline full;
 // every other entry point that touches the context stream calls it first.
+int chain_settle(mmw_ctx *ctx);     // mmwgpu.hip
 inline int join_pipe(mmw_ctx *ctx) {
     MMW_HIP(hipSetDevice(ctx->device));     // several contexts (devices) may live in one process
-    if (!ctx->pipe_pending) return MMW_OK;
-    for (int i = 0; i < PIPE_RING_MAX; ++i)
-        if (ctx->pipe_ang_used[i]) MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_ang[i], 0));
-    ctx->pipe_pending = false;
+    if (ctx->pipe_pending) {
+        for (int i = 0; i < PIPE_RING_MAX; ++i)
+            if (ctx->pipe_ang_used[i]) MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_ang[i], 0));
+        ctx->pipe_pending = false;
+    }
+    // Device-synchronised chain calls are checked (and, had their hand-off timed out, re-run) before anything else of
+    // this context consumes or downloads their output: one host synchronisation behind a batch of chain calls.
+    if (ctx->chain_dirty && !ctx->chain_settling) return chain_settle(ctx);
     return MMW_OK;
 }
 #define MMW_JOIN(ctx) MMW_TRY(mmw::join_pipe(ctx))

@@ -8,8 +8,10 @@
 #include "mmw_detect.h"
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <cstdlib>
+#include <thread>
 
 using namespace mmw;
 
@@ -195,19 +197,7 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
 int mmw_sync(mmw_ctx *ctx) {
     MMW_REQUIRE(ctx, "ctx is null");
     MMW_JOIN(ctx);
-    MMW_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->chain_dirty) {
-        // did a bounded spin of the device-synchronised chain give up?  (never expected; results would be incomplete)
-        unsigned aborted = 0;
-        MMW_HIP(hipMemcpy(&aborted, ctx->chain_ctl + CTL_ABORT, sizeof(unsigned), hipMemcpyDeviceToHost));
-        ctx->chain_dirty = false;
-        if (aborted) {
-            ctx->chain_layout[0] = 0;       // counters are inconsistent: the next call starts a fresh layout
-            return set_error(MMW_ERR_HIP, "chain hand-off timed out on the device (output incomplete): the range-Doppler and angle "
-                             "launches of the device-synchronised chain must run concurrently -- a tool that serialises kernel "
-                             "dispatches (e.g. rocprofv3 --pmc) needs MMW_CHAIN_MODE=events");
-        }
-    }
+    MMW_HIP(hipStreamSynchronize(ctx->stream));     // (MMW_JOIN above has settled any device-synchronised chain call)
     return MMW_OK;
 }
 
@@ -802,30 +792,103 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
 // INTEGRATION.md.)
 static std::mutex g_sync_mu;
 static mmw_ctx *g_sync_owner[64] = {};
+static bool g_sync_launching[64] = {};      // the owner is between acquire and the recording of its completion events
 static bool sync_slot_acquire(mmw_ctx *ctx) {
     if (ctx->device < 0 || ctx->device >= 64) return true;
     std::lock_guard<std::mutex> lock(g_sync_mu);
     mmw_ctx *&owner = g_sync_owner[ctx->device];
     if (owner && owner != ctx) {
-        // still running?  (its last device-synchronised call recorded pipe_ang[0] / [1] behind the two launches)
-        bool busy = false;
-        for (int i = 0; i < 2; ++i)
+        // still launching, or still running?  (its last device-synchronised call recorded pipe_ang[0] / [1] behind the two
+        // launches, under this mutex: sync_slot_launched)
+        bool busy = g_sync_launching[ctx->device];
+        for (int i = 0; i < 2 && !busy; ++i)
             if (owner->pipe_ang_used[i] && owner->pipe_ang[i] && hipEventQuery(owner->pipe_ang[i]) == hipErrorNotReady) busy = true;
         (void)hipGetLastError();
         if (busy) return false;
     }
     owner = ctx;
+    g_sync_launching[ctx->device] = true;
+    if (const int ms = env_int("MMW_SYNC_SLOT_TEST_SLEEP_MS", 0)) {      // test hook: widen the window between acquire and launch
+        g_sync_mu.unlock();
+        std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+        g_sync_mu.lock();
+    }
     return true;
+}
+// the owner's launches are enqueued (or have failed): record the completion events under the mutex, end the launch window
+static int sync_slot_launched(mmw_ctx *ctx, bool record) {
+    std::lock_guard<std::mutex> lock(g_sync_mu);
+    if (ctx->device >= 0 && ctx->device < 64 && g_sync_owner[ctx->device] == ctx) g_sync_launching[ctx->device] = false;
+    if (record) {
+        MMW_HIP(hipEventRecord(ctx->pipe_ang[0], ctx->q_ang));
+        MMW_HIP(hipEventRecord(ctx->pipe_ang[1], ctx->q_rd));
+        ctx->pipe_ang_used[0] = ctx->pipe_ang_used[1] = true;
+        for (int i = 2; i < PIPE_RING_MAX; ++i) ctx->pipe_ang_used[i] = false;
+    }
+    return MMW_OK;
 }
 static void sync_slot_forget(mmw_ctx *ctx) {
     std::lock_guard<std::mutex> lock(g_sync_mu);
-    for (auto &o : g_sync_owner)
-        if (o == ctx) o = nullptr;
+    for (int d = 0; d < 64; ++d)
+        if (g_sync_owner[d] == ctx) {
+            g_sync_owner[d] = nullptr;
+            g_sync_launching[d] = false;
+        }
 }
+
+static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_rd, void *d_out, int n_frames, int V, int S, int C,
+                        int A, int flags, bool allow_sync = true);
+
+// Have the device-synchronised chain calls enqueued since the last check completed?  Waits for them, reads the abort
+// word and, if a bounded spin gave up (the two launches of a call did not run side by side: a tool that serialises kernel
+// dispatches such as rocprofv3 --pmc, another process holding the CUs ...), resets the hand-off state and RE-RUNS the
+// affected calls on the event schedule -- same kernels as the serial schedule, no device-side waiting -- so that the
+// outputs the caller is about to read are complete.  MMW_CHAIN_NO_RERUN=1: report the timeout instead (MMW_ERR_HIP).
+extern "C++" {
+namespace mmw {
+int chain_settle(mmw_ctx *ctx) {
+    if (!ctx->chain_dirty) return MMW_OK;
+    ctx->chain_settling = true;
+    struct Done {
+        mmw_ctx *c;
+        ~Done() { c->chain_settling = false; }
+    } done{ctx};
+    if (ctx->q_rd) {
+        MMW_HIP(hipStreamSynchronize(ctx->q_rd));
+        MMW_HIP(hipStreamSynchronize(ctx->q_ang));
+    }
+    MMW_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned aborted = 0;
+    MMW_HIP(hipMemcpy(&aborted, ctx->chain_ctl + CTL_ABORT, sizeof(unsigned), hipMemcpyDeviceToHost));
+    ctx->chain_dirty = false;
+    std::vector<ChainCall> calls;
+    calls.swap(ctx->chain_calls);
+    if (!aborted) return MMW_OK;
+    // counters are inconsistent (aborted workgroups leave without drawing their past-the-end ticket): fresh layout
+    MMW_HIP(hipMemset(ctx->chain_ctl, 0, CTL_WORDS * sizeof(unsigned)));
+    ctx->chain_layout[0] = 0;
+    if (env_int("MMW_CHAIN_NO_RERUN", 0))
+        return set_error(MMW_ERR_HIP, "chain hand-off timed out on the device (output incomplete): the range-Doppler and angle "
+                         "launches of the device-synchronised chain must run concurrently -- a tool that serialises kernel "
+                         "dispatches (e.g. rocprofv3 --pmc) needs MMW_CHAIN_MODE=events");
+    for (const ChainCall &c : calls) {
+        MMW_TRY(chain3d_impl(ctx, c.d_cubes, RawView{c.ntx, c.nrx}, nullptr, c.d_out, c.n_frames, c.V, c.S, c.C, c.A, c.flags, false));
+        ++ctx->chain_fallbacks;
+    }
+    if (ctx->pipe_pending) {
+        for (int i = 0; i < PIPE_RING_MAX; ++i)
+            if (ctx->pipe_ang_used[i]) MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_ang[i], 0));
+        ctx->pipe_pending = false;
+    }
+    MMW_HIP(hipStreamSynchronize(ctx->stream));
+    return MMW_OK;
+}
+}  // namespace mmw
+}  // extern "C++"
 
 // One RD launch + one angle launch for the whole call, synchronised through device counters (ChainSync).
 static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes, RawView rv, void *d_out, int n_frames, int V,
-                        int S, int C, int flags) {
+                        int S, int C, int A_bins, int flags) {
     const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
     const long bins = (long)S * C;
     const bool mag_out = (flags & MMW_ANGLE_MAGNITUDE) != 0;
@@ -864,7 +927,7 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     cs.v_live = v_live;
     cs.tiles = tiles;
     cs.n_frames = n_frames;
-    cs.timeout = (unsigned long long)tune_int("MMW_CHAIN_TIMEOUT_MS", 2000) * 100000ull;      // 100 MHz ticks
+    cs.timeout = (unsigned long long)std::max(1, env_int("MMW_CHAIN_TIMEOUT_MS", 2000)) * 100000ull;      // 100 MHz ticks
     // order of the RD work items inside a frame: plain cubes by antenna; raw cubes rx-major, so that the ntx planes that
     // de-interleave the same raw rows are handed out back to back (their second and third read come from cache)
     {
@@ -903,7 +966,9 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     ctx->chain_rd_base += (unsigned)(n_rd_items + rd_grid);       // every workgroup draws one ticket past the end
     ctx->chain_ang_base += (unsigned)(n_ang_items + ang_grid);
     int rc;
-    {
+    if (env_int("MMW_CHAIN_DIAG_SKIP_RD", 0)) {
+        rc = MMW_OK;        // diagnostics: no producer -- the consumer's bounded spin must give up (tests of the abort path)
+    } else {
         ctx->stream = ctx->q_rd;
         ProfScope ps(ctx, "rd");
         if (fused) rc = launch_rd_fused_sync(ctx, d_cubes, ctx->scratch, n_rd_items, cs, rd_grid);
@@ -922,20 +987,19 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     ctx->stream = main_stream;
     if (rc != MMW_OK) {
         // a launch failed: the counters no longer match the host mirror; drain and force a fresh layout next time
+        (void)sync_slot_launched(ctx, false);
         (void)hipStreamSynchronize(ctx->q_rd);
         (void)hipStreamSynchronize(ctx->q_ang);
         ctx->chain_layout[0] = 0;
         return rc;
     }
-    MMW_HIP(hipEventRecord(ctx->pipe_ang[0], ctx->q_ang));
-    MMW_HIP(hipEventRecord(ctx->pipe_ang[1], ctx->q_rd));
-    ctx->pipe_ang_used[0] = ctx->pipe_ang_used[1] = true;
-    for (int i = 2; i < PIPE_RING_MAX; ++i) ctx->pipe_ang_used[i] = false;
+    MMW_TRY(sync_slot_launched(ctx, true));
+    ctx->chain_calls.push_back(ChainCall{d_cubes, d_out, rv.ntx, rv.nrx, n_frames, V, S, C, A_bins, flags});
     return MMW_OK;
 }
 
-static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_rd, void *d_out, int n_frames, int V,
-                        int S, int C, int A, int flags) {
+static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_rd, void *d_out, int n_frames, int V, int S, int C,
+                        int A, int flags, bool allow_sync) {
     const int magnitude = flags & MMW_ANGLE_MAGNITUDE;
     MMW_REQUIRE(ctx && d_cubes && d_out, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad shape (need A >= V)");
@@ -943,7 +1007,8 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
     MMW_HIP(hipSetDevice(ctx->device));
     const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
     const size_t out_frame_bytes = (size_t)A * S * C * (magnitude ? sizeof(float) : sizeof(cplx<float>));
-    ChainPlan plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags);
+    ChainPlan plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags, allow_sync);
+    if (plan.sync && ctx->chain_calls.size() >= 256) MMW_TRY(chain_settle(ctx));     // bound the unchecked backlog
     if (plan.sync && !sync_slot_acquire(ctx))       // another context of this process has synchronised work in flight here
         plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags, false);
     rv.vskip = plan.vskip;
@@ -951,7 +1016,8 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
     const int ring = plan.ring, rd_cus = plan.rd_cus;
     int chunk = plan.chunk;
     if (plan.sync) {
-        const int rc = chain3d_sync(ctx, plan, d_cubes, rv, d_out, n_frames, V, S, C, flags);
+        const int rc = chain3d_sync(ctx, plan, d_cubes, rv, d_out, n_frames, V, S, C, A, flags);
+        if (rc != MMW_OK) (void)sync_slot_launched(ctx, false);         // (whatever the exit path: end the launch window)
         if (rc != MMW_ERR_UNSUPPORTED) return rc;          // queues unavailable: the serial schedule below
         chunk = std::min(n_frames, 1024);
     }
@@ -1832,7 +1898,7 @@ int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, 
     plan[2] = p.ring;
     plan[3] = p.rd_cus;
     plan[4] = p.vskip > 2 ? V - 2 : V;      // range-Doppler planes transformed per frame
-    plan[5] = 0;
+    plan[5] = ctx->chain_fallbacks;      // chain calls re-run on the event schedule after a hand-off timeout (mmw_chain_settle)
     plan[6] = p.sync;
     plan[7] = p.sync ? p.ring_frames : 0;
     return MMW_OK;

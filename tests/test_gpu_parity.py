@@ -1369,12 +1369,17 @@ def test_split_range_doppler_kernel_for_planes_beyond_the_lds(S, C, monkeypatch)
         b.free()
 
 
-def test_two_contexts_on_one_device_share_the_synchronised_chain():
+@pytest.mark.parametrize("acquire_sleep_ms", [0, 30])
+def test_two_contexts_on_one_device_share_the_synchronised_chain(acquire_sleep_ms, monkeypatch):
     """Two contexts of one process on the SAME device, each driving large batches through mmw_chain3d from its own thread.
     Only one context at a time may keep the two persistent kernels of the device-synchronised schedule resident
     (sync_slot_acquire in mmwgpu.hip); the other takes the event schedule for that call.  Both must finish without the
-    hand-off timing out and produce the single-context result."""
+    hand-off timing out and produce the single-context result.  Second case: a sleep between a context's acquire and its
+    launches (test hook) -- the other thread arrives inside that window and must still be turned away (the slot
+    used to look free until the owner had recorded its events); no call may have needed the timeout re-run."""
     import threading
+    if acquire_sleep_ms:
+        monkeypatch.setenv("MMW_SYNC_SLOT_TEST_SLEEP_MS", str(acquire_sleep_ms))
     S, C, V, A, F = 256, 128, 12, 64, 300
     base = _lib.default_context()
     ctxs = [_lib.Context(base.device) for _ in range(2)]
@@ -1401,6 +1406,10 @@ def test_two_contexts_on_one_device_share_the_synchronised_chain():
         t.join()
     assert not errs, errs
     assert cross_schedule_dev(outs[0], outs[1]) <= CROSS_SCHEDULE_TOL
+    for c in ctxs:
+        p = (_lib.C.c_int * 8)()
+        _lib.check(c.lib.mmw_diag_chain_plan(c.handle, F, V, S, C, A, 0, p))
+        assert p[5] == 0, "a chain call timed out and was re-run: two contexts held the synchronised schedule at once"
     d_in = base.alloc(V * S * C * 8)
     _lib.check(base.lib.mmw_synth_cubes(base.handle, d_in.ptr, 1, V, S, C, 31337, 8, 30.0))
     cube0 = d_in.download((V, S, C), np.complex64)
@@ -1677,3 +1686,69 @@ def test_detect_points_edge_cases_and_pipeline_fallback(monkeypatch):
             np.testing.assert_array_equal(pipe.az_idx[f], az_i)
             np.testing.assert_array_equal(pipe.el_idx[f], el_i)
             np.testing.assert_allclose(pcs[f], pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
+
+
+def test_chain_handoff_timeout_is_detected_and_rerun(monkeypatch):
+    """The device-synchronised chain with its producer withheld (diagnostic hook): the consumer's bounded spin gives up,
+    the next host-synchronising entry point notices, resets the hand-off state and re-runs the call on the event
+    schedule -- the downloaded cube is the serial schedule's; with MMW_CHAIN_NO_RERUN=1 the download raises instead; the
+    context keeps working either way (a timed-out run used to return an incomplete cube with status 0)."""
+    import time
+    ctx = _lib.Context(0)
+    F, V, S, C, A = 96, 12, 256, 128, 64
+    d_in, d_out = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * A * S * C * 8)
+    _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 5150, 8, 30.0))
+
+    def chain():
+        _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+
+    def plan():
+        p = (_lib.C.c_int * 8)()
+        _lib.check(ctx.lib.mmw_diag_chain_plan(ctx.handle, F, V, S, C, A, 0, p))
+        return list(p)
+
+    picks = (0, 47, 95)
+    fetch = lambda: [d_out.download((A, S, C), np.complex64, f * A * S * C * 8) for f in picks]
+    monkeypatch.setenv("MMW_CHAIN_PIPELINE", "0")
+    chain()
+    ref = fetch()
+    monkeypatch.setenv("MMW_CHAIN_PIPELINE", "1")
+    monkeypatch.setenv("MMW_CHAIN_TIMEOUT_MS", "20")
+    assert plan()[6] == 1 and plan()[5] == 0                    # device-synchronised form, nothing re-run so far
+    # 1. producer withheld: the call itself returns at once, the sync settles it
+    d_out.zero()
+    monkeypatch.setenv("MMW_CHAIN_DIAG_SKIP_RD", "1")
+    chain()
+    monkeypatch.delenv("MMW_CHAIN_DIAG_SKIP_RD")
+    t0 = time.perf_counter()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    assert plan()[5] == 1, "the timed-out call was not re-run"
+    got = fetch()
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) <= 1e-6
+    print(f"hand-off timeout detected and call re-run on the event schedule in {dt * 1e3:.0f} ms")
+    assert dt < 2.0
+    # 2. the very next device-synchronised call on the same context is fine (fresh ring layout)
+    d_out.zero()
+    chain()
+    got = fetch()
+    assert plan()[5] == 1
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) <= 1e-6
+    # 3. no automatic re-run: the fetch path reports the timeout (it used to hand back an incomplete cube with status 0)
+    monkeypatch.setenv("MMW_CHAIN_NO_RERUN", "1")
+    monkeypatch.setenv("MMW_CHAIN_DIAG_SKIP_RD", "1")
+    d_out.zero()
+    chain()
+    monkeypatch.delenv("MMW_CHAIN_DIAG_SKIP_RD")
+    with pytest.raises(_lib.MmwGpuError, match="timed out"):
+        d_out.download((A, S, C), np.complex64, 0)
+    monkeypatch.delenv("MMW_CHAIN_NO_RERUN")
+    chain()
+    got = fetch()
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) <= 1e-6
+    d_in.free()
+    d_out.free()
+    ctx.close()
