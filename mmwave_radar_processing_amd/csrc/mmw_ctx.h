@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -115,7 +116,7 @@ struct mmw_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     std::vector<void *> owned;  // mmw_malloc'ed blocks still alive (freed at destroy)
-    std::vector<mmw::CztPlan> czt_plans;
+    std::deque<mmw::CztPlan> czt_plans;         // (deque: pointers to cached plans survive later insertions)
 };
 
 namespace mmw {

@@ -142,15 +142,20 @@ inline int czt_plan(mmw_ctx *ctx, const double *freq, int M, int n_used, const C
         if (p.d_segs) (void)hipFree(p.d_segs);
         return set_error(MMW_ERR_NOMEM, "hipMalloc for chirp-z tables failed");
     }
-    MMW_HIP(hipMemcpyAsync(p.d_segs, segs.data(), seg_bytes, hipMemcpyHostToDevice, ctx->stream));
-    MMW_HIP(hipMemcpyAsync(p.d_tabs, tabs.data(), tab_bytes, hipMemcpyHostToDevice, ctx->stream));
-    MMW_HIP(hipStreamSynchronize(ctx->stream));         // the staging vectors die with this scope
+    hipError_t e = hipMemcpyAsync(p.d_segs, segs.data(), seg_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p.d_tabs, tabs.data(), tab_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);        // the staging vectors die with this scope
+    if (e != hipSuccess) {                                              // nothing of a half-built plan stays allocated
+        (void)hipFree(p.d_segs);
+        (void)hipFree(p.d_tabs);
+        return set_error(MMW_ERR_HIP, "upload of the chirp-z tables failed: %s", hipGetErrorString(e));
+    }
     if (ctx->czt_plans.size() >= 8) {
         (void)hipFree(ctx->czt_plans.front().d_segs);   // the stream was just drained: nothing uses the oldest plan
         (void)hipFree(ctx->czt_plans.front().d_tabs);
-        ctx->czt_plans.erase(ctx->czt_plans.begin());
+        ctx->czt_plans.pop_front();
     }
-    ctx->czt_plans.push_back(std::move(p));
+    ctx->czt_plans.push_back(std::move(p));             // (a deque: plans handed out earlier stay where they are)
     *out = &ctx->czt_plans.back();
     return MMW_OK;
 }

@@ -1,7 +1,7 @@
 """Coarse range profile (reference: mmwave_radar_processing/processors/range_resp.py:8-57,153-164).
 
-Only the FFT hot path is accelerated; the reference's ZoomFFT / scipy peak
-picking (:59-150) belongs to the altimeter path that SURVEY.md marks out of scope.
+The FFT and the ZoomFFT (:59-102, as a chirp-z transform) run on the device; the scipy peak picking (:104-149) that
+``Altimeter`` builds on stays on the host, as in the reference.
 """
 from __future__ import annotations
 

@@ -76,3 +76,30 @@ def synth_raw_cube(seed: int, num_rx: int = 4, num_tx: int = 3, num_samples: int
     for t in range(num_tx):
         raw[:, :, t::num_tx] = virt[t * num_rx:(t + 1) * num_rx]
     return raw
+
+
+def synth_ground_sequence(seed: int, n_frames: int = 5, shape=(12, 256, 128), range_res_m: float = 0.0975887,
+                          altitude0_m: float = 1.02, climb_m: float = 0.07, ground_amp: float = 350.0,
+                          num_clutter: int = 3, noise_sigma: float = 30.0) -> np.ndarray:
+    """``[n_frames, V, S, C]`` cubes of a platform over flat ground: one strong return whose range grows by ``climb_m``
+    per frame (what ``Altimeter`` tracks), spread over a few Doppler lines, plus ``num_clutter`` weaker point targets
+    farther out and complex Gaussian noise; integer-valued complex64 like ``synth_cube``."""
+    V, S, C = shape
+    rng = np.random.default_rng(seed)
+    v = np.arange(V)[:, None, None]
+    n = np.arange(S)[None, :, None]
+    m = np.arange(C)[None, None, :]
+    cubes = np.empty((n_frames,) + tuple(shape), dtype=np.complex64)
+    for f in range(n_frames):
+        x = np.zeros(shape, dtype=np.complex128)
+        alt = altitude0_m + climb_m * f
+        for dv, a in ((-0.06, 0.5), (0.0, 1.0), (0.05, 0.6)):          # ground patch: a few Doppler lines
+            fr = alt / range_res_m / S
+            x += a * ground_amp * np.exp(1j * (2.0 * np.pi * (fr * n + dv * m + 0.02 * v) + rng.uniform(0, 2 * np.pi)))
+        for _ in range(num_clutter):
+            fr = rng.uniform(2.5, 9.0) / range_res_m / S
+            x += rng.uniform(30.0, 120.0) * np.exp(1j * (2.0 * np.pi * (fr * n + rng.uniform(-0.4, 0.4) * m +
+                                                                        rng.uniform(-0.3, 0.3) * v) + rng.uniform(0, 2 * np.pi)))
+        x += noise_sigma * (rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
+        cubes[f] = (np.rint(x.real) + 1j * np.rint(x.imag)).astype(np.complex64)
+    return cubes

@@ -430,6 +430,114 @@ def rd_detect_2d(cube, num_train=(4, 4), num_guard=(2, 2), pfa=1e-5):
     return raw, mag, d, thr, noise
 
 
+def rd_detect_2d_os(cube, num_train=(5, 5), num_guard=(3, 2), rho=0.7, alpha=2.0):
+    """RangeDopplerDetector2D(cfar_type="os_cfar_2d") -- range_doppler_detector_2d.py:49-65 with detectors/os_cfar.py:97-195
+    (the parameters of gui_configs/processor_params.yaml:40-47) -> dets int64 (N, 2)."""
+    mag = np.abs(range_doppler(cube)[0])
+    dets = os_cfar_2d(mag, num_train, num_guard, rho, alpha)[2]
+    return np.array(dets, dtype=int) if dets else np.empty((0, 2), dtype=int)
+
+
+_CFAR_1D = {"ca_cfar_1d": lambda x, p: ca_cfar_1d(x, p["num_train"], p["num_guard"], p["pfa"]),
+            "go_cfar_1d": lambda x, p: go_cfar_1d(x, p["num_train"], p["num_guard"], p["pfa"]),
+            "so_cfar_1d": lambda x, p: so_cfar_1d(x, p["num_train"], p["num_guard"], p["pfa"]),
+            "os_cfar_1d": lambda x, p: os_cfar_1d(x, p["num_train"], p["num_guard"], p["rho"], p["alpha"])}
+
+
+def cfar_1d(kind, x, params):
+    """detectors/detector_registry.py:15-27 keys -> detection index list."""
+    return _CFAR_1D[kind](x, params)[2]
+
+
+def _rows_to_dets(mag, rows, vel_kind, vel_params):
+    dets = [(int(r), int(d)) for r in rows for d in cfar_1d(vel_kind, mag[r, :], vel_params)]
+    return np.array(dets, dtype=int) if dets else np.empty((0, 2), dtype=int)
+
+
+def rd_detect_sequential(cube, rng_kind, rng_params, vel_kind, vel_params):
+    """RangeDopplerDetectorSequential.process -- range_doppler_detector_sequential.py:72-107: 1-D CFAR on the chirp-0
+    range profile, then 1-D CFAR along Doppler on |RD| of antenna 0 in every detected range row."""
+    rows = cfar_1d(rng_kind, range_profile(cube, 0), rng_params)
+    return _rows_to_dets(np.abs(range_doppler(cube)[0]), rows, vel_kind, vel_params)
+
+
+def find_peaks_db(resp_db, bins, max_peaks=3, threshold_db=20):
+    """RangeProcessor.find_peaks -- processors/range_resp.py:104-149 (scipy.signal.find_peaks, prominence 6 dB; peaks
+    within threshold_db of the strongest; strongest first; at most max_peaks)."""
+    from scipy.signal import find_peaks
+    peaks, _ = find_peaks(resp_db, prominence=6)
+    if len(peaks) == 0:
+        return np.array([]), np.array([])
+    vals = resp_db[peaks]
+    keep = vals >= (np.max(vals) - threshold_db)
+    peaks, vals = peaks[keep], vals[keep]
+    top = peaks[np.argsort(vals)[::-1]][:max_peaks]
+    return bins[top], resp_db[top]
+
+
+class Altimeter:
+    """processors/altimeter.py:6-140 -- STATEFUL (last-altitude gate): one instance per frame sequence."""
+
+    def __init__(self, sc, min_altitude_m, zoom_search_region_m, altitude_search_limit_m, range_bias=0.0, **_):
+        self.sc = sc
+        self.range_bins = np.arange(start=0, step=sc["range_res_m"], stop=sc["range_max_m"] - sc["range_res_m"] / 2)
+        self.min_altitude_m = float(min_altitude_m)                       # :23-27
+        self.zoom_search_region_m = float(zoom_search_region_m)
+        self.altitude_search_limit_m = float(altitude_search_limit_m)
+        self.range_bias = float(range_bias)
+        self.current_altitude_measured_m = self.min_altitude_m            # :34-35
+        self.current_altitude_corrected_m = self.min_altitude_m
+
+    def reset(self):                                                      # :37-40 (the corrected value is NOT reset)
+        self.current_altitude_measured_m = self.min_altitude_m
+
+    def find_ground_peak(self, peaks_m):                                  # :42-65
+        if peaks_m.size > 0:
+            valid = peaks_m[(peaks_m >= self.min_altitude_m) &
+                            (np.abs(peaks_m - self.current_altitude_measured_m) <= self.altitude_search_limit_m)]
+            if valid.size > 0:
+                return np.min(valid)
+        return -1.0
+
+    def process(self, cube, precise_est_enabled=True, **_):               # :104-140
+        coarse = range_profile(cube, 0)
+        peaks, _ = find_peaks_db(20 * np.log10(coarse), self.range_bins, max_peaks=3)
+        if peaks.size == 0:
+            return self.current_altitude_corrected_m
+        ground = self.find_ground_peak(peaks)
+        if ground < 0:
+            return self.current_altitude_corrected_m
+        if not precise_est_enabled:
+            self.current_altitude_measured_m = ground
+            self.current_altitude_corrected_m = ground + self.range_bias
+            return self.current_altitude_corrected_m
+        lo = max(1e-6, ground - self.zoom_search_region_m)                # :82-88
+        hi = min(np.max(self.range_bins) - 1e-6, ground + self.zoom_search_region_m)
+        zoom, zbins = range_zoom(cube, self.sc, lo, hi, 0)
+        zp, _ = find_peaks_db(20 * np.log10(zoom), zbins, max_peaks=2)
+        refined = self.find_ground_peak(zp) if zp.size > 0 else -1.0
+        if refined > 0:
+            self.current_altitude_measured_m = refined
+            self.current_altitude_corrected_m = refined + self.range_bias
+        return self.current_altitude_corrected_m
+
+
+def rd_ground_gate(range_bins, altitude_m):
+    """Range rows between the altitude and the 60-degree slant range -- range_doppler_ground_detector.py:91-107."""
+    lo = int(np.argmin(np.abs(range_bins - altitude_m)))
+    max_rng = min(np.max(range_bins), altitude_m / np.cos(np.deg2rad(60)))
+    hi = int(np.argmin(np.abs(range_bins - max_rng)))
+    return np.array([lo]) if hi == lo else np.arange(lo, hi + 1)
+
+
+def rd_detect_ground(cube, altimeter, sc, vel_kind, vel_params, altimeter_params):
+    """RangeDopplerGroundDetector.process -- range_doppler_ground_detector.py:72-127 (the detector's own range_bins are
+    RangeDopplerProcessor's: range_doppler_resp.py:33-47)."""
+    altitude = altimeter.process(cube, **altimeter_params)
+    rows = rd_ground_gate(rd_bins(sc)[0], altitude)
+    return _rows_to_dets(np.abs(range_doppler(cube)[0]), rows, vel_kind, vel_params), altitude
+
+
 # --------------------------------------------------------------------------
 # a15/a16  PointCloudGenerator -- processors/point_cloud_generator.py:108-248
 # --------------------------------------------------------------------------

@@ -31,6 +31,8 @@ from mmwave_radar_processing.processors.range_doppler_resp import RangeDopplerPr
 from mmwave_radar_processing.processors.range_angle_resp import RangeAngleProcessor     # noqa: E402
 from mmwave_radar_processing.processors.range_angle_resp_dbs_enhanced import RangeAngleProcessorDBSEnhanced  # noqa: E402
 from mmwave_radar_processing.processors.range_doppler_detection.range_doppler_detector_2d import RangeDopplerDetector2D  # noqa: E402
+from mmwave_radar_processing.processors.range_doppler_detection.range_doppler_detector_sequential import RangeDopplerDetectorSequential  # noqa: E402
+from mmwave_radar_processing.processors.range_doppler_detection.range_doppler_ground_detector import RangeDopplerGroundDetector  # noqa: E402
 from mmwave_radar_processing.processors.point_cloud_generator import PointCloudGenerator  # noqa: E402
 from mmwave_radar_processing.processors.simple_synthetic_array_beamformer_processor_multiFrame import SyntheticArrayBeamformerProcessor  # noqa: E402
 from mmwave_radar_processing.processors.doppler_azimuth_resp import DopplerAzimuthProcessor      # noqa: E402
@@ -284,9 +286,71 @@ def gen_doppler_azimuth():
     print("doppler_azimuth.npz:", {k: v.shape for k, v in d.items()})
 
 
+# detector parameters of the reference's shipped GUI config (gui_configs/processor_params.yaml:40-86)
+YAML_OS2D = {"num_train": [5, 5], "num_guard": [3, 2], "rho": 0.7, "alpha": 2}
+YAML_SEQ = dict(rng_cfar_type="os_cfar_1d", rng_cfar_params={"num_train": 5, "num_guard": 3, "rho": 0.6, "alpha": 2},
+                vel_cfar_type="os_cfar_1d", vel_cfar_params={"num_train": 5, "num_guard": 2, "rho": 0.7, "alpha": 3})
+GOSO_SEQ = dict(rng_cfar_type="go_cfar_1d", rng_cfar_params={"num_train": 8, "num_guard": 2, "pfa": 1e-3},
+                vel_cfar_type="so_cfar_1d", vel_cfar_params={"num_train": 6, "num_guard": 2, "pfa": 1e-4})
+YAML_GROUND = dict(vel_cfar_type="os_cfar_1d", vel_cfar_params={"num_train": 12, "num_guard": 4, "rho": 0.5, "alpha": 15},
+                   altimeter_params={"min_altitude_m": 0.25, "zoom_search_region_m": 0.2, "altitude_search_limit_m": 0.4,
+                                     "range_bias": 0.0, "precise_est_enabled": False})
+COARSE_GROUND = dict(vel_cfar_type="os_cfar_1d", vel_cfar_params={"num_train": 12, "num_guard": 4, "rho": 0.5, "alpha": 6},
+                     altimeter_params={"min_altitude_m": 0.6, "zoom_search_region_m": 0.2, "altitude_search_limit_m": 0.6,
+                                       "range_bias": 0.0, "precise_est_enabled": False})
+PRECISE_GROUND = dict(vel_cfar_type="os_cfar_1d", vel_cfar_params={"num_train": 16, "num_guard": 4, "rho": 0.5, "alpha": 12},
+                      altimeter_params={"min_altitude_m": 0.6, "zoom_search_region_m": 0.2, "altitude_search_limit_m": 0.6,
+                                        "range_bias": 0.03, "precise_est_enabled": True})
+
+
+def gen_detectors_rd():
+    """The detectors the reference's shipped YAMLs actually use, run by the reference on range-Doppler data:
+    RangeDopplerDetectorSequential, RangeDopplerDetector2D with os_cfar_2d, RangeDopplerGroundDetector (stateful, over a
+    5-frame sequence), PointCloudGenerator on the ground detector, and the 3-D chain on cubes with a non-finite sample."""
+    d = {}
+    cm = load_cm(synth.SYNTH_CFG_256x128x12)
+    with open(os.path.join(REF, "configs", "6843_RadVel_ods_20Hz.cfg")) as f:
+        cm2 = load_cm(f.read())
+    cases = [(f"s{s}", cm, synth.synth_cube(s)) for s in (0, 1, 2, 3)] + [("np2", cm2, synth.synth_cube(202, (12, 63, 70)))]
+    for tag, c, cube in cases:
+        d[f"{tag}_seq_yaml"] = RangeDopplerDetectorSequential(c, **YAML_SEQ).process(cube)
+        d[f"{tag}_seq_goso"] = RangeDopplerDetectorSequential(c, **GOSO_SEQ).process(cube)
+        d[f"{tag}_os2d_yaml"] = RangeDopplerDetector2D(c, cfar_type="os_cfar_2d", cfar_params=YAML_OS2D).process(cube)
+    # ground detector: stateful over the sequence; then reset() and the first two frames again
+    seq = synth.synth_ground_sequence(606, 5)
+    for name, params in (("yaml", YAML_GROUND), ("coarse", COARSE_GROUND), ("precise", PRECISE_GROUND)):
+        det = RangeDopplerGroundDetector(cm, **params)
+        alts = []
+        for f in range(seq.shape[0]):
+            d[f"ground_{name}_f{f}"] = det.process(seq[f])
+            alts.append(det.altimeter.current_altitude_corrected_m)
+        d[f"ground_{name}_alt"] = np.array(alts)
+        det.reset()
+        d[f"ground_{name}_after_reset_f3"] = det.process(seq[3])
+        d[f"ground_{name}_after_reset_alt"] = np.array(det.altimeter.current_altitude_corrected_m)
+    pcg = PointCloudGenerator(cm, az_antenna_idxs=[0, 3, 4, 7], el_antenna_idxs=[9, 8, 5, 4],
+                              detector_type="range_doppler_ground_detector", detector_params=PRECISE_GROUND)
+    for f in range(3):
+        d[f"ground_pc_f{f}"] = pcg.process(seq[f])
+    # non-finite samples: an end antenna (Hann weight exactly 0) and a middle one -- where is the 3-D chain's output finite?
+    dbs = RangeAngleProcessorDBSEnhanced(cm)
+    for tag, ant in (("inf_ant0", 0), ("inf_ant5", 5)):
+        cube = synth.synth_cube(3).copy()
+        cube[ant, 17, 9] = np.inf
+        f3 = dbs.compute_3d_windowed_fft(cube)
+        d[f"{tag}_finite_count"] = np.array(int(np.isfinite(f3).sum()))
+        d[f"{tag}_nan_count"] = np.array(int(np.isnan(f3).sum()))
+        d[f"{tag}_size"] = np.array(f3.size)
+    np.savez_compressed(os.path.join(HERE, "detectors_rd.npz"), **d)
+    print("detectors_rd.npz:", {k: (v.shape if v.ndim else v.item()) for k, v in d.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "doppler_azimuth":
         gen_doppler_azimuth()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "detectors_rd":
+        gen_detectors_rd()
         sys.exit(0)
     gen_cfgs()
     gen_small_chain()
@@ -294,3 +358,4 @@ if __name__ == "__main__":
     gen_cfar_known()
     gen_bartlett()
     gen_doppler_azimuth()
+    gen_detectors_rd()

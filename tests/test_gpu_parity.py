@@ -795,7 +795,7 @@ def test_processor_protocol_state_and_registries():
     np.testing.assert_array_equal(r, det.range_bins[[3, 7]])
     np.testing.assert_array_equal(v, det.vel_bins[[5, 1]])
     reg = get_range_doppler_detector_registry()
-    assert set(reg) == {"range_doppler_detector_2d", "range_doppler_detector_sequential"}
+    assert set(reg) == {"range_doppler_detector_2d", "range_doppler_detector_sequential", "range_doppler_ground_detector"}
     # a foreign magnitude map goes through the detector's own host path
     foreign = np.abs(np.random.default_rng(0).standard_normal((32, 16))) * 10
     out = det._detect(cube, foreign)
@@ -1752,3 +1752,111 @@ def test_chain_handoff_timeout_is_detected_and_rerun(monkeypatch):
     d_in.free()
     d_out.free()
     ctx.close()
+
+
+# ---- detectors the reference's shipped YAMLs use, against fixtures generated by the reference itself
+#      (tests/golden/make_golden.py::gen_detectors_rd -> detectors_rd.npz; oracle == fixtures in test_oracle_golden.py)
+from test_oracle_golden import GOSO_SEQ, GROUND, YAML_OS2D, YAML_SEQ, _rd_cases      # noqa: E402
+
+
+def _cm_for(tag):
+    if tag == "np2":
+        with open(os.path.join(GOLDEN, "cfg_scalars.json")) as fh:
+            return make_cm("\n".join(json.load(fh)["6843_RadVel_ods_20Hz.cfg"]["lines"]))
+    return make_cm(synth.SYNTH_CFG_256x128x12)
+
+
+def test_sequential_and_os2d_detectors_match_reference_fixtures():
+    g = np.load(os.path.join(GOLDEN, "detectors_rd.npz"))
+    for tag, _, cube in _rd_cases():
+        cm = _cm_for(tag)
+        for key, (rk, rp, vk, vp) in (("seq_yaml", YAML_SEQ), ("seq_goso", GOSO_SEQ)):
+            det = RangeDopplerDetectorSequential(cm, rng_cfar_type=rk, rng_cfar_params=rp, vel_cfar_type=vk, vel_cfar_params=vp)
+            got = det.process(cube)
+            np.testing.assert_array_equal(got, g[f"{tag}_{key}"])
+            assert got.dtype == g[f"{tag}_{key}"].dtype
+        det2 = RangeDopplerDetector2D(cm, cfar_type="os_cfar_2d",
+                                      cfar_params={"num_train": [5, 5], "num_guard": [3, 2], "rho": 0.7, "alpha": 2})
+        np.testing.assert_array_equal(det2.process(cube), g[f"{tag}_os2d_yaml"])
+    # the batch pipeline with the same OS detector (mask-by-counting kernel) on the four headline frames
+    from mmwave_radar_processing_amd.batch import FramePipeline
+    cm = _cm_for("s0")
+    pipe = FramePipeline(cm, max_frames=4, shape=(12, 256, 128), cfar=OsCFAR2D([5, 5], [3, 2], rho=0.7, alpha=2))
+    pipe.load(np.stack([synth.synth_cube(s) for s in range(4)]))
+    for s, d in enumerate(pipe.detect()):
+        np.testing.assert_array_equal(d, g[f"s{s}_os2d_yaml"])
+
+
+def test_ground_detector_and_altimeter_match_reference_fixtures():
+    """RangeDopplerGroundDetector (stateful Altimeter gate) over the 5-frame sequence, reset(), and through
+    PointCloudGenerator(detector_type="range_doppler_ground_detector") -- detections, altitude track and point clouds of the
+    reference."""
+    from mmwave_radar_processing_amd.processors.range_doppler_detection import RangeDopplerGroundDetector
+    g = np.load(os.path.join(GOLDEN, "detectors_rd.npz"))
+    cm = make_cm(synth.SYNTH_CFG_256x128x12)
+    seq = synth.synth_ground_sequence(606, 5)
+    for name, (vel_kind, vel_params, alt_params) in GROUND.items():
+        det = RangeDopplerGroundDetector(cm, vel_cfar_type=vel_kind, vel_cfar_params=vel_params, altimeter_params=alt_params)
+        track = []
+        for f in range(5):
+            np.testing.assert_array_equal(det.process(seq[f]), g[f"ground_{name}_f{f}"])
+            track.append(det.altimeter.current_altitude_corrected_m)
+        # (zoom bins are a linspace over the search window: the float32 chirp-z transform picks the reference's bin)
+        np.testing.assert_allclose(track, g[f"ground_{name}_alt"], rtol=0, atol=1e-9)
+        det.reset()
+        np.testing.assert_array_equal(det.process(seq[3]), g[f"ground_{name}_after_reset_f3"])
+        np.testing.assert_allclose(det.altimeter.current_altitude_corrected_m, g[f"ground_{name}_after_reset_alt"], rtol=0, atol=1e-9)
+    vel_kind, vel_params, alt_params = GROUND["precise"]
+    pcg = PointCloudGenerator(cm, az_antenna_idxs=[0, 3, 4, 7], el_antenna_idxs=[9, 8, 5, 4],
+                              detector_type="range_doppler_ground_detector",
+                              detector_params=dict(vel_cfar_type=vel_kind, vel_cfar_params=vel_params, altimeter_params=alt_params))
+    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    for f in range(3):
+        np.testing.assert_allclose(pcg.process(seq[f]), g[f"ground_pc_f{f}"], rtol=0, atol=1e-9 * sc["range_max_m"])
+
+
+def test_non_finite_sample_in_an_end_antenna_is_the_one_documented_divergence(monkeypatch):
+    """The reference's 3-D chain returns NaN everywhere when ANY antenna holds an inf sample -- also an end antenna, whose
+    Hann(12) weight is exactly 0 (0 * inf = NaN; fixture inf_ant0 / inf_ant5).  The angle kernels never LOAD the two
+    zero-weight planes (and mmw_chain3d(d_rd = NULL) does not even transform them), so an inf in antenna 0 or 11 leaves the
+    output FINITE and equal to the clean cube's; with the inf in a live antenna, or with MMW_ANGLE_ZE=0
+    MMW_CHAIN_SKIP_ENDS=0, nothing is finite, like the reference's."""
+    g = np.load(os.path.join(GOLDEN, "detectors_rd.npz"))
+    assert int(g["inf_ant0_finite_count"]) == 0 and int(g["inf_ant5_finite_count"]) == 0
+    ctx = _lib.default_context()
+    V, S, C, A = 12, 256, 128, 64
+    d_in, d_out, d_rd = ctx.alloc(V * S * C * 8), ctx.alloc(A * S * C * 8), ctx.alloc(V * S * C * 8)
+
+    def run(ant, keep_rd=False):
+        cube = synth.synth_cube(3).copy()
+        cube[ant, 17, 9] = np.inf
+        d_in.upload(cube)
+        _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, d_rd.ptr if keep_rd else None, d_out.ptr, 1, V, S, C, A, 0))
+        return int(np.isfinite(d_out.download((A, S, C), np.complex64)).sum())
+
+    assert run(5) == 0                              # live antenna: nothing finite, as in the reference
+    assert run(0, keep_rd=True) == A * S * C        # the divergence: the end planes are transformed here, but never read
+    assert run(0) == A * S * C                      # ... and here not even transformed
+    ref = O.fft3d_windowed(synth.synth_cube(3), A)
+    cube = synth.synth_cube(3).copy()
+    cube[0, 17, 9] = np.inf
+    d_in.upload(cube)
+    _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, 1, V, S, C, A, 0))
+    assert rel_err(d_out.download((A, S, C), np.complex64), ref) <= SPEC_TOL        # ... and equals the clean cube's result
+    monkeypatch.setenv("MMW_CHAIN_SKIP_ENDS", "0")
+    monkeypatch.setenv("MMW_ANGLE_ZE", "0")
+    if True:
+        # (the knobs are read once per process; in a fresh process they restore the reference's behaviour)
+        import subprocess, sys
+        code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+                "from mmwave_radar_processing_amd import _lib, synth\n"
+                "ctx = _lib.default_context(); V, S, C, A = 12, 256, 128, 64\n"
+                "d_in, d_out = ctx.alloc(V*S*C*8), ctx.alloc(A*S*C*8)\n"
+                "cube = synth.synth_cube(3).copy(); cube[0, 17, 9] = np.inf; d_in.upload(cube)\n"
+                "_lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, 1, V, S, C, A, 0))\n"
+                "print(int(np.isfinite(d_out.download((A, S, C), np.complex64)).sum()))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ), timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert int(out.stdout.strip().splitlines()[-1]) == 0
+    for b in (d_in, d_out, d_rd):
+        b.free()

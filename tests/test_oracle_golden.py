@@ -207,3 +207,79 @@ def test_range_zoom_matches_reference_zoomfft(golden):
     z, zb = O.range_zoom(cube, sc, 0.6, 1.9, chirp_idx=3)
     close(z, g["zoom_mag"], 1e-11)
     np.testing.assert_array_equal(zb, g["zoom_bins"])
+
+
+# parameters of tests/golden/make_golden.py::gen_detectors_rd (gui_configs/processor_params.yaml:40-86 and variants)
+YAML_OS2D = dict(num_train=(5, 5), num_guard=(3, 2), rho=0.7, alpha=2)
+YAML_SEQ = ("os_cfar_1d", {"num_train": 5, "num_guard": 3, "rho": 0.6, "alpha": 2},
+            "os_cfar_1d", {"num_train": 5, "num_guard": 2, "rho": 0.7, "alpha": 3})
+GOSO_SEQ = ("go_cfar_1d", {"num_train": 8, "num_guard": 2, "pfa": 1e-3},
+            "so_cfar_1d", {"num_train": 6, "num_guard": 2, "pfa": 1e-4})
+GROUND = {
+    "yaml": ("os_cfar_1d", {"num_train": 12, "num_guard": 4, "rho": 0.5, "alpha": 15},
+             {"min_altitude_m": 0.25, "zoom_search_region_m": 0.2, "altitude_search_limit_m": 0.4, "range_bias": 0.0,
+              "precise_est_enabled": False}),
+    "coarse": ("os_cfar_1d", {"num_train": 12, "num_guard": 4, "rho": 0.5, "alpha": 6},
+               {"min_altitude_m": 0.6, "zoom_search_region_m": 0.2, "altitude_search_limit_m": 0.6, "range_bias": 0.0,
+                "precise_est_enabled": False}),
+    "precise": ("os_cfar_1d", {"num_train": 16, "num_guard": 4, "rho": 0.5, "alpha": 12},
+                {"min_altitude_m": 0.6, "zoom_search_region_m": 0.2, "altitude_search_limit_m": 0.6, "range_bias": 0.03,
+                 "precise_est_enabled": True}),
+}
+
+
+def _rd_cases():
+    sc256 = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    with open(os.path.join(GOLDEN, "cfg_scalars.json")) as fh:
+        ods = json.load(fh)["6843_RadVel_ods_20Hz.cfg"]
+    sc_ods = O.cfg_scalars("\n".join(ods["lines"]))
+    return [(f"s{s}", sc256, synth.synth_cube(s)) for s in (0, 1, 2, 3)] + [("np2", sc_ods, synth.synth_cube(202, (12, 63, 70)))]
+
+
+def test_sequential_and_os2d_detectors_on_range_doppler_data():
+    """Reference-generated detections of RangeDopplerDetectorSequential (YAML OS parameters and a GO / SO pairing) and of
+    RangeDopplerDetector2D with the YAML's os_cfar_2d on four headline frames and the (12, 63, 70) cube: oracle == reference,
+    values and order."""
+    g = np.load(os.path.join(GOLDEN, "detectors_rd.npz"))
+    total = 0
+    for tag, _, cube in _rd_cases():
+        np.testing.assert_array_equal(O.rd_detect_sequential(cube, *YAML_SEQ), g[f"{tag}_seq_yaml"])
+        np.testing.assert_array_equal(O.rd_detect_sequential(cube, *GOSO_SEQ), g[f"{tag}_seq_goso"])
+        np.testing.assert_array_equal(O.rd_detect_2d_os(cube, **YAML_OS2D), g[f"{tag}_os2d_yaml"])
+        total += g[f"{tag}_seq_yaml"].shape[0] + g[f"{tag}_os2d_yaml"].shape[0]
+    assert total > 2000
+
+
+def test_ground_detector_sequence_with_altimeter_state():
+    """RangeDopplerGroundDetector over a 5-frame sequence (the altimeter keeps its last altitude), reset(), one more frame:
+    detections and the altitude track of the oracle == reference, for the YAML parameters (never locks on: the ground return
+    lies beyond its search limit), a coarse lock and a zoom-FFT (precise) lock."""
+    g = np.load(os.path.join(GOLDEN, "detectors_rd.npz"))
+    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    seq = synth.synth_ground_sequence(606, 5)
+    for name, (vel_kind, vel_params, alt_params) in GROUND.items():
+        alt = O.Altimeter(sc, **alt_params)
+        track = []
+        for f in range(5):
+            dets, a = O.rd_detect_ground(seq[f], alt, sc, vel_kind, vel_params, alt_params)
+            np.testing.assert_array_equal(dets, g[f"ground_{name}_f{f}"])
+            track.append(a)
+        np.testing.assert_allclose(track, g[f"ground_{name}_alt"], rtol=0, atol=1e-12)
+        alt.reset()
+        dets, a = O.rd_detect_ground(seq[3], alt, sc, vel_kind, vel_params, alt_params)
+        np.testing.assert_array_equal(dets, g[f"ground_{name}_after_reset_f3"])
+        np.testing.assert_allclose(a, g[f"ground_{name}_after_reset_alt"], rtol=0, atol=1e-12)
+    assert g["ground_precise_f0"].shape[0] > 0 and g["ground_precise_alt"][4] > g["ground_precise_alt"][0]
+
+
+def test_non_finite_sample_poisons_the_reference_chain():
+    """A single inf sample -- in an end antenna (Hann weight exactly 0: 0 * inf = NaN) or a middle one -- leaves no finite
+    value in the reference's 3-D cube; the oracle restates that."""
+    g = np.load(os.path.join(GOLDEN, "detectors_rd.npz"))
+    for tag, ant in (("inf_ant0", 0), ("inf_ant5", 5)):
+        cube = synth.synth_cube(3).copy()
+        cube[ant, 17, 9] = np.inf
+        with np.errstate(all="ignore"):
+            f3 = O.fft3d_windowed(cube, 64)
+        assert int(np.isfinite(f3).sum()) == int(g[f"{tag}_finite_count"]) == 0
+        assert f3.size == int(g[f"{tag}_size"])
