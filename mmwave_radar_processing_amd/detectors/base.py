@@ -15,6 +15,7 @@ import numpy as np
 from numpy.lib.stride_tricks import sliding_window_view
 
 from .. import _lib
+from .._lazy import LazyAttrs
 
 
 def compute_alpha_ca(num_train_cells: int, pfa: float) -> float:
@@ -22,7 +23,7 @@ def compute_alpha_ca(num_train_cells: int, pfa: float) -> float:
     return num_train_cells * (pfa ** (-1.0 / num_train_cells) - 1.0)
 
 
-class _DeviceCFAR:
+class _DeviceCFAR(LazyAttrs):
     """Shared device plumbing: run one CFAR kernel over a float64 host array."""
 
     _ctx: Optional[_lib.Context] = None

@@ -52,11 +52,31 @@ class PointCloudGenerator(_Processor):
         self.phase_shifts, self.angle_bins = angle_tables(self.num_angle_bins)
 
     def process(self, adc_cube: np.ndarray, **kwargs) -> np.ndarray:
-        dets = self.detector.process(adc_cube, **kwargs)
+        det = self.detector
+        # detections and both argmax index lists from ONE device call where the detector has the fused kernel
+        # (RangeDopplerDetector2D with a CA-CFAR whose plane fits the LDS, lists of <= 8 antennas): mmw_detect_points
+        fused = getattr(det, "process_points", None)
+        if fused is not None and max(self.az_antenna_idxs.size, self.el_antenna_idxs.size) <= 8:
+            dets = fused(adc_cube, [int(i) for i in self.az_antenna_idxs], [int(i) for i in self.el_antenna_idxs],
+                         self.shift_az_resp, self.shift_el_resp, self.num_angle_bins)
+            if dets is not None:
+                self.n_refined = int(det.screen_stats[3] + det.screen_stats[4])
+                if dets.shape[0] == 0:
+                    return np.empty((0, 4))
+                det_ranges, det_velocities, _, _ = det._map_detections_to_bins(dets)
+                az_idx, el_idx = det.points
+                n = dets.shape[0]
+                az = self.angle_bins[az_idx] if az_idx is not None else np.zeros(n)
+                el = self.angle_bins[el_idx] if el_idx is not None else np.zeros(n)
+                return self._convert_to_cartesian(det_ranges, az, el, det_velocities)
+        dets = det.process(adc_cube, **kwargs)
         if dets.shape[0] == 0:
             return np.empty((0, 4))
-        det_ranges, det_velocities, r_idx, v_idx = self.detector._map_detections_to_bins(dets)
-        az, el = self._compute_angle_estimation(self.detector.rng_dop_resp_raw, r_idx, v_idx)
+        det_ranges, det_velocities, r_idx, v_idx = det._map_detections_to_bins(dets)
+        # (None = "the cube the detector has just left on the device": passing detector.rng_dop_resp_raw, as the reference
+        #  does, would first download and convert it)
+        az, el = self._compute_angle_estimation(None if getattr(det, "_dev", None) is not None else det.rng_dop_resp_raw,
+                                                r_idx, v_idx)
         return self._convert_to_cartesian(det_ranges, az, el, det_velocities)
 
     # ------------------------------------------------------------------ angles
@@ -78,13 +98,13 @@ class PointCloudGenerator(_Processor):
             return az_angles, el_angles
         ctx, bufs = self._device()
         L, h = ctx.lib, ctx.handle
-        raw = np.asarray(rng_dop_resp_raw)
         r_idx = np.asarray(det_range_idxs).astype(np.int64)
         v_idx = np.asarray(det_velocity_idxs).astype(np.int64)
         A = int(self.num_angle_bins)
         d_idx = bufs.get("angle_idx", n * 4)
         dev = getattr(self.detector, "_dev", None)
-        resident = dev is not None and raw is self.detector.rng_dop_resp_raw
+        resident = dev is not None and (rng_dop_resp_raw is None or rng_dop_resp_raw is self.detector.__dict__.get("rng_dop_resp_raw"))
+        raw = None if resident else np.asarray(rng_dop_resp_raw)
         if resident:
             d_rd, (V, S, C), d_cube = dev[0], dev[2], dev[3]
             dets = np.ascontiguousarray(np.stack([r_idx, v_idx], axis=1), dtype=np.int32)
