@@ -300,6 +300,17 @@ int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]);
  * this instead of restating the rule. */
 int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, int flags, int plan[8]);
 
+/* Host logic without a device (planning only; what tests/cpp/host_sanitize.cpp runs under ASan / UBSan):
+ * mmw_diag_chain_plan_nodev = mmw_diag_chain_plan for a device of num_cu CUs (raw != 0: mmw_chain3d_raw);
+ * mmw_diag_detect_plan: tiling of mmw_detect_points -- plan[0] supported, [1] row tiles per frame, [2] rows per tile,
+ *   [3] band rows, [4] band pitch, [5] LDS bytes, [6] compile-time window, [7] rounding-error budget of the range-Doppler
+ *   kernel for this plane in units of 2^-24 of the plane's L1 norm;
+ * mmw_diag_czt_runs: the uniform runs (offset, length, zero-filled) a zoom frequency list of M bins is cut into. */
+int mmw_diag_chain_plan_nodev(int num_cu, int raw, int n_frames, int V, int S, int C, int A, int flags, int plan[8]);
+int mmw_diag_detect_plan(int S, int C, int cfar_kind, int train_r, int train_d, int guard_r, int guard_d, int n_az,
+                         int n_el, int A, int plan[8]);
+int mmw_diag_czt_runs(const double *h_freq, int M, int n_used, int *h_runs, int cap, int *n_runs);
+
 /* ---------------------------------------------------------------- per-kernel timing hook for bench.py
  * Average duration (ms) of the most recent launch group of the named kernel family measured
  * with HIP event pairs on the launching queue (no host sync): "rd", "angle", "cfar", ...

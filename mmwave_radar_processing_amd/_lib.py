@@ -84,6 +84,9 @@ _SIGNATURES = {
     "mmw_diag_mfma_peak": [_vp, _i, C.POINTER(_d)],
     "mmw_diag_rd_plan": [_i, _i, _i, _ip],
     "mmw_diag_chain_plan": [_vp, _i, _i, _i, _i, _i, _i, _ip],
+    "mmw_diag_chain_plan_nodev": [_i, _i, _i, _i, _i, _i, _i, _i, _ip],
+    "mmw_diag_detect_plan": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _ip],
+    "mmw_diag_czt_runs": [C.POINTER(_d), _i, _i, _ip, _i, _ip],
     "mmw_profile_enable": [_vp, _i],
     "mmw_profile_get": [_vp, C.c_char_p, C.POINTER(_f), _ip],
     "mmw_profile_reset": [_vp],

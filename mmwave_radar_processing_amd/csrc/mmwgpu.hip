@@ -1904,6 +1904,56 @@ int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, 
     return MMW_OK;
 }
 
+// Host-logic diagnostics that need no device (run under AddressSanitizer / UBSan by tests/cpp/host_sanitize.cpp):
+// the chain schedule for a device with `num_cu` CUs, the tiling of the fused detection stage, the runs a chirp-z plan
+// cuts a frequency list into.
+int mmw_diag_chain_plan_nodev(int num_cu, int raw, int n_frames, int V, int S, int C, int A, int flags, int plan[8]) {
+    MMW_REQUIRE(plan && num_cu > 0 && n_frames > 0 && V > 0 && S > 0 && C > 0 && A >= V, "bad argument");
+    mmw_ctx fake;
+    fake.num_cu = num_cu;
+    const ChainPlan p = chain_plan(&fake, false, raw != 0, n_frames, V, S, C, A, flags);
+    plan[0] = p.pipelined;
+    plan[1] = p.chunk;
+    plan[2] = p.ring;
+    plan[3] = p.rd_cus;
+    plan[4] = p.vskip > 2 ? V - 2 : V;
+    plan[5] = 0;
+    plan[6] = p.sync;
+    plan[7] = p.sync ? p.ring_frames : 0;
+    return MMW_OK;
+}
+
+int mmw_diag_detect_plan(int S, int C, int cfar_kind, int train_r, int train_d, int guard_r, int guard_d, int n_az, int n_el, int A,
+                         int plan[8]) {
+    MMW_REQUIRE(plan && S > 0 && C > 0 && train_r >= 0 && train_d >= 0 && guard_r >= 0 && guard_d >= 0 && n_az >= 0 && n_el >= 0,
+                "bad argument");
+    const DetectPlan p = detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el, A);
+    plan[0] = p.ok;
+    plan[1] = p.tiles;
+    plan[2] = p.tile_rows;
+    plan[3] = p.band_rows;
+    plan[4] = p.band_pitch;
+    plan[5] = (int)p.lds_screen;
+    plan[6] = p.ct_window;
+    plan[7] = rd_error_ulps(S, C);
+    return MMW_OK;
+}
+
+int mmw_diag_czt_runs(const double *h_freq, int M, int n_used, int *h_runs, int cap, int *n_runs) {
+    MMW_REQUIRE(h_freq && n_runs && M > 0 && n_used > 0 && cap >= 0 && (cap == 0 || h_runs), "bad argument");
+    const int L = czt_length(n_used);
+    *n_runs = 0;
+    if (L <= 0) return MMW_OK;              // no chirp-z length for this many input points
+    const auto runs = czt_runs(h_freq, M, L - n_used + 1);
+    *n_runs = (int)runs.size();
+    for (int i = 0; i < *n_runs && i < cap; ++i) {          // (offset, length, filled with zeros) per run
+        h_runs[3 * i] = std::get<0>(runs[i]);
+        h_runs[3 * i + 1] = std::get<1>(runs[i]);
+        h_runs[3 * i + 2] = std::get<2>(runs[i]) ? 1 : 0;
+    }
+    return MMW_OK;
+}
+
 int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops) {
     MMW_REQUIRE(ctx && tflops && (kind == 0 || kind == 1), "bad argument");
     MMW_JOIN(ctx);
