@@ -243,6 +243,49 @@ def cpu_baseline_detect(seconds: float = 12.0):
                       f"RD + CA-CFAR + angle argmax, single thread) in {dt:.1f} s"}
 
 
+def host_stream_record(ctx, chunk_frames: int = 128, n_chunks: int = 8):
+    """PCIe-INCLUSIVE rate of the detection pipeline for frame loops whose cubes arrive on the host (never `value`):
+    FramePipeline.stream over pinned host chunks, upload of chunk k + 1 on the copy queue while chunk k is processed;
+    complex64 cubes and int16 I/Q raw cubes (half the bytes; layout not pinned by the reference)."""
+    from mmwave_radar_processing_amd import synth
+    from mmwave_radar_processing_amd.batch import FramePipeline
+    from mmwave_radar_processing_amd.config_managers import ConfigManager
+    from mmwave_radar_processing_amd.detectors import CaCFAR2D
+    cm = ConfigManager()
+    cm.load_cfg_text(synth.SYNTH_CFG_256x128x12)
+    pipe = FramePipeline(cm, max_frames=chunk_frames, shape=(V, S, C), cfar=CaCFAR2D(DET_CFAR["train"], DET_CFAR["guard"], DET_CFAR["pfa"]),
+                         az_antenna_idxs=AZ_ANT, el_antenna_idxs=EL_ANT, det_capacity=DET_CAP, ctx=ctx)
+    pipe.synth(chunk_frames, seed0=4_000_000)
+    cubes = pipe.cubes()
+    nrx, ntx = 4, 3
+    out = {"chunk_frames": chunk_frames, "chunks": n_chunks}
+    work = lambda p: (p._alloc_detect(), p._detect_fused(True))[1]          # device results stay resident; counts come back
+    for name, tx in (("c64", 0), ("i16", ntx)):
+        if tx:
+            raw = np.empty((chunk_frames, nrx, S, ntx * C), dtype=np.complex64)
+            for t in range(ntx):
+                raw[:, :, :, t::ntx] = cubes[:, t * nrx:(t + 1) * nrx]
+            host = np.stack([raw.real, raw.imag], axis=-1).astype(np.int16)
+        else:
+            host = cubes
+        pin = [ctx.host_array(host.shape, host.dtype) for _ in range(2)]
+        for p in pin:
+            p[...] = host
+        ctx.sync()
+        dets = 0
+        for counts in pipe.stream([pin[i % 2] for i in range(2)], work=work, num_tx=tx, pinned=True):      # warm-up
+            pass
+        t0 = time.perf_counter()
+        for counts in pipe.stream([pin[i % 2] for i in range(n_chunks)], work=work, num_tx=tx, pinned=True):
+            dets += int(counts.sum())
+        dt = time.perf_counter() - t0
+        frames = n_chunks * chunk_frames
+        out[name] = {"frames_per_s": frames / dt, "host_bytes_per_frame": host.nbytes // chunk_frames,
+                     "h2d_GBs": frames * (host.nbytes / chunk_frames) / dt / 1e9, "detections": dets}
+    pipe.bufs.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -452,6 +495,7 @@ def main():
                 out["cpu_baseline_all_cores"] = cpu_baseline_pool()
                 if det_extra is not None:
                     out["detect"]["cpu_baseline"] = cpu_baseline_detect(6.0)
+                    out["detect"]["host_stream_pcie_inclusive"] = host_stream_record(ctx)
         print(json.dumps(out))
         if not parity_ok:
             sys.exit("bench.py: GPU output differs from the oracle (spectra beyond 1e-5 / any index) -- the figure above is invalid")

@@ -69,6 +69,24 @@ int mmw_memcpy_h2d(mmw_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int mmw_memcpy_d2h(mmw_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int mmw_memset(mmw_ctx *ctx, void *d_dst, int value, size_t bytes);
 
+/* ---------------------------------------------------------------- host streaming
+ * For frame loops whose cubes arrive on the host (the reference's scripts/test_vel_estimation.py:145-151): pinned staging
+ * blocks, asynchronous copies on the compute queue or on a separate copy queue, and events to order the two, so that
+ * chunk k + 1 is uploaded while chunk k is processed (batch.FramePipeline.stream).
+ *   mmw_host_alloc / mmw_host_free   pinned host memory owned by the context
+ *   mmw_memcpy_async                 to_host = 0: host -> device, 1: device -> host; queue = MMW_QUEUE_*; returns at once
+ *   mmw_event_create / _destroy / _record(queue) / mmw_queue_wait_event(queue, event) / mmw_event_sync(event) */
+#define MMW_QUEUE_COMPUTE 0
+#define MMW_QUEUE_COPY    1
+int mmw_host_alloc(mmw_ctx *ctx, void **h_ptr, size_t bytes);
+int mmw_host_free(mmw_ctx *ctx, void *h_ptr);
+int mmw_memcpy_async(mmw_ctx *ctx, void *dst, const void *src, size_t bytes, int to_host, int queue);
+int mmw_event_create(mmw_ctx *ctx, void **event);
+int mmw_event_destroy(mmw_ctx *ctx, void *event);
+int mmw_event_record(mmw_ctx *ctx, void *event, int queue);
+int mmw_queue_wait_event(mmw_ctx *ctx, int queue, void *event);
+int mmw_event_sync(mmw_ctx *ctx, void *event);
+
 /* ---------------------------------------------------------------- timing (HIP events on the ctx stream) */
 int mmw_timer_start(mmw_ctx *ctx);
 int mmw_timer_stop(mmw_ctx *ctx, float *elapsed_ms);   /* synchronises on the stop event */

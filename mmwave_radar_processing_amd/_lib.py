@@ -23,6 +23,7 @@ MMW_ERR_UNSUPPORTED = -5
 ABI_VERSION = 3          # include/mmwgpu.h MMWGPU_ABI_VERSION: the argtypes below are for exactly this revision
 CFAR_CA, CFAR_OS, CFAR_GO, CFAR_SO = 0, 1, 2, 3
 ANGLE_MAGNITUDE, ANGLE_NO_WINDOW, ANGLE_NO_SHIFT = 1, 2, 4
+QUEUE_COMPUTE, QUEUE_COPY = 0, 1
 
 
 class MmwGpuError(RuntimeError):
@@ -47,6 +48,14 @@ _SIGNATURES = {
     "mmw_memcpy_h2d": [_vp, _vp, _vp, _sz],
     "mmw_memcpy_d2h": [_vp, _vp, _vp, _sz],
     "mmw_memset": [_vp, _vp, _i, _sz],
+    "mmw_host_alloc": [_vp, C.POINTER(_vp), _sz],
+    "mmw_host_free": [_vp, _vp],
+    "mmw_memcpy_async": [_vp, _vp, _vp, _sz, _i, _i],
+    "mmw_event_create": [_vp, C.POINTER(_vp)],
+    "mmw_event_destroy": [_vp, _vp],
+    "mmw_event_record": [_vp, _vp, _i],
+    "mmw_queue_wait_event": [_vp, _i, _vp],
+    "mmw_event_sync": [_vp, _vp],
     "mmw_timer_start": [_vp],
     "mmw_timer_stop": [_vp, C.POINTER(_f)],
     "mmw_synth_cubes": [_vp, _vp, _i, _i, _i, _i, C.c_uint64, _i, _f],
@@ -213,6 +222,35 @@ class Context:
 
     def sync(self):
         check(self.lib.mmw_sync(self.handle))
+
+    # host streaming ------------------------------------------------------
+    def host_array(self, shape, dtype) -> np.ndarray:
+        """Pinned host memory as an ndarray (freed with the context)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(self.lib.mmw_host_alloc(self.handle, C.byref(p), nbytes))
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        return arr
+
+    def event(self):
+        e = C.c_void_p()
+        check(self.lib.mmw_event_create(self.handle, C.byref(e)))
+        return e
+
+    def copy_async(self, dst, src, nbytes, to_host=False, queue=QUEUE_COPY):
+        check(self.lib.mmw_memcpy_async(self.handle, dst, src, int(nbytes), int(bool(to_host)), int(queue)))
+
+    def record(self, event, queue):
+        check(self.lib.mmw_event_record(self.handle, event, int(queue)))
+
+    def wait(self, queue, event):
+        check(self.lib.mmw_queue_wait_event(self.handle, int(queue), event))
+
+    def event_sync(self, event):
+        check(self.lib.mmw_event_sync(self.handle, event))
 
     def timer_start(self):
         check(self.lib.mmw_timer_start(self.handle))

@@ -127,6 +127,79 @@ class FramePipeline:
         _lib.check(self.ctx.lib.mmw_virtual_array_reformat_i16(self.ctx.handle, d_i16.ptr, self.d_in.ptr, self.n_frames,
                                                                self.V // num_tx, num_tx, self.S, self.C))
 
+    def stream(self, chunks, work: Callable[["FramePipeline"], object] = None, num_tx: int = 0, pinned: bool = False):
+        """Host-resident frame loop (the reference's scripts/test_vel_estimation.py:145-151): iterate ``chunks`` of host cubes
+        and yield ``work(self)`` per chunk (default: ``point_clouds()``), with the upload of chunk k + 1 on the copy queue
+        while chunk k is processed.
+
+        ``chunks``: ``[F_k <= max_frames, V, S, C]`` complex64 cubes, or -- with ``num_tx > 0`` -- int16 I/Q raw cubes
+        ``[F_k, V / num_tx, S, num_tx * C, 2]`` (layout of ``load_raw_i16``: no upstream oracle).  ``pinned=True``: the chunks
+        already live in pinned memory (``ctx.host_array``) and are copied from where they are; otherwise each chunk is first
+        copied into one of two pinned staging blocks (a host memcpy, usually the slowest stage of the loop)."""
+        ctx, Q = self.ctx, _lib
+        work = work or (lambda p: p.point_clouds())
+        i16 = num_tx > 0
+        frame_bytes = self.cube_bytes // 2 if i16 else self.cube_bytes
+        dev = [self.bufs.get("stream_in0", self.max_frames * frame_bytes), self.bufs.get("stream_in1", self.max_frames * frame_bytes)]
+        ev_up, ev_free = [ctx.event(), ctx.event()], [ctx.event(), ctx.event()]
+        stage = [None, None]
+        d_cubes_own = self.d_in
+        it = iter(chunks)
+
+        def upload(k, chunk):
+            b = k % 2
+            a = np.asarray(chunk)
+            want = np.int16 if i16 else np.complex64
+            if a.dtype != want or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a, dtype=want)
+            n = a.shape[0]
+            if n > self.max_frames or a.nbytes != n * frame_bytes:
+                raise ValueError(f"chunk of shape {a.shape} does not hold <= {self.max_frames} frames of {frame_bytes} bytes")
+            if k >= 2:
+                ctx.wait(Q.QUEUE_COPY, ev_free[b])          # the compute of chunk k - 2 has read device block b
+            src = a
+            if not pinned:
+                if k >= 2:
+                    ctx.event_sync(ev_up[b])                 # copy k - 2 has left staging block b
+                if stage[b] is None:
+                    stage[b] = ctx.host_array((self.max_frames * frame_bytes,), np.uint8)
+                src = stage[b][:a.nbytes]
+                src[:] = a.reshape(-1).view(np.uint8)
+            ctx.copy_async(dev[b].ptr, src.ctypes.data, a.nbytes, to_host=False, queue=Q.QUEUE_COPY)
+            ctx.record(ev_up[b], Q.QUEUE_COPY)
+            return n, src
+
+        nxt = next(it, None)
+        k = 0
+        pending = upload(0, nxt) if nxt is not None else None
+        keep = []                                           # sources of copies in flight stay referenced
+        try:
+            while pending is not None:
+                n, src = pending
+                keep = [src]
+                nxt = next(it, None)
+                pending = upload(k + 1, nxt) if nxt is not None else None
+                if pending is not None:
+                    keep.append(pending[1])
+                b = k % 2
+                ctx.wait(Q.QUEUE_COMPUTE, ev_up[b])
+                self.n_frames = n
+                if i16:
+                    self.d_in = d_cubes_own
+                    _lib.check(ctx.lib.mmw_virtual_array_reformat_i16(ctx.handle, dev[b].ptr, self.d_in.ptr, n, self.V // num_tx,
+                                                                      num_tx, self.S, self.C))
+                else:
+                    self.d_in = dev[b]
+                out = work(self)
+                ctx.record(ev_free[b], Q.QUEUE_COMPUTE)
+                yield out
+                k += 1
+        finally:
+            self.d_in = d_cubes_own
+            ctx.sync()
+            for e in ev_up + ev_free:
+                _lib.check(ctx.lib.mmw_event_destroy(ctx.handle, e))
+
     def chain3d_raw(self, magnitude: bool = False):
         """3-D windowed FFT straight from the raw cubes of ``load_raw`` (``mmw_chain3d_raw``)."""
         F, A, S, C = self.n_frames, self.A, self.S, self.C

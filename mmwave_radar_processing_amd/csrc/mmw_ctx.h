@@ -104,6 +104,8 @@ struct mmw_ctx {
     bool chain_settling = false;             // inside mmw_chain_settle (its own entry-point calls must not recurse)
     bool rd_attr_set = false;    // hipFuncSetAttribute(max dynamic LDS) done for this context's device
     bool pipe_pending = false;   // chain work in flight on q_rd/q_ang that the context stream has not joined yet
+    hipStream_t q_copy = nullptr;               // copy queue of the host-streaming API (mmw_memcpy_async), created lazily
+    std::vector<void *> host_owned;             // mmw_host_alloc'ed pinned blocks still alive
     hipEvent_t t0 = nullptr, t1 = nullptr;      // mmw_timer_*
     bool profiling = false;                     // per-family kernel timing (mmw_profile_*)
     int prof_every = 1;                         // time every n-th launch group of a family (event records cost ~us)

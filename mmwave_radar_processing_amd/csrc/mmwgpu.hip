@@ -189,6 +189,11 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
         }
         (void)hipEventDestroy(ctx->pipe_begin);
     }
+    if (ctx->q_copy) {
+        (void)hipStreamSynchronize(ctx->q_copy);
+        (void)hipStreamDestroy(ctx->q_copy);
+    }
+    for (void *p : ctx->host_owned) (void)hipHostFree(p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MMW_OK;
@@ -247,6 +252,89 @@ int mmw_memset(mmw_ctx *ctx, void *d_dst, int value, size_t bytes) {
     MMW_JOIN(ctx);
     if (!bytes) return MMW_OK;
     MMW_HIP(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return MMW_OK;
+}
+
+// ------------------------------------------------------------------ host streaming (pinned staging, copy queue, events)
+// A frame loop that receives its cubes on the host (scripts/test_vel_estimation.py:145-151 in the reference) uploads chunk
+// k + 1 while chunk k is processed: pinned host blocks, a second queue for the copies, events to order the two.
+int mmw_host_alloc(mmw_ctx *ctx, void **h_ptr, size_t bytes) {
+    MMW_REQUIRE(ctx && h_ptr, "null argument");
+    MMW_HIP(hipSetDevice(ctx->device));
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+        return set_error(MMW_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    ctx->host_owned.push_back(p);
+    *h_ptr = p;
+    return MMW_OK;
+}
+
+int mmw_host_free(mmw_ctx *ctx, void *h_ptr) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    if (!h_ptr) return MMW_OK;
+    auto it = std::find(ctx->host_owned.begin(), ctx->host_owned.end(), h_ptr);
+    MMW_REQUIRE(it != ctx->host_owned.end(), "pointer was not allocated by mmw_host_alloc of this context");
+    MMW_HIP(hipSetDevice(ctx->device));
+    if (ctx->q_copy) MMW_HIP(hipStreamSynchronize(ctx->q_copy));
+    MMW_HIP(hipStreamSynchronize(ctx->stream));
+    MMW_HIP(hipHostFree(h_ptr));
+    ctx->host_owned.erase(it);
+    return MMW_OK;
+}
+
+static int queue_of(mmw_ctx *ctx, int queue, hipStream_t *out) {
+    MMW_REQUIRE(queue == MMW_QUEUE_COMPUTE || queue == MMW_QUEUE_COPY, "queue must be MMW_QUEUE_COMPUTE or MMW_QUEUE_COPY");
+    MMW_HIP(hipSetDevice(ctx->device));
+    if (queue == MMW_QUEUE_COPY && !ctx->q_copy) MMW_HIP(hipStreamCreateWithFlags(&ctx->q_copy, hipStreamNonBlocking));
+    *out = queue == MMW_QUEUE_COPY ? ctx->q_copy : ctx->stream;
+    return MMW_OK;
+}
+
+int mmw_memcpy_async(mmw_ctx *ctx, void *dst, const void *src, size_t bytes, int to_host, int queue) {
+    MMW_REQUIRE(ctx && (bytes == 0 || (dst && src)), "null argument");
+    hipStream_t q;
+    MMW_TRY(queue_of(ctx, queue, &q));
+    if (queue == MMW_QUEUE_COMPUTE) MMW_JOIN(ctx);
+    if (!bytes) return MMW_OK;
+    MMW_HIP(hipMemcpyAsync(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, q));
+    return MMW_OK;
+}
+
+int mmw_event_create(mmw_ctx *ctx, void **event) {
+    MMW_REQUIRE(ctx && event, "null argument");
+    MMW_HIP(hipSetDevice(ctx->device));
+    hipEvent_t e = nullptr;
+    MMW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = e;
+    return MMW_OK;
+}
+
+int mmw_event_destroy(mmw_ctx *ctx, void *event) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    if (event) MMW_HIP(hipEventDestroy((hipEvent_t)event));
+    return MMW_OK;
+}
+
+int mmw_event_record(mmw_ctx *ctx, void *event, int queue) {
+    MMW_REQUIRE(ctx && event, "null argument");
+    hipStream_t q;
+    MMW_TRY(queue_of(ctx, queue, &q));
+    if (queue == MMW_QUEUE_COMPUTE) MMW_JOIN(ctx);          // chain work of the context is part of "the compute queue so far"
+    MMW_HIP(hipEventRecord((hipEvent_t)event, q));
+    return MMW_OK;
+}
+
+int mmw_queue_wait_event(mmw_ctx *ctx, int queue, void *event) {
+    MMW_REQUIRE(ctx && event, "null argument");
+    hipStream_t q;
+    MMW_TRY(queue_of(ctx, queue, &q));
+    MMW_HIP(hipStreamWaitEvent(q, (hipEvent_t)event, 0));
+    return MMW_OK;
+}
+
+int mmw_event_sync(mmw_ctx *ctx, void *event) {
+    MMW_REQUIRE(ctx && event, "null argument");
+    MMW_HIP(hipEventSynchronize((hipEvent_t)event));
     return MMW_OK;
 }
 

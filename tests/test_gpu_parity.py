@@ -1860,3 +1860,45 @@ def test_non_finite_sample_in_an_end_antenna_is_the_one_documented_divergence(mo
         assert int(out.stdout.strip().splitlines()[-1]) == 0
     for b in (d_in, d_out, d_rd):
         b.free()
+
+
+def test_frame_pipeline_stream_overlaps_uploads_and_matches_load():
+    """FramePipeline.stream: host chunks (complex64, pinned complex64, int16 raw) through the double-buffered upload give the
+    results of load() + point_clouds() chunk by chunk, ragged last chunk included."""
+    from mmwave_radar_processing_amd.batch import FramePipeline
+    cm = make_cm(synth.synth_cfg_text(num_samples=64, num_loops=32))
+    shape, az, el = (12, 64, 32), list(range(8)), [8, 9, 10, 11]
+    cubes = np.stack([synth.synth_cube(9100 + f, shape) for f in range(11)])
+    chunks = [cubes[0:4], cubes[4:8], cubes[8:11]]
+    cfar = CaCFAR2D((4, 4), (2, 2), 1e-3)
+    ref_pipe = FramePipeline(cm, max_frames=4, shape=shape, cfar=cfar, az_antenna_idxs=az, el_antenna_idxs=el)
+    ref = []
+    for c in chunks:
+        ref_pipe.load(c)
+        ref.append(ref_pipe.point_clouds())
+    pipe = FramePipeline(cm, max_frames=4, shape=shape, cfar=cfar, az_antenna_idxs=az, el_antenna_idxs=el)
+    got = list(pipe.stream(chunks))
+    assert len(got) == 3 and [len(g) for g in got] == [4, 4, 3]
+    for g, r in zip(got, ref):
+        for a, b in zip(g, r):
+            np.testing.assert_array_equal(a, b)
+    # chunks that already live in pinned memory
+    pinned = pipe.ctx.host_array(cubes.shape, np.complex64)
+    pinned[...] = cubes
+    got2 = list(pipe.stream([pinned[0:4], pinned[4:8], pinned[8:11]], pinned=True))
+    for g, r in zip(got2, ref):
+        for a, b in zip(g, r):
+            np.testing.assert_array_equal(a, b)
+    # int16 I/Q raw chunks (layout not pinned by the reference): same detections as the complex64 cubes they encode
+    nrx, ntx = 4, 3
+    raw = np.empty((11, nrx, 64, ntx * 32), dtype=np.complex64)
+    for t in range(ntx):
+        raw[:, :, :, t::ntx] = cubes[:, t * nrx:(t + 1) * nrx]
+    iq = np.stack([raw.real, raw.imag], axis=-1).astype(np.int16)
+    got3 = list(pipe.stream([iq[0:4], iq[4:8], iq[8:11]], num_tx=ntx))
+    for g, r in zip(got3, ref):
+        for a, b in zip(g, r):
+            np.testing.assert_array_equal(a, b)
+    # a custom work function: detections only
+    got4 = list(pipe.stream(chunks, work=lambda p: p.detect()))
+    assert [len(g) for g in got4] == [4, 4, 3] and got4[2][2].dtype == np.int64
