@@ -146,6 +146,14 @@ int mmw_range_doppler_raw(mmw_ctx *ctx, const void *d_raw, void *d_out, int n_fr
                           int S, int loops);
 int mmw_chain3d_raw(mmw_ctx *ctx, const void *d_raw, void *d_rd, void *d_out, int n_frames, int num_rx, int num_tx,
                     int S, int loops, int A, int flags);
+/* int16 (I, Q) raw cubes [F][num_rx][S][num_tx * loops][2]: conversion and de-interleave inside the first kernel's loads
+ * (256 x 128 planes and every plane shape of the shipped cfgs; other shapes convert first), no complex64 cube in between.
+ * NO UPSTREAM ORACLE for the sample layout (the reference's reader, cpsl_datasets, is not in its tree): defined as
+ * mmw_virtual_array_reformat_i16 + the virtual-array entry point, and bit-identical to that. */
+int mmw_range_doppler_raw_i16(mmw_ctx *ctx, const void *d_raw_i16, void *d_out, int n_frames, int num_rx, int num_tx,
+                              int S, int loops);
+int mmw_chain3d_raw_i16(mmw_ctx *ctx, const void *d_raw_i16, void *d_rd, void *d_out, int n_frames, int num_rx,
+                        int num_tx, int S, int loops, int A, int flags);
 /* mmw_dbs_gather: d_out[F][S][n_out] float32 = d_mag[F][h_ang_idx[i]][s][h_vel_idx[i]] -- the Doppler-beam-
  *   sharpening column pick of perform_dbs_sharpen (processors/range_angle_resp_dbs_enhanced.py:216-263); the
  *   nearest-bin index tables are computed by the host from its angle / velocity bin tables. */

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "mmw_chain3d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_range_doppler_raw": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_chain3d_raw": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "mmw_range_doppler_raw_i16": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_chain3d_raw_i16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "mmw_dbs_gather": [_vp, _vp, _ip, _ip, _vp, _i, _i, _i, _i, _i],
     "mmw_mean_over_range": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_doppler_azimuth": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i],

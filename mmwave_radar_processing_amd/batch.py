@@ -107,7 +107,7 @@ class FramePipeline:
                              f"got {raw.shape} with num_tx={num_tx}")
         self.d_raw = self.bufs.get("raw", self.max_frames * self.cube_bytes)
         self.d_raw.upload(raw)
-        self.n_frames, self._raw_tx = raw.shape[0], num_tx
+        self.n_frames, self._raw_tx, self.d_raw_i16 = raw.shape[0], num_tx, None
         _lib.check(self.ctx.lib.mmw_virtual_array_reformat(self.ctx.handle, self.d_raw.ptr, self.d_in.ptr, self.n_frames,
                                                            self.V // num_tx, num_tx, self.S, self.C))
 
@@ -123,7 +123,8 @@ class FramePipeline:
                              f"got {raw.shape} with num_tx={num_tx}")
         d_i16 = self.bufs.get("raw_i16", self.max_frames * self.cube_bytes // 2)
         d_i16.upload(raw)
-        self.n_frames = raw.shape[0]
+        self.n_frames, self._raw_tx, self.d_raw_i16 = raw.shape[0], num_tx, d_i16
+        self.d_raw = None
         _lib.check(self.ctx.lib.mmw_virtual_array_reformat_i16(self.ctx.handle, d_i16.ptr, self.d_in.ptr, self.n_frames,
                                                                self.V // num_tx, num_tx, self.S, self.C))
 
@@ -201,10 +202,14 @@ class FramePipeline:
                 _lib.check(ctx.lib.mmw_event_destroy(ctx.handle, e))
 
     def chain3d_raw(self, magnitude: bool = False):
-        """3-D windowed FFT straight from the raw cubes of ``load_raw`` (``mmw_chain3d_raw``)."""
+        """3-D windowed FFT straight from the raw cubes of ``load_raw`` / ``load_raw_i16`` (``mmw_chain3d_raw[_i16]``)."""
         F, A, S, C = self.n_frames, self.A, self.S, self.C
         self.d_cube3d = self.bufs.get("cube3d", max(F, 1) * A * S * C * (4 if magnitude else 8))
         self._cube3d_mag = magnitude
+        if getattr(self, "d_raw_i16", None) is not None:        # int16 cells: converted inside the first kernel's loads
+            _lib.check(self.ctx.lib.mmw_chain3d_raw_i16(self.ctx.handle, self.d_raw_i16.ptr, None, self.d_cube3d.ptr, F,
+                                                        self.V // self._raw_tx, self._raw_tx, S, C, A, int(magnitude)))
+            return
         _lib.check(self.ctx.lib.mmw_chain3d_raw(self.ctx.handle, self.d_raw.ptr, None, self.d_cube3d.ptr, F,
                                                 self.V // self._raw_tx, self._raw_tx, S, C, A, int(magnitude)))
 

@@ -546,7 +546,17 @@ struct RawView {
     int ntx, nrx;       // ntx <= 1: the input already is the virtual-array cube
     int vskip;          // V > 2: do not transform the planes of virtual antennas 0 and V - 1 of every frame (their
                         // Hann(V) weight is exactly 0 and the chain's angle kernel never loads them); 0 = all planes
+    int i16;            // raw cube of int16 (I, Q) pairs instead of complex64 (same indexing, 4-byte cells); NO UPSTREAM
+                        // ORACLE for this sample layout (mmw_virtual_array_reformat_i16)
 };
+// element `elem` of a raw cube: complex64, or an int16 (I, Q) pair converted in registers
+template <bool I16> __device__ __forceinline__ cplx<float> raw_cell(const void *base, long elem) {
+    if constexpr (I16) {
+        const short2 v = reinterpret_cast<const short2 *>(base)[elem];
+        return cplx<float>{(float)v.x, (float)v.y};
+    } else
+        return reinterpret_cast<const cplx<float> *>(base)[elem];
+}
 // Planes a launch really transforms, and workgroup -> plane for the non-raw kernels (raw kernels keep their XCD-grouped
 // mapping and the workgroups of a skipped plane exit at once).
 __host__ __device__ __forceinline__ long skip_planes(long planes, RawView rv) {
@@ -579,12 +589,15 @@ __device__ __forceinline__ long raw_block_plane(long b, long planes, RawView rv)
     const int rx = (int)(g - f * rv.nrx);
     return f * (rv.nrx * rv.ntx) + tx * rv.nrx + rx;
 }
-__device__ __forceinline__ const cplx<float> *raw_plane(const cplx<float> *in, long plane, int S, int C, RawView rv) {
+__device__ __forceinline__ long raw_plane_off(long plane, int S, int C, RawView rv) {      // in cells
     const int V = rv.nrx * rv.ntx;
     const long f = plane / V;
     const int v = (int)(plane - f * V);
     const int tx = v / rv.nrx, rx = v - tx * rv.nrx;
-    return in + ((f * rv.nrx + rx) * S) * (long)C * rv.ntx + tx;
+    return ((f * rv.nrx + rx) * S) * (long)C * rv.ntx + tx;
+}
+__device__ __forceinline__ const cplx<float> *raw_plane(const cplx<float> *in, long plane, int S, int C, RawView rv) {
+    return in + raw_plane_off(plane, S, C, rv);
 }
 
 // ------------------------------------------------------------------ fused range-Doppler, 256 x 128
@@ -604,7 +617,7 @@ constexpr int RD_LDS_MAIN = 128 * RD_PITCH;                       // complex ele
 constexpr int RD_LDS_BYTES = RD_LDS_MAIN * 8 + 128 * 8 + 16 + 64;      // + W128 table + ticket words + L1 partials
 
 // RAW: the input is the raw [F][num_rx][256][num_tx * 128] cube (two 8-B loads per lane and row instead of one 16-B)
-template <bool NTIN, int ABL = 0, bool RAW = false>   // ABL: timing-only ablations (1 no stores, 2 no loads, 3 neither)
+template <bool NTIN, int ABL = 0, bool RAW = false, bool I16 = false>   // ABL: timing-only ablations (1 no stores, 2 no loads, 3 neither)
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
@@ -626,8 +639,8 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
             if (plane < 0 || skip_raw_plane(plane, rv)) return;
         } else plane = (int)skip_block_plane(blockIdx.x, rv);
         const f32x4 *src = in + (long)plane * (RD_S * RD_C / 2);
-        const cplx<float> *rsrc = nullptr;
-        if constexpr (RAW) rsrc = raw_plane(reinterpret_cast<const cplx<float> *>(in), plane, RD_S, RD_C, rv);
+        long roff = 0;
+        if constexpr (RAW) roff = raw_plane_off(plane, RD_S, RD_C, rv);
         cplx<float> *dst = out + (long)plane * (RD_S * RD_C);
         // ---- step 0: load, window, range pass 1 (n = 16*n1 + w)
         cplx<float> y0[16], y1[16];
@@ -637,8 +650,8 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
             f32x4 v;
             if constexpr (ABL & 2) v = f32x4{(float)(n + l), (float)(n - l), (float)(n ^ l), 1.0f};
             else if constexpr (RAW) {
-                const cplx<float> *e = rsrc + (long)(n * RD_C + 2 * l) * rv.ntx;
-                const cplx<float> a = e[0], b = e[rv.ntx];
+                const long e = roff + (long)(n * RD_C + 2 * l) * rv.ntx;
+                const cplx<float> a = raw_cell<I16>(in, e), b = raw_cell<I16>(in, e + rv.ntx);
                 v = f32x4{a.x, a.y, b.x, b.y};
             } else v = NTIN ? __builtin_nontemporal_load(src + n * (RD_C / 2) + l) : src[n * (RD_C / 2) + l];
             const float hs = hann_s[n];
@@ -1155,12 +1168,15 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
                                     hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
         ctx->rd_attr_set = true;
     }
-    if (rv.ntx > 1) {            // raw cube: the de-interleave is folded into the row loads
-        auto kern = k_rd_fused_256x128<false, 0, true>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
-        hipLaunchKernelGGL(kern, dim3((unsigned)raw_grid(planes, rv)), dim3(1024), RD_LDS_BYTES, ctx->stream,
-                           (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                           (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
+    if (rv.ntx > 1) {            // raw cube: the de-interleave (and the int16 -> float conversion) is folded into the row loads
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
+            hipLaunchKernelGGL(kern, dim3((unsigned)raw_grid(planes, rv)), dim3(1024), RD_LDS_BYTES, ctx->stream,
+                               (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                               (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
+        };
+        if (rv.i16) go(k_rd_fused_256x128<false, 0, true, true>);
+        else go(k_rd_fused_256x128<false, 0, true>);
         return check_launch("rd_fused_raw");
     }
     const int blocks = (int)skip_planes(planes, rv);   // one plane per workgroup

@@ -334,12 +334,20 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         if (!PERSIST && (!PAIRED || raw)) {
             // element loads (odd C, or the raw cube's tx-strided view): a few at a time, straight into the LDS
             const cplx<float> *in = raw ? raw_plane(in_base, plane, S, C, a.raw) : in_base + plane * a.in_plane_stride;
+            const short2 *in16 = reinterpret_cast<const short2 *>(a.in) + (raw ? raw_plane_off(plane, S, C, a.raw) : 0);
+            const bool i16 = raw && a.raw.i16;          // (uniform) int16 (I, Q) cells, converted here
 #pragma unroll 4
             for (int q = 0; q < EROUNDS; ++q) {
                 const int e = t + q * NT;
                 if (CELLS % NT == 0 || q + 1 < EROUNDS || e < CELLS) {
                     const int s = e / C, c = e - s * C;
-                    const cplx<float> y = __builtin_nontemporal_load(in + (long)e * ntx) * (win_s[s] * win_c[c]);
+                    cplx<float> x;
+                    if (i16) {
+                        const short2 v = in16[(long)e * ntx];
+                        x = cplx<float>{(float)v.x, (float)v.y};
+                    } else
+                        x = __builtin_nontemporal_load(in + (long)e * ntx);
+                    const cplx<float> y = x * (win_s[s] * win_c[c]);
                     lds[s * Cp + c] = y;
                     if constexpr (!SYNC) l1_acc += fabsf(y.x) + fabsf(y.y);
                 }

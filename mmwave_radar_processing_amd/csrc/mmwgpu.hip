@@ -431,6 +431,23 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
     {
         ProfScope ps(ctx, "rd");
         bool l1_done = false;
+        // int16 raw cubes: folded into the loads of the 256 x 128 kernel and of the compile-time mixed-radix kernels (the
+        // plane shapes of every shipped cfg); anything else converts + de-interleaves first (one extra pass)
+        const bool i16_folded = rv.i16 && rv.ntx > 1 && !env_int("MMW_NO_I16_FOLD", 0) &&
+                                ((fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0)) ||
+                                 (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0) && !tune_int("MMW_NO_MIXED_CT", 0) &&
+                                  !(rd_lds_supported(S, C) && env_int("MMW_PREFER_LDS_RD", 0))));
+        if (rv.i16 && !i16_folded) {
+            MMW_REQUIRE(rv.ntx >= 1 && rv.nrx >= 1, "int16 cubes are raw cubes");
+            const long total = (long)n_frames * V * S * C;
+            hipLaunchKernelGGL(k_reformat_i16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const short2 *)d_cubes, (float2 *)d_out, total, rv.nrx, rv.ntx, S, C);
+            MMW_TRY(check_launch("reformat_i16"));
+            // every kernel below may run in place on a virtual-array cube: a workgroup has read all of its plane (and a
+            // persistent one prefetches only planes it will write itself) before it stores
+            d_cubes = d_out;
+            rv = RawView{1, 0, rv.vskip, 0};
+        }
         if (fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
             MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C, rv, rv.ntx > 1 ? nullptr : d_l1, &l1_done));
         else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && !(rd_mixed_ct_supported(S, C) && !env_int("MMW_PREFER_LDS_RD", 0)))      // the compile-time kernel is faster where both exist (64 x 64: 6.0 vs 4.4 TB/s)
@@ -1212,6 +1229,28 @@ int mmw_chain3d_raw(mmw_ctx *ctx, const void *d_raw, void *d_rd, void *d_out, in
     MMW_REQUIRE(ctx, "ctx is null");
     MMW_TRY(raw_args_ok(num_rx, num_tx));
     return chain3d_impl(ctx, d_raw, RawView{num_tx, num_rx}, d_rd, d_out, n_frames, num_rx * num_tx, S, loops, A, flags);
+}
+
+// int16 (I, Q) raw cubes [F][num_rx][S][num_tx * loops][2]: the conversion to float and the TDM de-interleave happen in the
+// loads of the first kernel -- the 4-byte cells are read once, no complex64 cube is written in between.  NO UPSTREAM ORACLE
+// for this sample layout (the reference gets complex cubes from the absent cpsl_datasets reader): results are defined as,
+// and tested bit-identical to, mmw_virtual_array_reformat_i16 followed by the virtual-array entry point.
+int mmw_range_doppler_raw_i16(mmw_ctx *ctx, const void *d_raw_i16, void *d_out, int n_frames, int num_rx, int num_tx, int S,
+                              int loops) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
+    MMW_TRY(raw_args_ok(num_rx, num_tx));
+    MMW_REQUIRE(num_tx > 1, "int16 cubes are raw TDM cubes (num_tx > 1); convert a single-tx cube with mmw_virtual_array_reformat_i16");
+    return range_doppler_impl(ctx, d_raw_i16, d_out, nullptr, n_frames, num_rx * num_tx, S, loops, RawView{num_tx, num_rx, 0, 1});
+}
+
+int mmw_chain3d_raw_i16(mmw_ctx *ctx, const void *d_raw_i16, void *d_rd, void *d_out, int n_frames, int num_rx, int num_tx, int S,
+                        int loops, int A, int flags) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_TRY(raw_args_ok(num_rx, num_tx));
+    MMW_REQUIRE(num_tx > 1, "int16 cubes are raw TDM cubes (num_tx > 1)");
+    // (event / serial schedules: the device-synchronised producer kernels take complex64 cubes only)
+    return chain3d_impl(ctx, d_raw_i16, RawView{num_tx, num_rx, 0, 1}, d_rd, d_out, n_frames, num_rx * num_tx, S, loops, A, flags, false);
 }
 
 int mmw_range_profile(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C,

@@ -1902,3 +1902,35 @@ def test_frame_pipeline_stream_overlaps_uploads_and_matches_load():
     # a custom work function: detections only
     got4 = list(pipe.stream(chunks, work=lambda p: p.detect()))
     assert [len(g) for g in got4] == [4, 4, 3] and got4[2][2].dtype == np.int64
+
+
+@pytest.mark.parametrize("nrx,ntx,S,C", [(4, 3, 256, 128), (4, 3, 63, 100), (4, 2, 254, 50), (4, 3, 64, 32), (2, 2, 16, 8),
+                                         (4, 3, 512, 64)])
+def test_int16_raw_cubes_folded_into_the_first_kernel(nrx, ntx, S, C):
+    """mmw_range_doppler_raw_i16 / mmw_chain3d_raw_i16 (int16 I/Q cells converted and de-interleaved inside the loads of the
+    first kernel; NO UPSTREAM ORACLE for the layout) == mmw_virtual_array_reformat_i16 followed by the virtual-array entry
+    point, bit for bit, and within the spectrum tolerance of the oracle on the de-interleaved cube."""
+    ctx = _lib.default_context()
+    F, V, A = 5, nrx * ntx, 64
+    rng = np.random.default_rng(S * 1000 + C)
+    iq = rng.integers(-2000, 2000, size=(F, nrx, S, ntx * C, 2), dtype=np.int16)
+    d_iq, d_virt = ctx.alloc(iq.nbytes), ctx.alloc(F * V * S * C * 8)
+    d_a, d_b = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * V * S * C * 8)
+    d_iq.upload(iq)
+    L, h = ctx.lib, ctx.handle
+    _lib.check(L.mmw_virtual_array_reformat_i16(h, d_iq.ptr, d_virt.ptr, F, nrx, ntx, S, C))
+    _lib.check(L.mmw_range_doppler(h, d_virt.ptr, d_a.ptr, None, F, V, S, C))
+    _lib.check(L.mmw_range_doppler_raw_i16(h, d_iq.ptr, d_b.ptr, F, nrx, ntx, S, C))
+    a, b = d_a.download((F, V, S, C), np.complex64), d_b.download((F, V, S, C), np.complex64)
+    np.testing.assert_array_equal(a, b)
+    virt = d_virt.download((F, V, S, C), np.complex64)
+    assert rel_err(b[2], O.range_doppler(virt[2])) <= SPEC_TOL
+    # the 3-D chain
+    d_o1, d_o2 = ctx.alloc(F * A * S * C * 8), ctx.alloc(F * A * S * C * 8)
+    _lib.check(L.mmw_chain3d(h, d_virt.ptr, None, d_o1.ptr, F, V, S, C, A, 0))
+    _lib.check(L.mmw_chain3d_raw_i16(h, d_iq.ptr, None, d_o2.ptr, F, nrx, ntx, S, C, A, 0))
+    o1, o2 = d_o1.download((F, A, S, C), np.complex64), d_o2.download((F, A, S, C), np.complex64)
+    assert cross_schedule_dev(o1, o2) <= CROSS_SCHEDULE_TOL
+    assert rel_err(o2[4], O.fft3d_windowed(virt[4], A)) <= SPEC_TOL
+    for buf in (d_iq, d_virt, d_a, d_b, d_o1, d_o2):
+        buf.free()

@@ -75,6 +75,16 @@ def main():
             F * 2 * cube_b)
         run("chain3d_raw", lambda: _lib.check(L.mmw_chain3d_raw(ctx.handle, d_in.ptr, None, d_out.ptr, F, nrx, ntx, S, C, A, 0)),
             F * (cube_b + out_b))
+        # int16 (I, Q) raw cubes (layout not pinned by the reference): separate conversion pass vs the loads of the first kernel
+        d_iq = ctx.alloc(F * cube_b // 2)
+        _lib.check(L.mmw_memset(ctx.handle, d_iq.ptr, 1, F * cube_b // 2))
+        run("reformat_i16", lambda: _lib.check(L.mmw_virtual_array_reformat_i16(ctx.handle, d_iq.ptr, d_rd.ptr, F, nrx, ntx, S, C)),
+            F * (cube_b // 2 + cube_b))
+        run("rd_raw_i16", lambda: _lib.check(L.mmw_range_doppler_raw_i16(ctx.handle, d_iq.ptr, d_rd.ptr, F, nrx, ntx, S, C)),
+            F * (cube_b // 2 + cube_b))
+        run("chain3d_raw_i16", lambda: _lib.check(L.mmw_chain3d_raw_i16(ctx.handle, d_iq.ptr, None, d_out.ptr, F, nrx, ntx, S, C, A, 0)),
+            F * (cube_b // 2 + out_b))
+        d_iq.free()
     d_mag = ctx.alloc(F * S * C * 8)
     run("rd_mag64", lambda: _lib.check(L.mmw_range_doppler_mag64(ctx.handle, d_in.ptr, d_mag.ptr, F, V, S, C, 0)),
         F * (S * C * 8 + S * C * 8))
@@ -116,6 +126,13 @@ def main():
         _lib.check(L.mmw_angle_argmax(ctx.handle, d_rd.ptr, d_dets.ptr, d_cnt.ptr, d_idx.ptr, min(F, 65535), V, S, C, cap,
                                       ants, n_ant, A, 1))
     run("detect_batch_config3", detect_batch, F * (2 * cube_b + S * C * 4))
+    d_az, d_el, d_l1p, d_m32 = ctx.alloc(F * cap * 4), ctx.alloc(F * cap * 4), ctx.alloc(F * V * 4), ctx.alloc(F * S * C * 4)
+    az8, n_az = _lib.int_array(range(min(8, V)))
+    el4, n_el = _lib.int_array(range(max(0, V - 4), V))
+    if L.mmw_detect_points_supported(S, C, 0, 4, 4, 2, 2, n_az, n_el):
+        run("detect_points_config3", lambda: _lib.check(L.mmw_detect_points(
+            ctx.handle, d_in.ptr, d_rd.ptr, d_l1p.ptr, d_m32.ptr, d_dets.ptr, d_cnt.ptr, d_az.ptr, d_el.ptr, F, V, S, C, 0, 4, 4, 2, 2,
+            alpha, 0, cap, az8, n_az, 1, el4, n_el, 0, A, None)), F * (2 * cube_b + S * C * 4))
     d_l1 = ctx.alloc(F * V * 4)
 
     def detect_batch_exact():       # the product path of FramePipeline.point_clouds: exact azimuth argmax
