@@ -70,7 +70,7 @@ struct CztPlan {
 struct ChainCall {
     const void *d_cubes;
     void *d_out;
-    int ntx, nrx, n_frames, V, S, C, A, flags;
+    int ntx, nrx, n_frames, V, S, C, A, flags, i16;
 };
 
 struct PendingSpan {

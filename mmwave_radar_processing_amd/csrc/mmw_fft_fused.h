@@ -52,6 +52,7 @@ struct ChainSync {
     unsigned long long vmap;    // 16 x 4 bits: live-plane index within a frame -> virtual antenna (order of the RD work items);
                                 // a packed word, not an array: indexing an array in the argument block spills it to scratch
     int ntx, nrx;               // ntx > 1: the RD input is the raw [F][nrx][S][ntx * C] cube
+    int i16;                    // ... of int16 (I, Q) cells (256 x 128 producer only)
 };
 #define MMW_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 // one lane: wait until (int)(*cnt - target) >= 0; false on timeout / abort (and the abort flag is raised).
@@ -732,7 +733,8 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
 // L1N: also write l1[plane] = sum of |re| + |im| of the windowed plane (the error-bound scale of mmw_angle_argmax_exact;
 // same quantity as k_plane_l1, here for free while the samples are in registers).
 // RAWIN (SYNC only): the input is the raw cube; the de-interleave is folded into the row loads (two 8-B loads per lane).
-template <bool NTIN, int PF, bool SYNC = false, bool L1N = false, bool RAWIN = false>
+// I16 (RAWIN only): the raw cube holds int16 (I, Q) cells: one 4-byte load per cell, converted when the plane is windowed.
+template <bool NTIN, int PF, bool SYNC = false, bool L1N = false, bool RAWIN = false, bool I16 = false>
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
@@ -763,16 +765,23 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
             const int tx = v / cs.nrx, rx = v - tx * cs.nrx;
             // buffer loads: the (uniform) row base lives in the descriptor and the scalar offset, the lane part is one
             // 32-bit register for the whole plane -- 64-bit per-lane pointers for 32 loads do not fit the register budget
-            const cplx<float> *rowbase = reinterpret_cast<const cplx<float> *>(in) + (((long)f * cs.nrx + rx) * RD_S) * (long)RD_C * cs.ntx + tx;
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx<float> *>(rowbase), 0,
-                                                              (int)((unsigned)(RD_S * RD_C) * (unsigned)cs.ntx * 8u), 0x00020000);
-            const unsigned voff = (unsigned)(2 * l0 * cs.ntx) * 8u, step = (unsigned)cs.ntx * 8u;
+            constexpr unsigned CELL = I16 ? 4u : 8u;
+            const char *rowbase = reinterpret_cast<const char *>(in) + ((((long)f * cs.nrx + rx) * RD_S) * (long)RD_C * cs.ntx + tx) * (long)CELL;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0,
+                                                              (int)((unsigned)(RD_S * RD_C) * (unsigned)cs.ntx * CELL), 0x00020000);
+            const unsigned voff = (unsigned)(2 * l0 * cs.ntx) * CELL, step = (unsigned)cs.ntx * CELL;
 #pragma unroll
             for (int n1 = decltype(FIRST)::value; n1 < decltype(LAST)::value; ++n1) {
-                const unsigned soff = (unsigned)((16 * n1 + w0) * RD_C * cs.ntx) * 8u;
-                const cplx<float> a = __builtin_bit_cast(cplx<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
-                const cplx<float> b = __builtin_bit_cast(cplx<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + step, soff, 0));
-                nx[n1] = f32x4{a.x, a.y, b.x, b.y};
+                const unsigned soff = (unsigned)((16 * n1 + w0) * RD_C * cs.ntx) * CELL;
+                if constexpr (I16) {        // the raw (I, Q) words travel as they are: converting here would wait for the load
+                    const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+                    const unsigned b = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + step, soff, 0);
+                    nx[n1] = f32x4{__builtin_bit_cast(float, a), 0.f, __builtin_bit_cast(float, b), 0.f};
+                } else {
+                    const cplx<float> a = __builtin_bit_cast(cplx<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+                    const cplx<float> b = __builtin_bit_cast(cplx<float>, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + step, soff, 0));
+                    nx[n1] = f32x4{a.x, a.y, b.x, b.y};
+                }
             }
         } else {
             long plane_in = item;
@@ -828,7 +837,13 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int n = 16 * n1 + w;
-            const f32x4 v = nx[n1];
+            f32x4 v = nx[n1];
+            if constexpr (I16) {
+                // (copies first: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0 for .z as well)
+                const float wa = v.x, wb = v.z;
+                const int a = __builtin_bit_cast(int, wa), b = __builtin_bit_cast(int, wb);
+                v = f32x4{(float)(short)(a & 0xffff), (float)(a >> 16), (float)(short)(b & 0xffff), (float)(b >> 16)};
+            }
             const float hs = hann_s[n];
             y0[n1] = cplx<float>{v.x, v.y} * (hs * hc0);
             y1[n1] = cplx<float>{v.z, v.w} * (hs * hc1);
@@ -1148,7 +1163,8 @@ int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_ite
                            (float *)nullptr);
         return MMW_OK;
     };
-    if (cs.ntx > 1) MMW_TRY(go(k_rd_fused_256x128_persist<false, 4, true, false, true>));
+    if (cs.ntx > 1 && cs.i16) MMW_TRY(go(k_rd_fused_256x128_persist<false, 4, true, false, true, true>));
+    else if (cs.ntx > 1) MMW_TRY(go(k_rd_fused_256x128_persist<false, 4, true, false, true>));
     else MMW_TRY(go(k_rd_fused_256x128_persist<true, 6, true>));
     return check_launch("rd_fused_sync");
 }

@@ -837,7 +837,7 @@ struct ChainPlan {
     int ring_frames;        // sync: frames in the ring of RD cubes
 };
 static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_frames, int V, int S, int C, int A, int flags,
-                            bool allow_sync = true) {
+                            bool allow_sync = true, bool i16 = false) {
     ChainPlan p{};
     // Planes nobody reads are not transformed: with the Hann(V) antenna window the end antennas have weight exactly 0
     // (np.hanning end points) and k_angle64's ZE variant never loads them, so when the RD cube is only an internal
@@ -878,7 +878,8 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     const char *mode = std::getenv("MMW_CHAIN_MODE");
     // (windowed chains only: the un-windowed angle variants of the persistent kernel exceed its register budget)
     // raw cubes: RAWIN variant of the 256 x 128 kernel, MODE 3 of the compile-time mixed-radix ones
-    const bool sync_shape = fused_rd_ok(S, C) || ((raw ? rd_mixed_ct_raw_sync_supported(S, C) : rd_mixed_ct_supported(S, C)) &&
+    // (int16 raw cubes: the 256 x 128 producer only)
+    const bool sync_shape = fused_rd_ok(S, C) || (!i16 && (raw ? rd_mixed_ct_raw_sync_supported(S, C) : rd_mixed_ct_supported(S, C)) &&
                                                   !tune_int("MMW_NO_MIXED_CT", 0) && tune_int("MMW_MIXED_CT_SYNC", 1));
     p.sync = allow_sync && p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
@@ -977,7 +978,7 @@ int chain_settle(mmw_ctx *ctx) {
                          "launches of the device-synchronised chain must run concurrently -- a tool that serialises kernel "
                          "dispatches (e.g. rocprofv3 --pmc) needs MMW_CHAIN_MODE=events");
     for (const ChainCall &c : calls) {
-        MMW_TRY(chain3d_impl(ctx, c.d_cubes, RawView{c.ntx, c.nrx}, nullptr, c.d_out, c.n_frames, c.V, c.S, c.C, c.A, c.flags, false));
+        MMW_TRY(chain3d_impl(ctx, c.d_cubes, RawView{c.ntx, c.nrx, 0, c.i16}, nullptr, c.d_out, c.n_frames, c.V, c.S, c.C, c.A, c.flags, false));
         ++ctx->chain_fallbacks;
     }
     if (ctx->pipe_pending) {
@@ -1046,6 +1047,7 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     }
     cs.ntx = rv.ntx > 1 ? rv.ntx : 1;
     cs.nrx = rv.nrx;
+    cs.i16 = rv.i16;
     cs.naps_rd = std::max(0, env_int("MMW_SYNC_NAPS_RD", 32));
     cs.naps_ang = std::max(0, env_int("MMW_SYNC_NAPS_ANG", 4));
     const int n_rd_items = n_frames * v_live, n_ang_items = n_frames * tiles;
@@ -1099,7 +1101,7 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
         return rc;
     }
     MMW_TRY(sync_slot_launched(ctx, true));
-    ctx->chain_calls.push_back(ChainCall{d_cubes, d_out, rv.ntx, rv.nrx, n_frames, V, S, C, A_bins, flags});
+    ctx->chain_calls.push_back(ChainCall{d_cubes, d_out, rv.ntx, rv.nrx, n_frames, V, S, C, A_bins, flags, rv.i16});
     return MMW_OK;
 }
 
@@ -1111,11 +1113,12 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
     if (n_frames == 0) return MMW_OK;
     MMW_HIP(hipSetDevice(ctx->device));
     const size_t cube_bytes = (size_t)V * S * C * sizeof(cplx<float>);
+    const size_t in_frame_bytes = rv.i16 ? cube_bytes / 2 : cube_bytes;      // int16 (I, Q) cells are 4 bytes
     const size_t out_frame_bytes = (size_t)A * S * C * (magnitude ? sizeof(float) : sizeof(cplx<float>));
-    ChainPlan plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags, allow_sync);
+    ChainPlan plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags, allow_sync, rv.i16 != 0);
     if (plan.sync && ctx->chain_calls.size() >= 256) MMW_TRY(chain_settle(ctx));     // bound the unchecked backlog
     if (plan.sync && !sync_slot_acquire(ctx))       // another context of this process has synchronised work in flight here
-        plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags, false);
+        plan = chain_plan(ctx, d_rd != nullptr, rv.ntx > 1, n_frames, V, S, C, A, flags, false, rv.i16 != 0);
     rv.vskip = plan.vskip;
     const bool pipelined = plan.pipelined;
     const int ring = plan.ring, rd_cus = plan.rd_cus;
@@ -1138,7 +1141,7 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
         }
         for (int f0 = 0; f0 < n_frames; f0 += chunk) {
             const int nf = std::min(chunk, n_frames - f0);
-            const char *in = (const char *)d_cubes + (size_t)f0 * cube_bytes;
+            const char *in = (const char *)d_cubes + (size_t)f0 * in_frame_bytes;
             char *rd = d_rd ? (char *)d_rd + (size_t)f0 * cube_bytes : (char *)rd_scratch;
             MMW_TRY(range_doppler_impl(ctx, in, rd, nullptr, nf, V, S, C, rv));
             MMW_TRY(angle_fft_impl(ctx, rd, (char *)d_out + (size_t)f0 * out_frame_bytes, nf, V, S, C, A, flags));
@@ -1187,7 +1190,7 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
         if (ctx->pipe_ang_used[slot]) MMW_PIPE_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_ang[slot], 0));
         ctx->stream = ctx->q_rd;
         ctx->active_cus = rd_cus > 0 ? rd_cus : ctx->num_cu;
-        int rc = range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * cube_bytes, rd, nullptr, nf, V, S, C, rv);
+        int rc = range_doppler_impl(ctx, (const char *)d_cubes + (size_t)f0 * in_frame_bytes, rd, nullptr, nf, V, S, C, rv);
         ctx->stream = main_stream;
         ctx->active_cus = 0;
         if (rc != MMW_OK) return fail(rc);
@@ -1249,8 +1252,7 @@ int mmw_chain3d_raw_i16(mmw_ctx *ctx, const void *d_raw_i16, void *d_rd, void *d
     MMW_REQUIRE(ctx, "ctx is null");
     MMW_TRY(raw_args_ok(num_rx, num_tx));
     MMW_REQUIRE(num_tx > 1, "int16 cubes are raw TDM cubes (num_tx > 1)");
-    // (event / serial schedules: the device-synchronised producer kernels take complex64 cubes only)
-    return chain3d_impl(ctx, d_raw_i16, RawView{num_tx, num_rx, 0, 1}, d_rd, d_out, n_frames, num_rx * num_tx, S, loops, A, flags, false);
+    return chain3d_impl(ctx, d_raw_i16, RawView{num_tx, num_rx, 0, 1}, d_rd, d_out, n_frames, num_rx * num_tx, S, loops, A, flags);
 }
 
 int mmw_range_profile(mmw_ctx *ctx, const void *d_cubes, float *d_out, int n_frames, int V, int S, int C,

@@ -1906,7 +1906,7 @@ def test_frame_pipeline_stream_overlaps_uploads_and_matches_load():
 
 @pytest.mark.parametrize("nrx,ntx,S,C", [(4, 3, 256, 128), (4, 3, 63, 100), (4, 2, 254, 50), (4, 3, 64, 32), (2, 2, 16, 8),
                                          (4, 3, 512, 64)])
-def test_int16_raw_cubes_folded_into_the_first_kernel(nrx, ntx, S, C):
+def test_int16_raw_cubes_folded_into_the_first_kernel(nrx, ntx, S, C, monkeypatch):
     """mmw_range_doppler_raw_i16 / mmw_chain3d_raw_i16 (int16 I/Q cells converted and de-interleaved inside the loads of the
     first kernel; NO UPSTREAM ORACLE for the layout) == mmw_virtual_array_reformat_i16 followed by the virtual-array entry
     point, bit for bit, and within the spectrum tolerance of the oracle on the de-interleaved cube."""
@@ -1931,6 +1931,39 @@ def test_int16_raw_cubes_folded_into_the_first_kernel(nrx, ntx, S, C):
     _lib.check(L.mmw_chain3d_raw_i16(h, d_iq.ptr, None, d_o2.ptr, F, nrx, ntx, S, C, A, 0))
     o1, o2 = d_o1.download((F, A, S, C), np.complex64), d_o2.download((F, A, S, C), np.complex64)
     assert cross_schedule_dev(o1, o2) <= CROSS_SCHEDULE_TOL
+    # several chunks per call, serial and overlapped schedules (the input of chunk k starts k * chunk * 4-byte-cell frames in)
+    for pipe in ("0", "1"):
+        monkeypatch.setenv("MMW_CHAIN_CHUNK", "2")
+        monkeypatch.setenv("MMW_CHAIN_PIPELINE", pipe)
+        d_o2.zero()
+        _lib.check(L.mmw_chain3d_raw_i16(h, d_iq.ptr, None, d_o2.ptr, F, nrx, ntx, S, C, A, 0))
+        assert cross_schedule_dev(o1, d_o2.download((F, A, S, C), np.complex64)) <= CROSS_SCHEDULE_TOL
+    monkeypatch.delenv("MMW_CHAIN_CHUNK")
+    if (S, C) == (256, 128):
+        # the device-synchronised schedule (int16 variant of the persistent 256 x 128 producer), larger batch, twice in a row
+        F2 = 150
+        iq2 = rng.integers(-2000, 2000, size=(F2, nrx, S, ntx * C, 2), dtype=np.int16)
+        d_iq2, d_v2 = ctx.alloc(iq2.nbytes), ctx.alloc(F2 * V * S * C * 8)
+        d_p, d_q = ctx.alloc(F2 * A * S * C * 8), ctx.alloc(F2 * A * S * C * 8)
+        d_iq2.upload(iq2)
+        _lib.check(L.mmw_virtual_array_reformat_i16(h, d_iq2.ptr, d_v2.ptr, F2, nrx, ntx, S, C))
+        monkeypatch.setenv("MMW_CHAIN_PIPELINE", "0")
+        _lib.check(L.mmw_chain3d(h, d_v2.ptr, None, d_p.ptr, F2, V, S, C, A, 0))
+        monkeypatch.setenv("MMW_CHAIN_PIPELINE", "1")
+        plan = (_lib.C.c_int * 8)()
+        _lib.check(L.mmw_diag_chain_plan(h, F2, V, S, C, A, 0, plan))
+        assert plan[6] == 1
+        for _ in range(2):
+            _lib.check(L.mmw_chain3d_raw_i16(h, d_iq2.ptr, None, d_q.ptr, F2, nrx, ntx, S, C, A, 0))
+        picks = [0, 71, 149]
+        p_ = np.stack([d_p.download((A, S, C), np.complex64, f * A * S * C * 8) for f in picks])
+        q_ = np.stack([d_q.download((A, S, C), np.complex64, f * A * S * C * 8) for f in picks])
+        assert cross_schedule_dev(p_, q_) <= CROSS_SCHEDULE_TOL
+        _lib.check(L.mmw_diag_chain_plan(h, F2, V, S, C, A, 0, plan))
+        assert plan[5] == 0             # no hand-off timeout, nothing re-run
+        for buf in (d_iq2, d_v2, d_p, d_q):
+            buf.free()
+    monkeypatch.delenv("MMW_CHAIN_PIPELINE")
     assert rel_err(o2[4], O.fft3d_windowed(virt[4], A)) <= SPEC_TOL
     for buf in (d_iq, d_virt, d_a, d_b, d_o1, d_o2):
         buf.free()
