@@ -18,6 +18,14 @@ namespace mmw {
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// LDS traffic inside one wave needs no hardware barrier (DS instructions of a wave execute in order); the compiler
+// must not move accesses across the hand-over
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // W[f][e][t] (complex64, row-major [E][Tp] per frame); phase reduced mod 1 turn in float64 before the sincos.
 // P [F][3][E] element positions of each frame's (synthetic) array, dirs [3][T] steering directions.
 __global__ __launch_bounds__(256) void k_steer(cplx<float> *W, const double *P, const double *dirs,
@@ -136,6 +144,168 @@ __global__ __launch_bounds__(256) void k_sum_parts(const cplx<float> *__restrict
     out[i] = acc;
 }
 
+// ------------------------------------------------------------------ small contractions: steering fused, no LDS operand tiles
+// At the reference's own sizes (S = 256 samples, E = 256 synthetic elements, 60-64 steering directions, a handful of
+// frames) the tiled kernel above is a few workgroups stepping through K one load latency at a time, behind a separate
+// k_steer launch.  Here ONE 32 x 32 output tile per workgroup, its NW waves splitting K in chunks of 64:
+//   * A operand straight from global memory into registers: the MFMA sums over k, so WHICH k a lane feeds to a step is
+//     free -- half-wave h takes k0 + 32 h + s in step s and every lane reads 256 contiguous bytes of its own row;
+//   * B operand never exists in memory: lane (j, h) evaluates W[k0 + 32 h + s][n0 + j] itself (element positions of
+//     the chunk in a wave-private LDS strip, phase reduced mod one turn in float64 as in k_steer, then a float32
+//     sine / cosine: 2e-7 of |W|), interleaved with the MFMAs of the previous step;
+//   * the NW partial tiles meet in LDS; no k_sum_parts pass, no W round trip.
+// Workgroup ids are decoded so that the column tiles of one row tile run on the same XCD back to back (ids are dealt
+// round-robin over the 8 XCDs): the second reader of an X row tile finds it in that XCD's L2.
+__device__ __forceinline__ void sincos_turns_f32(float r, float &sn, float &cs) {     // r in [-0.5, 0.5] turns
+    const float q = rintf(4.f * r);
+    const float x = fmaf(q, -0.25f, r) * 6.2831853071795865f;                          // [-pi/4, pi/4], reduction exact
+    const float x2 = x * x;
+    float sp = fmaf(x2, 2.7557319e-6f, -1.9841270e-4f);
+    sp = fmaf(sp, x2, 8.3333333e-3f);
+    sp = fmaf(sp, x2, -1.6666667e-1f);
+    const float s = fmaf(x * x2, sp, x);
+    float cp = fmaf(x2, 2.4801587e-5f, -1.3888889e-3f);
+    cp = fmaf(cp, x2, 4.1666667e-2f);
+    cp = fmaf(cp, x2, -0.5f);
+    const float c = fmaf(x2, cp, 1.f);
+    const int qi = (int)q & 3;                  // quarter turns: 0: (c, s)  1: (-s, c)  2: (-c, -s)  3: (s, -c)
+    const float a = (qi & 1) ? s : c, b = (qi & 1) ? c : s;
+    cs = (qi == 1 || qi == 2) ? -a : a;
+    sn = (qi >= 2) ? -b : b;
+}
+
+constexpr int BT_STRIP = 3 * 64 * 8 + 64 * 4;          // wave-private LDS: element positions + taper of one chunk
+// NW waves per workgroup, NS MFMA steps per chunk (a chunk = 2 NS values of k: half-wave h feeds k0 + NS h + s to step s).
+// FAST: E a multiple of 2 NS -- every chunk whole, 16-byte row loads (no second load path to merge).
+// VAR 1: v_sin_f32 / v_cos_f32 (input in turns) instead of the polynomial: the same end-to-end error (2.1e-7 against
+// 1.7e-7 of the peak at 256 x 256 x 60) for a third of the instructions.  That matters because float32 MFMAs and float32
+// vector instructions do NOT overlap on this chip (mmw_diag_mfma_peak kinds 2-5: eight independent v_fma_f32 behind every
+// v_mfma_f32_32x32x2 take the rate from 150 to 99 TF with two waves per SIMD, to 74 TF with one -- the matrix and the
+// vector float32 rates are the same 256 flop/clk/CU, evidently the same multipliers): every vector instruction in this
+// loop is paid in full, so the steering is trimmed to the minimum (float64 dot product + fract, one convert, two
+// transcendentals, two multiplies per element) and eight waves per workgroup (two per SIMD) only hide latencies.
+template <int NW, int NS, bool FAST, int VAR>
+__global__ __launch_bounds__(64 * NW) void k_bartlett_tile(const cplx<float> *__restrict__ X, const double *__restrict__ P,
+                                                            const double *__restrict__ dirs, const float *__restrict__ hamming,
+                                                            cplx<float> *__restrict__ Cm, int S, int E, int T, int tiles_s, int NT,
+                                                            int MT, double inv_lambda, long long *clk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = 2 * NS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, ij = lane & 31;
+    const int slot = blockIdx.x >> 3, st = slot / NT, nt = slot - st * NT;
+    const int mt = st * 8 + (blockIdx.x & 7);
+    if (mt >= MT) return;                               // padding of the row-tile count to the 8 XCDs (whole workgroup)
+    auto mark = [&](int i) {        // diagnostics (MMW_PHASE_CLOCKS=1): workgroup 0, wave 0
+        if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[i] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    mark(0);
+    const int fi = mt / tiles_s;
+    const long f = fi;
+    const int m0 = (mt - fi * tiles_s) * 32, n0 = nt * 32;
+    double *Ps = reinterpret_cast<double *>(smem + wave * BT_STRIP);
+    float *hs = reinterpret_cast<float *>(smem + wave * BT_STRIP + 3 * 64 * 8);
+    float *red = reinterpret_cast<float *>(smem + NW * BT_STRIP);                     // [NW][2][16][64]
+    const int tc = n0 + ij < T ? n0 + ij : T - 1;
+    const double dx = dirs[tc] * inv_lambda, dy = dirs[T + tc] * inv_lambda, dz = dirs[2 * T + tc] * inv_lambda;
+    const int gm = m0 + ij < S ? m0 + ij : S - 1;
+    const cplx<float> *xrow = X + (f * S + gm) * (long)E;
+    const double *Pf = P + f * 3 * E;
+    // four accumulators: no MFMA waits for the result of the one issued just before it (summed after the loop)
+    v16f acc_r = {0}, acc_i = {0}, acc_r2 = {0}, acc_i2 = {0};
+    const int n_chunks = (E + CH - 1) / CH;
+    for (int q = wave; q < n_chunks; q += NW) {
+        const int k0 = q * CH, kb = k0 + NS * h;
+        // element positions first: their loads retire before the (later issued) row loads, so the phase reduction below
+        // overlaps the rows' flight
+        const int e_st = k0 + lane < E ? k0 + lane : E - 1;
+        const bool st_on = lane < CH;
+        const double p0 = Pf[e_st], p1 = Pf[E + e_st], p2 = Pf[2 * E + e_st];
+        const float hv = (st_on && k0 + lane < E) ? hamming[e_st] : 0.f;
+        f32x4 ra[NS / 2];
+        if (FAST) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(xrow + kb);
+#pragma unroll
+            for (int j = 0; j < NS / 2; ++j) ra[j] = src[j];
+        } else {                                        // last chunk / odd row pitch: clamped 8-byte loads, taper 0 beyond E
+#pragma unroll
+            for (int j = 0; j < NS / 2; ++j) {
+                const int ka = kb + 2 * j < E ? kb + 2 * j : E - 1, kc = kb + 2 * j + 1 < E ? kb + 2 * j + 1 : E - 1;
+                const cplx<float> a = xrow[ka], c = xrow[kc];
+                ra[j] = f32x4{a.x, a.y, c.x, c.y};
+            }
+        }
+        mark(1);
+        if (st_on) {
+            Ps[lane] = p0;
+            Ps[64 + lane] = p1;
+            Ps[128 + lane] = p2;
+            hs[lane] = hv;
+        }
+        wave_lds_sync();
+        // Reduced phases (float64 up to the reduction mod one turn) and tapers of the chunk's steps first -- this runs
+        // while the X rows are still in flight; the sine / cosine of step s + 1 sits between the MFMAs of step s.
+        float rt[NS], hm[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int ke = NS * h + s;
+            const double turns = dx * Ps[ke] + dy * Ps[64 + ke] + dz * Ps[128 + ke];
+            rt[s] = (float)(VAR & 1 ? __builtin_amdgcn_fract(turns) : turns - rint(turns));      // [0, 1) or [-0.5, 0.5] turns
+            hm[s] = hs[ke];
+        }
+        auto steer = [&](int s, float &br, float &bi) {
+            float sn, cs;
+            if (VAR & 1) {
+                sn = __builtin_amdgcn_sinf(rt[s]);
+                cs = __builtin_amdgcn_cosf(rt[s]);
+            } else {
+                sincos_turns_f32(rt[s], sn, cs);
+            }
+            br = cs * hm[s];
+            bi = sn * hm[s];
+        };
+        mark(2);
+        float br, bi;
+        steer(0, br, bi);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float nbr = 0.f, nbi = 0.f;
+            if (s + 1 < NS) steer(s + 1, nbr, nbi);
+            const float ar = (s & 1) ? ra[s >> 1].z : ra[s >> 1].x, ai = (s & 1) ? ra[s >> 1].w : ra[s >> 1].y;
+            acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, br, acc_r, 0, 0, 0);
+            acc_i = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, bi, acc_i, 0, 0, 0);
+            acc_r2 = __builtin_amdgcn_mfma_f32_32x32x2f32(-ai, bi, acc_r2, 0, 0, 0);
+            acc_i2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, br, acc_i2, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, (VAR & 1) ? 3 : 8, 0);      // vector-ALU work of the next element
+            }
+            br = nbr;
+            bi = nbi;
+        }
+        mark(3);
+        wave_lds_sync();                                // the strip is rewritten by the next chunk
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[((wave * 2 + 0) * 16 + r) * 64 + lane] = acc_r[r] + acc_r2[r];
+        red[((wave * 2 + 1) * 16 + r) * 64 + lane] = acc_i[r] + acc_i2[r];
+    }
+    __syncthreads();
+    // C/D map of the 32x32 shapes: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); partial tiles added in wave order
+    for (int r = wave; r < 16; r += NW) {
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            sr += red[((w * 2 + 0) * 16 + r) * 64 + lane];
+            si += red[((w * 2 + 1) * 16 + r) * 64 + lane];
+        }
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h, col = n0 + ij;
+        if (row < S && col < T) Cm[(f * S + row) * (long)T + col] = cplx<float>{sr, si};
+    }
+    mark(4);
+}
+
 // d_X [F][S][E] c64, d_P [F][3][E] f64, d_dirs [3][T] f64 -> d_out [F][S][T] c64
 inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int n_frames, int S,
                     int E, int T, double lambda_m) {
@@ -157,6 +327,37 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
     MMW_TRY(get_table<float>(ctx, TAB_HAMMING, E, &ham));
     MMW_TRY(get_table<float>(ctx, TAB_HANN, S, &hann));
     ProfScope ps(ctx, "bartlett");
+    // small contractions (at most four 32 x 32 tiles per CU): steering evaluated inside the tile kernel
+    const int tiles_s = (S + 31) / 32, NT = (T + 31) / 32;
+    const long MT = (long)n_frames * tiles_s;     // (< 2^31: n_frames <= 65535)
+    const int path = tune_int("MMW_BARTLETT_PATH", 0);      // 1: tile kernel, 2: tiled GEMM (experiments / tests)
+    if (path == 1 || (path == 0 && MT * NT <= 4L * ctx->num_cu)) {
+        ProfScope pg(ctx, "cgemm");
+        const int nw = 8;
+        const unsigned grid = (unsigned)(8 * NT * ((MT + 7) / 8));
+        const size_t lds = (size_t)nw * BT_STRIP + (size_t)nw * 2 * 16 * 64 * 4;
+        const bool poly = tune_int("MMW_BARTLETT_POLY", 0) != 0;       // polynomial sine / cosine instead of v_sin / v_cos
+        auto kern = k_bartlett_tile<8, 16, false, 1>;
+        if ((E & 31) == 0) kern = poly ? k_bartlett_tile<8, 16, true, 0> : k_bartlett_tile<8, 16, true, 1>;
+        else if (poly) kern = k_bartlett_tile<8, 16, false, 0>;
+        long long *d_clk = nullptr;
+        if (tune_int("MMW_PHASE_CLOCKS", 0)) {
+            MMW_HIP(hipMalloc((void **)&d_clk, 5 * sizeof(long long)));
+            MMW_HIP(hipMemsetAsync(d_clk, 0, 5 * sizeof(long long), ctx->stream));
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, ctx->stream, (const cplx<float> *)d_X, d_P, d_dirs,
+                           (const float *)ham, Cm, S, E, T, tiles_s, NT, (int)MT, 1.0 / lambda_m, d_clk);
+        if (d_clk) {
+            long long h[5] = {0};
+            MMW_HIP(hipStreamSynchronize(ctx->stream));
+            MMW_HIP(hipMemcpy(h, d_clk, sizeof(h), hipMemcpyDeviceToHost));
+            MMW_HIP(hipFree(d_clk));
+            std::fprintf(stderr, "bartlett tile clocks (workgroup 0 wave 0): loads issued %lld, positions landed + rows %lld, "
+                                 "phases %lld, MFMA loop %lld, reduce + store %lld\n",
+                         h[1] - h[0], 0LL, h[2] - h[1], h[3] - h[2], h[4] - h[3]);
+        }
+        MMW_TRY(check_launch("bartlett_tile"));
+    } else {
     const long nW = (long)E * Tp;
     hipLaunchKernelGGL(k_steer, dim3((unsigned)((nW + 255) / 256), (unsigned)n_frames), dim3(256), 0, ctx->stream, W, d_P, d_dirs,
                        (const float *)ham, E, T, Tp, 1.0 / lambda_m);
@@ -172,6 +373,7 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
             hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n_c + 255) / 256)), dim3(256), 0, ctx->stream, Cparts, Cm, n_c, ksplit);
             MMW_TRY(check_launch("sum_parts"));
         }
+    }
     }
     // hann(S) window and FFT along S for every steering column of every frame (:537-540)
     FftArgs a{};
@@ -204,6 +406,42 @@ __global__ __launch_bounds__(256) void k_diag_mfma(float *sink, int iters, int k
         }
         const float v = a0[0] + a1[1] + a2[2] + a3[3];
         if (v == 12345.678f) sink[0] = v;
+    } else if (kind >= 2) {
+        // kind 2 / 3: the same MFMA stream with 8 / 16 independent float32 FMAs after every MFMA -- do a wave's (or the
+        // SIMD's other wave's) vector instructions run under an MFMA in flight?  (rate reported counts the MFMAs only)
+        v16f a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = seed + (float)j;
+        const float m = 0.999f, c = 0.001f;
+        auto valu = [&]() {
+#pragma unroll
+            for (int rep = 0; rep < (kind == 3 ? 2 : 1); ++rep)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(m), "v"(c));
+        };
+        for (int i = 0; i < iters; ++i) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 1.0f, a0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            valu();
+            __builtin_amdgcn_sched_barrier(0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 0.5f, a1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            valu();
+            __builtin_amdgcn_sched_barrier(0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 0.25f, a2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            valu();
+            __builtin_amdgcn_sched_barrier(0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(seed, 0.125f, a3, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            valu();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float t = a0[0] + a1[1] + a2[2] + a3[3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += v[j];
+        if (t == 12345.678f) sink[0] = t;
     } else {
         v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
         const double sd = seed;
@@ -219,179 +457,210 @@ __global__ __launch_bounds__(256) void k_diag_mfma(float *sink, int iters, int k
 }
 
 // ------------------------------------------------------------------ Capon / MVDR (float64)
-// X [F][V][R][K] complex64 (K snapshots per range bin), steering table Ast [V][T] complex128, out [F][R][T] float32:
+// X [F][V][R][K] complex64 (K snapshots per range bin), angle table Zt [T] complex128 = a_1(theta_t), out [F][R][T] float32:
 //   P = 1 / Re( a^H (Rxx + delta tr(Rxx)/V I)^-1 a ),  Rxx = X_r X_r^H / K,  a_v = exp(-j pi v sin(theta)).
-// One WAVE per (frame, range bin), four waves per workgroup walking the bins of a batch (the single-frame kernel of
-// round 1 -- one 64-thread workgroup per bin, serial Cholesky / inverse on one to sixteen lanes, a workgroup barrier
-// per step -- was latency bound at 160 ns per bin).  Per bin:
-//   1. the V snapshot rows (K x 8 B, contiguous) arrive by coalesced 16-B loads into a wave-private LDS tile
-//      (pitch KT + 2: the MFMA operand reads that follow are bank-conflict free);
-//   2. Rxx on v_mfma_f64_16x16x4_f64: 4 real MFMAs per 4 snapshots (Re = xr xr^T + xi xi^T, Im = xi xr^T - xr xi^T);
-//   3. trace + diagonal loading by a 16-lane shuffle sum; right-looking Cholesky Rxx = L L^H in LDS with all 64 lanes on
-//      the trailing update, V steps, wave-synchronous (no workgroup barriers: each wave owns its matrix);
-//   4. a^H Rxx^-1 a = |L^-1 a|^2: every lane forward-substitutes L y = a for its steering angles with L broadcast from
-//      LDS -- V (V + 1) / 2 complex MACs per angle instead of the 16 x 16 of an explicit inverse and a second GEMM.
-constexpr int CAPON_KT = 64;                        // snapshots staged per pass
-constexpr int CAPON_XP = CAPON_KT + 2;              // LDS row pitch of the snapshot tile (complex64 elements)
-constexpr int CAPON_WAVE_LDS = 16 * CAPON_XP * 8 + 16 * 17 * 16 + 16 * 8;   // tile + matrix + 1 / diag
+// Earlier forms, for the record: round 1 ran one 64-thread workgroup per bin with a serial Cholesky (160 ns per bin);
+// round 2 one wave per bin with an LDS snapshot tile, a wave-synchronous Cholesky and a forward substitution per angle
+// (V (V + 1) / 2 complex multiply-adds per angle: ~10 k vector-ALU clocks per bin next to the 8.2 k clocks its 128 MFMAs
+// occupy the matrix pipe -- 6.7 us per frame at 32 x 512 bins, matrix pipe 31 % busy).  This form:
+// For a uniform line array a_v = z^v, so a^H Rxx^-1 a = g_0 + 2 Re sum_{d >= 1} g_d conj(z)^d with g_d the sum of the
+// d-th lower diagonal of Rxx^-1: V - 1 complex multiply-adds per steering angle instead of the V (V + 1) / 2 of a
+// forward substitution, once the inverse is there.  Per (frame, range bin), one wave:
+//   1. snapshots straight from global memory into MFMA operand registers (the covariance sums over snapshots, so WHICH
+//      snapshot a lane feeds to a step is free: lane (antenna i, slot s) takes 16-byte pairs 8 j + 2 s of each 32-snapshot
+//      chunk -- every load instruction reads whole 64-byte runs); the next chunk (or the next bin's first) is in flight
+//      during the MFMAs; no LDS tile;
+//   2. Rxx on v_mfma_f64_16x16x4_f64 as before; the C/D registers ARE the matrix layout of step 3 (column = lane & 15,
+//      rows (lane >> 4) + 4 q);
+//   3. diagonal loading, then V symmetric sweeps (Gauss-Jordan on a Hermitian positive definite matrix, no pivoting):
+//      the pivot column goes through a 16-entry LDS strip (A_kc = conj(A_ck)), everything else stays in registers;
+//      one reciprocal per sweep, no square roots; the result is -Rxx^-1;
+//   4. the V diagonal sums by V lanes out of an LDS copy, then Horner in conj(z) for every angle of the lane.
+// About 5 k vector-ALU clocks per bin next to the 8.2 k clocks its 128 MFMAs occupy the matrix pipe, four waves per SIMD
+// so that one wave's sweeps run under another's MFMAs (the Cholesky / substitution form above needed ~10 k).
+constexpr int CAPON2_WAVE_LDS = 16 * 16 + 16 * 17 * 16 + 16 * 16;     // pivot column + matrix copy + diagonal sums
+constexpr int CAPON2_UTAB = 192;                                     // conj(z) of the first 192 angles, per workgroup
 
-// LDS traffic inside one wave needs no hardware barrier (DS instructions of a wave execute in order); the compiler
-// must not move accesses across the hand-over
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int HV>       // antennas V <= 2 HV: sizes the register arrays (prefetched rows, substitution vector)
-__global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__restrict__ X, const cplx<double> *__restrict__ Ast,
-                                                      float *__restrict__ out, int V, int R, int K, int T, long n_bins,
-                                                      double delta, long long *clk) {
+// Snapshot chunks (32 per chunk) alternate between two register slots; the loads of chunk c + 2 (or of the next bin's
+// chunk of the same slot) are issued right after the MFMAs that consumed the slot, so two chunks = 64 MFMAs of look-ahead
+// are always in flight -- with one chunk the 2 k clocks of 32 MFMAs did not cover an HBM round trip under load.
+template <int NQ, bool ALIGNED>     // antennas V <= 4 NQ: register rows per lane; ALIGNED: K a multiple of 32 (no chunk tail)
+__global__ __launch_bounds__(256, 4) void k_capon_sweep(const cplx<float> *__restrict__ X, const cplx<double> *__restrict__ Zt,
+                                                        float *__restrict__ out, int V, int R, int K, int T, int n_bins,
+                                                        double delta, long long *clk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    char *base = smem + (size_t)w * CAPON_WAVE_LDS;
-    cplx<float> *Xs = reinterpret_cast<cplx<float> *>(base);                              // [16][CAPON_XP]
-    cplx<double>(*Mx)[17] = reinterpret_cast<cplx<double>(*)[17]>(base + 16 * CAPON_XP * 8);
-    double *inv_d = reinterpret_cast<double *>(base + 16 * CAPON_XP * 8 + 16 * 17 * 16);
-    const int li = l & 15, lk = l >> 4;
-    // rows >= V of the tile stay zero
-    for (int e = l; e < 16 * CAPON_XP; e += 64) Xs[e] = cplx<float>{0.f, 0.f};
-    wave_lds_sync();
-    // Steering vectors by recurrence: a_v(theta) = z^v with z = a_1 = exp(-j pi sin(theta)).  A lane serves the same
-    // angles t = l, l + 64, ... for every bin, so their z live in registers for the whole kernel; the table form read
-    // a_i[t] from global memory inside the substitution loop -- twelve dependent L2 round trips per angle and bin, which
-    // made phase 4 ~60 k of the ~67 k clocks a wave spent on a bin.  (11 complex products: ~3e-15 relative.)
-    constexpr int ZR = 1;                       // angle rounds held in registers (T <= 256); further rounds reload z
-    cplx<double> zreg[ZR];
-#pragma unroll
-    for (int q = 0; q < ZR; ++q) {
-        const int t = l + 64 * q;
-        zreg[q] = (t < T && V > 1) ? Ast[(long)T + t] : cplx<double>{1.0, 0.0};
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, li = l & 15, lk = l >> 4;
+    cplx<double> *utab = reinterpret_cast<cplx<double> *>(smem);                           // [CAPON2_UTAB]
+    char *base = smem + CAPON2_UTAB * 16 + (size_t)w * CAPON2_WAVE_LDS;
+    cplx<double> *colbuf = reinterpret_cast<cplx<double> *>(base);                         // [16]
+    cplx<double>(*Mx)[17] = reinterpret_cast<cplx<double>(*)[17]>(base + 256);
+    cplx<double> *gbuf = reinterpret_cast<cplx<double> *>(base + 256 + 16 * 17 * 16);      // [16]
+    for (int t = threadIdx.x; t < CAPON2_UTAB; t += 256) {
+        const cplx<double> z = t < T ? Zt[t] : cplx<double>{1.0, 0.0};
+        utab[t] = cplx<double>{z.x, -z.y};
     }
-    // half a wave per antenna row: lane h = l & 31 brings snapshots k0 + 2h, 2h + 1 of rows (l >> 5), (l >> 5) + 2, ...
-    f32x4 pre[HV];
-    auto fetch_chunk = [&](const cplx<float> *xrow, int k0) {
+    __syncthreads();
+    constexpr int ZR = CAPON2_UTAB / 64;
+    const int n_chunks = (K + 31) >> 5;
+    // lanes of the padding rows (li >= V) read antenna 0 again: their products only reach covariance entries with a row or
+    // a column >= V, which nothing below reads
+    const long lane_off = (long)(li < V ? li : 0) * R * K + 2 * lk;
+    f32x4 slot0[4], slot1[4];
+    auto fetch = [&](f32x4 *dst, const cplx<float> *xrow, int chunk) {        // xrow: antenna row of the lane, + 2 lk
+        if (ALIGNED) {
 #pragma unroll
-        for (int i = 0; i < HV; ++i) {
-            const int v = (l >> 5) + 2 * i, k = k0 + 2 * (l & 31);
-            f32x4 q = {0.f, 0.f, 0.f, 0.f};
-            if (v < V) {
-                const cplx<float> *src = xrow + (long)v * R * K + k;
-                if (k + 1 < K && ((K & 1) == 0)) q = *reinterpret_cast<const f32x4 *>(src);     // 16-B aligned when K is even
-                else {
-                    if (k < K) { q.x = src[0].x; q.y = src[0].y; }
-                    if (k + 1 < K) { q.z = src[1].x; q.w = src[1].y; }
-                }
+            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const f32x4 *>(xrow + 32 * chunk + 8 * j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 32 * chunk + 8 * j + 2 * lk, ka = k < K ? k : K - 1, kb = k + 1 < K ? k + 1 : K - 1;
+                const cplx<float> a = xrow[ka - 2 * lk], b = xrow[kb - 2 * lk];
+                dst[j] = f32x4{k < K ? a.x : 0.f, k < K ? a.y : 0.f, k + 1 < K ? b.x : 0.f, k + 1 < K ? b.y : 0.f};
             }
-            pre[i] = q;
         }
     };
-    auto stash_chunk = [&]() {
+    v4d cr, ci;
+    auto mfma_chunk = [&](const f32x4 *cur) {
 #pragma unroll
-        for (int i = 0; i < HV; ++i) {
-            const int v = (l >> 5) + 2 * i;
-            if (v < V) *reinterpret_cast<f32x4 *>(&Xs[v * CAPON_XP + 2 * (l & 31)]) = pre[i];
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double xr = e ? cur[j].z : cur[j].x, xi = e ? cur[j].w : cur[j].y;
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xr, ci, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr, xi, ci, 0, 0, 0);
+            }
         }
     };
-    const long first_bin = (long)blockIdx.x * 4 + w, bin_step = (long)gridDim.x * 4;
-    for (long bin = first_bin; bin < n_bins; bin += bin_step) {
-        const long f = bin / R;
-        const int r = (int)(bin - f * R);
-        const cplx<float> *xb = X + ((f * V) * R + r) * (long)K;        // antenna v at xb + v * R * K
+    // (frame, range bin) of this wave's bins, advanced without divisions: bin -> bin + 4 gridDim.x
+    const int first_bin = blockIdx.x * 4 + w, bin_step = gridDim.x * 4;
+    const int step_f = bin_step / R, step_r = bin_step - step_f * R;
+    int nf = first_bin / R, nr = first_bin - nf * R;        // of the NEXT bin to be fetched
+    auto row_of = [&](int f, int r) { return X + ((long)f * V * R + r) * (long)K + lane_off; };
+    const cplx<float> *nrow = row_of(nf, nr);
+    if (first_bin < n_bins) {
+        fetch(slot0, nrow, 0);
+        if (n_chunks > 1) fetch(slot1, nrow, 1);
+    }
+    for (int bin = first_bin; bin < n_bins; bin += bin_step) {
         auto mark = [&](int i) {        // diagnostics (MMW_PHASE_CLOCKS=1): phase boundaries of workgroup 0, wave 0
             if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[i] = (long long)__builtin_amdgcn_s_memtime();
         };
         mark(0);
-        // ---- 1 + 2: covariance.  The snapshot chunks are software pipelined: chunk c + 1 travels from global memory to
-        //      registers while the MFMAs of chunk c run out of the LDS tile, and chunk 0 of the NEXT bin during this bin's
-        //      Cholesky (below) -- the exposed load latency was ~2/3 of this phase's 18 k clocks.
-        v4d cr = {0, 0, 0, 0}, ci = {0, 0, 0, 0};
-        if (bin == first_bin) {
-            fetch_chunk(xb, 0);
-            stash_chunk();
-            wave_lds_sync();
+        // ---- 1 + 2: covariance
+        cr = v4d{0, 0, 0, 0};
+        ci = v4d{0, 0, 0, 0};
+        const cplx<float> *crow = nrow;
+        const int nbin = bin + bin_step;
+        nf += step_f;
+        nr += step_r;
+        if (nr >= R) {
+            nr -= R;
+            ++nf;
         }
-        for (int k0 = 0; k0 < K; k0 += CAPON_KT) {
-            const bool more = k0 + CAPON_KT < K;
-            if (more) fetch_chunk(xb, k0 + CAPON_KT);
-#pragma unroll 4
-            for (int kk = 0; kk < CAPON_KT; kk += 4) {
-                const cplx<float> x = Xs[li * CAPON_XP + kk + lk];       // operand maps: A[i = l&15][k = l>>4], B[k][j = l&15]
-                const double xr = x.x, xi = x.y;
-                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, cr, 0, 0, 0);
-                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, cr, 0, 0, 0);
-                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xr, ci, 0, 0, 0);
-                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr, xi, ci, 0, 0, 0);
-            }
-            wave_lds_sync();
-            if (more) {
-                stash_chunk();
-                wave_lds_sync();
+        const bool more = nbin < n_bins;
+        nrow = row_of(more ? nf : 0, more ? nr : 0);
+        for (int c = 0; c < n_chunks; c += 2) {
+            mfma_chunk(slot0);
+            if (c + 2 < n_chunks) fetch(slot0, crow, c + 2);
+            else if (more) fetch(slot0, nrow, 0);
+            if (c + 1 < n_chunks) {
+                mfma_chunk(slot1);
+                if (c + 3 < n_chunks) fetch(slot1, crow, c + 3);
+                else if (more && n_chunks > 1) fetch(slot1, nrow, 1);
             }
         }
         mark(1);
-        // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+        // ---- 3: f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.  Diagonal loading, sweeps.
         const double invK = 1.0 / (double)K;
+        cplx<double> a[NQ];
+        double tr = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Mx[lk + 4 * q][li] = cplx<double>{cr[q] * invK, ci[q] * invK};
-        wave_lds_sync();
-        // next bin's first chunk: in flight during the Cholesky, into the (free) tile before the substitution
-        const long nbin = bin + bin_step;
-        if (nbin < n_bins) {
-            const long nf = nbin / R;
-            fetch_chunk(X + ((nf * V) * R + (nbin - nf * R)) * (long)K, 0);
+        for (int q = 0; q < NQ; ++q) {
+            a[q] = cplx<double>{cr[q] * invK, ci[q] * invK};
+            if (lk + 4 * q == li && li < V) tr += a[q].x;
         }
-        // ---- 3: diagonal loading, Cholesky (lower triangle of Mx becomes L, diagonal real)
-        double tr = (l < V) ? Mx[l][l].x : 0.0;
-        for (int d = 8; d >= 1; d >>= 1) tr += __shfl_xor(tr, d, 64);      // lanes 0..15 hold the 16 diagonal terms
-        tr = __shfl(tr, 0, 64);
-        if (l < V) Mx[l][l] = cplx<double>{Mx[l][l].x + delta * tr / (double)V, 0.0};
-        wave_lds_sync();
-        for (int j = 0; j < V; ++j) {
-            const double d = sqrt(Mx[j][j].x), inv = 1.0 / d;
-            wave_lds_sync();
-            if (l == j) {
-                Mx[j][j] = cplx<double>{d, 0.0};
-                inv_d[j] = inv;
-            } else if (l > j && l < V) Mx[l][j] = Mx[l][j] * inv;
-            wave_lds_sync();
+        for (int d = 32; d >= 1; d >>= 1) tr += __shfl_xor(tr, d, 64);
+        const double load = delta * tr / (double)V;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = l + 64 * q, i = idx >> 4, c = idx & 15;
-                if (c > j && c <= i && i < V) {
-                    const cplx<double> a = Mx[i][j], b = Mx[c][j];
-                    Mx[i][c] = Mx[i][c] - cplx<double>{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};   // a * conj(b)
+        for (int q = 0; q < NQ; ++q)
+            if (lk + 4 * q == li && li < V) a[q] = cplx<double>{a[q].x + load, 0.0};
+        // sweep k = 4 kq + kk: the pivot row lives in register kq of the lanes with lk == kk
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) {
+            for (int kk = 0; kk < 4 && 4 * kq + kk < V; ++kk) {
+                const int k = 4 * kq + kk;
+                if (li == k) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) colbuf[lk + 4 * q] = a[q];
                 }
+                wave_lds_sync();
+                const double d = colbuf[k].x;
+                const cplx<double> pc = colbuf[li];
+                cplx<double> t[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) t[q] = colbuf[lk + 4 * q];
+                double inv = __builtin_amdgcn_rcp(d);
+                inv = fma(fma(-d, inv, 1.0), inv, inv);
+                inv = fma(fma(-d, inv, 1.0), inv, inv);
+                // everywhere: A_ic -= (A_ik / d) conj(A_ck); then the pivot column becomes A_ik / d, the pivot row
+                // conj(A_ck) / d and the pivot itself -1 / d   (symmetric sweep: the matrix ends as -Rxx^-1)
+                const bool ck = li == k;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    t[q] = cplx<double>{t[q].x * inv, t[q].y * inv};
+                    const double nx = fma(-t[q].y, pc.y, fma(-t[q].x, pc.x, a[q].x));
+                    const double ny = fma(-t[q].y, pc.x, fma(t[q].x, pc.y, a[q].y));
+                    a[q] = ck ? t[q] : cplx<double>{nx, ny};
+                }
+                if (lk == kk) a[kq] = ck ? cplx<double>{-inv, 0.0} : cplx<double>{pc.x * inv, -pc.y * inv};
+                wave_lds_sync();            // the strip is rewritten by the next sweep
             }
-            wave_lds_sync();
-        }
-        if (nbin < n_bins) {
-            stash_chunk();
-            wave_lds_sync();
         }
         mark(2);
-        // ---- 4: P(theta) = 1 / |L^-1 a(theta)|^2
-        auto solve = [&](int t, cplx<double> z) {
-            cplx<double> y[2 * HV];
-            cplx<double> a = cplx<double>{1.0, 0.0};      // a_0
-            double p = 0.0;
+        // ---- 4: diagonal sums of Rxx^-1 = -a, then P = 1 / (g_0 + 2 Re sum_d g_d conj(z)^d)
 #pragma unroll
-            for (int i = 0; i < 2 * HV; ++i) {
-                if (i < V) {
-                    cplx<double> s = a;
-#pragma unroll
-                    for (int k = 0; k < i; ++k) s = s - cmul(Mx[i][k], y[k]);      // Mx[i][k]: same address in every lane
-                    y[i] = s * inv_d[i];
-                    p += y[i].x * y[i].x + y[i].y * y[i].y;
-                    a = cmul(a, z);
-                }
-            }
-            out[bin * T + t] = (float)(1.0 / p);
+        for (int q = 0; q < NQ; ++q) Mx[lk + 4 * q][li] = a[q];
+        wave_lds_sync();
+        if (l < V) {
+            cplx<double> g = cplx<double>{0.0, 0.0};
+            for (int qd = 0; qd + l < V; ++qd) g = g - Mx[qd + l][qd];
+            gbuf[l] = g;
+        }
+        wave_lds_sync();
+        auto spectrum = [&](double re_sum, double g0) {
+            const double den = g0 + 2.0 * re_sum;
+            double r = __builtin_amdgcn_rcp(den);
+            r = fma(fma(-den, r, 1.0), r, r);
+            return (float)fma(fma(-den, r, 1.0), r, r);
         };
+        const double g0 = gbuf[0].x;
+        // Horner: s = u (g_1 + u (g_2 + ... + u g_{V-1})), only Re(s) of the last product is needed
+        cplx<double> u[ZR], acc[ZR];
+#pragma unroll
+        for (int q = 0; q < ZR; ++q) {
+            u[q] = utab[l + 64 * q];
+            acc[q] = V > 1 ? gbuf[V - 1] : cplx<double>{0.0, 0.0};
+        }
+        for (int d = V - 2; d >= 1; --d) {
+            const cplx<double> g = gbuf[d];
+#pragma unroll
+            for (int q = 0; q < ZR; ++q) {
+                const double nx = fma(-acc[q].y, u[q].y, fma(acc[q].x, u[q].x, g.x));
+                acc[q].y = fma(acc[q].y, u[q].x, fma(acc[q].x, u[q].y, g.y));
+                acc[q].x = nx;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < ZR; ++q)
-            if (l + 64 * q < T) solve(l + 64 * q, zreg[q]);
-        for (int t = l + 64 * ZR; t < T; t += 64) solve(t, V > 1 ? Ast[(long)T + t] : cplx<double>{1.0, 0.0});
+            if (l + 64 * q < T) out[(long)bin * T + l + 64 * q] = spectrum(fma(-acc[q].y, u[q].y, acc[q].x * u[q].x), g0);
+        for (int tt = l + 64 * ZR; tt < T; tt += 64) {
+            const cplx<double> z = Zt[tt], uu = cplx<double>{z.x, -z.y};
+            cplx<double> s = V > 1 ? gbuf[V - 1] : cplx<double>{0.0, 0.0};
+            for (int d = V - 2; d >= 1; --d) s = cmul(s, uu) + gbuf[d];
+            out[(long)bin * T + tt] = spectrum(s.x * uu.x - s.y * uu.y, g0);
+        }
         mark(3);
         wave_lds_sync();
     }
@@ -399,38 +668,49 @@ __global__ __launch_bounds__(256, 3) void k_capon_batch(const cplx<float> *__res
 
 inline int capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_out, int n_frames, int V, int R, int K,
                  int T, double delta) {
-    std::vector<double> ast((size_t)V * T * 2, 0.0);
-    for (int v = 0; v < V; ++v)
+    // z_t = a_1(theta_t) = exp(-j pi sin(theta_t)); the table stays on the device while the caller keeps its angle grid
+    // (an upload per call was a host synchronisation per call)
+    if (ctx->capon_key.size() != (size_t)T || std::memcmp(ctx->capon_key.data(), h_thetas, (size_t)T * sizeof(double)) != 0) {
+        std::vector<double> zt((size_t)T * 2);
         for (int t = 0; t < T; ++t) {
-            const double ph = -M_PI * (double)v * std::sin(h_thetas[t]);     // a_v = exp(-j pi v sin(theta))
-            ast[((size_t)v * T + t) * 2] = std::cos(ph);
-            ast[((size_t)v * T + t) * 2 + 1] = std::sin(ph);
+            const double ph = -M_PI * std::sin(h_thetas[t]);
+            zt[2 * t] = std::cos(ph);
+            zt[2 * t + 1] = std::sin(ph);
         }
-    MMW_TRY(ensure_scratch(ctx, ast.size() * sizeof(double)));
-    MMW_HIP(hipMemcpyAsync(ctx->scratch, ast.data(), ast.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MMW_HIP(hipStreamSynchronize(ctx->stream));   // ast is a host temporary
+        MMW_HIP(hipStreamSynchronize(ctx->stream));                     // a launch in flight may still read the old table
+        if (ctx->capon_z) (void)hipFree(ctx->capon_z);
+        ctx->capon_z = nullptr;
+        ctx->capon_key.clear();
+        MMW_HIP(hipMalloc(&ctx->capon_z, zt.size() * sizeof(double)));
+        MMW_HIP(hipMemcpy(ctx->capon_z, zt.data(), zt.size() * sizeof(double), hipMemcpyHostToDevice));
+        ctx->capon_key.assign(h_thetas, h_thetas + T);
+    }
     ProfScope ps(ctx, "capon");
-    const long n_bins = (long)n_frames * R;
-    const int lds = 4 * CAPON_WAVE_LDS;
-    // three workgroups (12 waves) fit a CU's LDS; a few per CU, each wave walking its share of the bins
-    const long want = (n_bins + 3) / 4;
-    const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 3 * std::max(1, tune_int("MMW_CAPON_WG_ROUNDS", 2)));
-    auto kern = V <= 4 ? k_capon_batch<2> : V <= 8 ? k_capon_batch<4> : V <= 12 ? k_capon_batch<6> : k_capon_batch<8>;
+    const int n_bins = n_frames * R;
+    // sixteen waves per CU (four per SIMD), each wave walking its share of the bins
+    const long want = ((long)n_bins + 3) / 4;
+    const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 4 * std::max(1, tune_int("MMW_CAPON_WG_ROUNDS", 1)));
+    const int lds = CAPON2_UTAB * 16 + 4 * CAPON2_WAVE_LDS;
+    if ((long)n_frames * R >= (1L << 31)) return set_error(MMW_ERR_INVALID, "capon: more than 2^31 range bins in one call");
+    auto kern = (K & 31) == 0 ? (V <= 4 ? k_capon_sweep<1, true> : V <= 8 ? k_capon_sweep<2, true> : V <= 12 ? k_capon_sweep<3, true>
+                                                                                             : k_capon_sweep<4, true>)
+                              : (V <= 4 ? k_capon_sweep<1, false> : V <= 8 ? k_capon_sweep<2, false> : V <= 12 ? k_capon_sweep<3, false>
+                                                                                              : k_capon_sweep<4, false>);
     if (tune_int("MMW_PHASE_CLOCKS", 0)) {
         long long *d = nullptr, h[4] = {0};
         MMW_HIP(hipMalloc((void **)&d, sizeof(h)));
         MMW_HIP(hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
-                           (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, n_bins, delta, d);
+                           (const cplx<double> *)ctx->capon_z, d_out, V, R, K, T, n_bins, delta, d);
         MMW_HIP(hipStreamSynchronize(ctx->stream));
         MMW_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
         MMW_HIP(hipFree(d));
-        std::fprintf(stderr, "capon clocks (last bin of workgroup 0 wave 0): covariance %lld, Cholesky %lld, substitution %lld\n",
+        std::fprintf(stderr, "capon clocks (last bin of workgroup 0 wave 0): covariance %lld, sweeps %lld, spectrum %lld\n",
                      h[1] - h[0], h[2] - h[1], h[3] - h[2]);
         return check_launch("capon");
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, (const cplx<float> *)d_X,
-                       (const cplx<double> *)ctx->scratch, d_out, V, R, K, T, n_bins, delta, (long long *)nullptr);
+                       (const cplx<double> *)ctx->capon_z, d_out, V, R, K, T, n_bins, delta, (long long *)nullptr);
     return check_launch("capon");
 }
 

@@ -119,6 +119,8 @@ struct mmw_ctx {
     size_t scratch_bytes = 0;
     std::vector<void *> owned;  // mmw_malloc'ed blocks still alive (freed at destroy)
     std::deque<mmw::CztPlan> czt_plans;         // (deque: pointers to cached plans survive later insertions)
+    void *capon_z = nullptr;                    // exp(-j pi sin(theta_t)) of the last Capon angle grid ...
+    std::vector<double> capon_key;              // ... and the grid it was built from
 };
 
 namespace mmw {

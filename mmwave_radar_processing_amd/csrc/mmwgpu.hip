@@ -169,6 +169,7 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
     }
     for (void *p : ctx->owned) (void)hipFree(p);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->capon_z) (void)hipFree(ctx->capon_z);
     if (ctx->chain_ctl) (void)hipFree(ctx->chain_ctl);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -2084,10 +2085,12 @@ int mmw_diag_czt_runs(const double *h_freq, int M, int n_used, int *h_runs, int 
 }
 
 int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops) {
-    MMW_REQUIRE(ctx && tflops && (kind == 0 || kind == 1), "bad argument");
+    MMW_REQUIRE(ctx && tflops && kind >= 0 && kind <= 5, "bad argument");
     MMW_JOIN(ctx);
     MMW_TRY(ensure_scratch(ctx, 256));
-    const int iters = 1 << 15, wgs = ctx->num_cu * 2;            // 8 waves per CU = 2 per SIMD
+    // kinds 4 / 5: kinds 2 / 3 (vector FMAs between the MFMAs) with ONE wave per SIMD
+    const int iters = 1 << 15, wgs = ctx->num_cu * (kind >= 4 ? 1 : 2);            // 8 waves per CU = 2 per SIMD
+    if (kind >= 4) kind -= 2;
     hipLaunchKernelGGL(k_diag_mfma, dim3(wgs), dim3(256), 0, ctx->stream, (float *)ctx->scratch, 256, kind);    // warm-up
     MMW_HIP(hipEventRecord(ctx->t0, ctx->stream));
     hipLaunchKernelGGL(k_diag_mfma, dim3(wgs), dim3(256), 0, ctx->stream, (float *)ctx->scratch, iters, kind);
@@ -2096,7 +2099,7 @@ int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops) {
     MMW_HIP(hipEventSynchronize(ctx->t1));
     float ms = 0.f;
     MMW_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
-    const double flops_per_mfma = kind == 0 ? 2.0 * 32 * 32 * 2 : 2.0 * 16 * 16 * 4;
+    const double flops_per_mfma = kind != 1 ? 2.0 * 32 * 32 * 2 : 2.0 * 16 * 16 * 4;
     *tflops = (double)wgs * 4 * iters * 4 * flops_per_mfma / (ms * 1e-3) / 1e12;
     return MMW_OK;
 }

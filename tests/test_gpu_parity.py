@@ -453,6 +453,44 @@ def test_bartlett_mfma_vs_oracle_shapes(S, E, naz, nel):
     assert rel_err(outb[2], 2.0 * ref) <= SPEC_TOL
 
 
+def test_bartlett_both_contraction_paths():
+    """The steering-matrix contraction has two kernels: the fused tile kernel (small problems: steering evaluated in the
+    kernel) and the LDS-tiled GEMM behind k_steer (large ones).  A problem big enough for the second by default, and --
+    in fresh processes, the knob is read once -- the small shapes forced through each path and through the polynomial
+    sine / cosine variant of the tile kernel."""
+    from mmwave_radar_processing_amd.processors.steering_beamformers import SyntheticArrayBeamformerCore
+    rng = np.random.default_rng(77)
+    S, E = 512, 128
+    az, el = np.linspace(-1.2, 1.2, 300), np.linspace(-0.4, 0.4, 3)            # 900 directions: 48 x 29 tiles of 32 x 32
+    lam = 299792458.0 / 77e9
+    X = (rng.standard_normal((3, S, E)) + 1j * rng.standard_normal((3, S, E))).astype(np.complex64)
+    P = rng.uniform(-0.05, 0.05, (3, 3, E))
+    out = SyntheticArrayBeamformerCore(az, el, lam).contract(X, P)
+    for f in range(3):
+        assert rel_err(out[f], O.bartlett_response(X[f].astype(complex), P[f], O.steering_dirs(az, el), lam)) <= SPEC_TOL
+    import subprocess, sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from oracle import oracle_np as O\n"
+            "from mmwave_radar_processing_amd.processors.steering_beamformers import SyntheticArrayBeamformerCore\n"
+            "lam = 299792458.0 / 77e9; worst = 0.0\n"
+            "for S, E, naz, nel in ((256, 256, 60, 1), (128, 100, 33, 3), (70, 37, 5, 2)):\n"
+            "    rng = np.random.default_rng(S + E)\n"
+            "    X = (rng.standard_normal((2, S, E)) + 1j * rng.standard_normal((2, S, E))).astype(np.complex64)\n"
+            "    P = rng.uniform(-0.05, 0.05, (2, 3, E))\n"
+            "    az, el = np.linspace(-1.2, 1.2, naz), np.linspace(-0.4, 0.4, nel)\n"
+            "    out = SyntheticArrayBeamformerCore(az, el, lam).contract(X, P)\n"
+            "    for f in range(2):\n"
+            "        ref = O.bartlett_response(X[f].astype(complex), P[f], O.steering_dirs(az, el), lam)\n"
+            "        worst = max(worst, float(np.abs(out[f] - ref).max() / np.abs(ref).max()))\n"
+            "print(worst)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for knobs in ({"MMW_BARTLETT_PATH": "2"}, {"MMW_BARTLETT_PATH": "1"}, {"MMW_BARTLETT_PATH": "1", "MMW_BARTLETT_POLY": "1"}):
+        run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **knobs), timeout=300)
+        assert run.returncode == 0, run.stderr
+        worst = float(run.stdout.strip().splitlines()[-1])
+        print(f"bartlett {knobs}: worst deviation {worst:.2e} of the peak")
+        assert worst <= SPEC_TOL
+
+
 def test_capon_mfma_vs_own_oracle():
     """BASELINE config 4 shape: 12-element array x 512 range bins.  NO UPSTREAM ORACLE (the reference has no Capon code,
     SURVEY.md F2): parity unpinned -- checked against this build's own float64 definition (oracle_np.capon_spectrum),
@@ -485,6 +523,13 @@ def test_capon_mfma_vs_own_oracle():
     P2 = CaponBeamformer(th2, delta=1e-2).process(X2)
     for f in range(2):
         np.testing.assert_allclose(P2[f], O.capon_spectrum(X2[f], th2, delta=1e-2), rtol=2e-5)
+    # sixteen antennas (four register rows per lane), 200 angles (beyond the 192 held in the LDS table), K = 96 and K = 33
+    for Vn, Kn in ((16, 96), (13, 33), (3, 64), (1, 32)):
+        X3 = (rng.standard_normal((2, Vn, 9, Kn)) + 1j * rng.standard_normal((2, Vn, 9, Kn))).astype(np.complex64)
+        th3 = np.linspace(-1.2, 1.2, 200)
+        P3 = CaponBeamformer(th3, delta=1e-2).process(X3)
+        for f in range(2):
+            np.testing.assert_allclose(P3[f], O.capon_spectrum(X3[f], th3, delta=1e-2), rtol=2e-5)
     # two uncorrelated sources 0.12 rad apart: closer than the Rayleigh width of a 12-element half-wavelength array
     # (2 / V = 0.17 in sin(theta)), so the delay-and-sum (Bartlett) spectrum shows ONE lobe while the MVDR spectrum,
     # whose peak width shrinks with SNR, shows two peaks at the source angles with a dip between them.  With exact

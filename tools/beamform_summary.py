@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build profiles/r02_beamform.json from tools/kbench.py's beamformer entries and the rocprofv3 --pmc database of
+"""Build profiles/rNN_beamform.json from tools/kbench.py's beamformer entries and the rocprofv3 --pmc database of
 tools/beamform_prof.py (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE).
 
     python tools/beamform_summary.py <kbench.json> <pmc_results.db> <out.json> [<previous r02_beamform.json>]
@@ -12,18 +12,30 @@ kb = json.load(open(sys.argv[1]))
 db = sqlite3.connect(sys.argv[2])
 out_path = sys.argv[3]
 prev = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else {}
+LABELS = (("k_capon_batch", "k_capon_batch (32 frames per launch)"),
+          ("k_capon_sweep", "k_capon_sweep (32 frames of 12 x 512 x 128, 181 angles per launch)"),
+          ("k_cgemm_mfma", "k_cgemm_mfma (16 frames x 256 x 256 x 900 per launch)"),
+          ("k_bartlett_tile", "k_bartlett_tile (16 frames x 256 x 256 x 64 per launch, steering fused)"))
 pmc = {}
 for kernel, counter, n, total in db.execute("select kernel_name, counter_name, count(distinct dispatch_id), sum(value) from "
                                             "counters_collection group by kernel_name, counter_name"):
-    for key, label in (("k_capon_batch", "k_capon_batch (32 frames per launch)"),
-                       ("k_cgemm_mfma", "k_cgemm_mfma (16 frames x 256 x 256 x 900 per launch)")):
+    for key, label in LABELS:
         if key in kernel:
             pmc.setdefault(label, {})[counter] = total / n
 for kernel, avg in db.execute("select kernel_name, avg(end - start) from counters_collection group by kernel_name"):
-    for key, label in (("k_capon_batch", "k_capon_batch (32 frames per launch)"),
-                       ("k_cgemm_mfma", "k_cgemm_mfma (16 frames x 256 x 256 x 900 per launch)")):
+    for key, label in LABELS:
         if key in kernel:
             pmc[label]["avg_duration_us_under_pmc"] = avg / 1e3
+NOTE = ("BASELINE configs[3] (Capon/MVDR, 12-element array x 512 range bins x 128 snapshots, 181 angles -- NO UPSTREAM ORACLE, parity "
+        "unpinned) and the Bartlett steering-matrix contraction (reference ...multiFrame.py:499-585). Timings: tools/kbench.py (HIP "
+        "events, kernels alone on the chip; cgemm_ms of the 64-direction entries is the ONE fused tile kernel: steering + GEMM + "
+        "split-K sum). Matrix-core counters: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 "
+        "tools/beamform_prof.py` (10 launches each; SQ_VALU_MFMA_BUSY_CYCLES counts 64 cycles per v_mfma_f64_16x16x4_f64 / "
+        "v_mfma_f32_32x32x2_f32 summed over all 1024 SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs). Peaks: measured on the same "
+        "device by mmw_diag_mfma_peak (back-to-back MFMAs, register operands, 2 waves/SIMD): the guide's 157.3 TF for f32 MFMA is "
+        "reproduced; it lists no f64 figure, the probe gives ~47 TF for v_mfma_f64_16x16x4_f64 (the clock drops under that load). "
+        "mfma_valu_overlap_probe: the same MFMA stream with 8 / 16 independent v_fma_f32 after every MFMA, two waves and one wave "
+        "per SIMD -- vector float32 work is NOT hidden under float32 MFMAs on this chip.")
 res = {}
 for label, c in pmc.items():
     cyc = c["GRBM_GUI_ACTIVE"] / 8
@@ -32,8 +44,12 @@ for label, c in pmc.items():
                   "mfma_busy_fraction_of_simd_time": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024),
                   "SQ_BUSY_CYCLES_per_launch": c["SQ_BUSY_CYCLES"],
                   "avg_duration_us_under_pmc": c.get("avg_duration_us_under_pmc")}
-out = {"note": prev.get("note", ""), "mfma_peak_measured_TFLOPs": kb.get("mfma_peak_measured_TFLOPs"),
+out = {"note": NOTE, "mfma_peak_measured_TFLOPs": kb.get("mfma_peak_measured_TFLOPs"),
+       "mfma_valu_overlap_probe_TFLOPs_of_MFMA_work": kb.get("mfma_valu_overlap_probe"),
        "kbench": {k: v for k, v in kb.items() if k.startswith(("bartlett", "capon"))}, "pmc": res,
+       "round2_for_comparison": {k: prev.get("kbench", {}).get(k) for k in
+                                 ("bartlett_F1_256x256x64", "bartlett_F16_256x256x64", "capon_F32_12x512x128_T181")},
+       "round2_pmc": prev.get("pmc"),
        "round1_for_comparison": prev.get("round1_for_comparison")}
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps({"kbench": out["kbench"], "pmc": res}, indent=1))

@@ -180,6 +180,13 @@ def main():
         _lib.check(L.mmw_diag_mfma_peak(ctx.handle, kind, ct.byref(v)))
         peak[name] = v.value
     res["mfma_peak_measured_TFLOPs"] = {k: round(v, 1) for k, v in peak.items()}
+    probe = {}
+    for kind, name in ((2, "8_fma_per_mfma_2_waves_per_simd"), (3, "16_fma_per_mfma_2_waves_per_simd"),
+                       (4, "8_fma_per_mfma_1_wave_per_simd"), (5, "16_fma_per_mfma_1_wave_per_simd")):
+        v = ct.c_double(0)
+        _lib.check(L.mmw_diag_mfma_peak(ctx.handle, kind, ct.byref(v)))
+        probe[name] = round(v.value, 1)
+    res["mfma_valu_overlap_probe"] = probe
     rng = np.random.default_rng(1)
     lam = 299792458.0 / 77e9
     for Fb, Sb, Eb, Tb in ((1, 256, 256, 64), (16, 256, 256, 64), (16, 256, 256, 900)):
