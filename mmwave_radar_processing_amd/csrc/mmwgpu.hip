@@ -851,8 +851,13 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // Mixed-radix planes above 80 KB leave ONE range-Doppler workgroup per CU and are arithmetic bound: 5/8 of the chip
     // (tools/chain_modes.sh: 254 x 50, 100 x 100, 120 x 126 are 6-25 % faster at 160 than at 128 CUs; the angle stage
     // still saturates its store stream from the other 96).
-    const bool heavy_rd = !fused_rd_ok(S, C) && (size_t)S * (C | 1) * sizeof(cplx<float>) > 80 * 1024;
-    const int rd_cus_dflt = heavy_rd ? ctx->num_cu * 5 / 8 : ctx->num_cu / 2;
+    // Planes with a 127-point level are arithmetic bound wherever they run (the level is a dense real matrix product on
+    // float32 MFMAs, which share the vector ALUs): 5/8 as well at 63 x 127 (+4 %), 3/4 at 254 x 50 (one 104 KB plane per
+    // CU: 4.06 against 3.82 TB/s at 5/8; sweep of 128..208 CUs in profiles/r03_chain_rd_cus.log).
+    const size_t plane_lds = (size_t)S * (C | 1) * sizeof(cplx<float>);
+    const bool big_prime = S % 127 == 0 || C % 127 == 0;
+    const bool heavy_rd = !fused_rd_ok(S, C) && (plane_lds > 80 * 1024 || big_prime);
+    const int rd_cus_dflt = !heavy_rd ? ctx->num_cu / 2 : (big_prime && plane_lds > 100 * 1024) ? ctx->num_cu * 3 / 4 : ctx->num_cu * 5 / 8;
     p.rd_cus = env_int("MMW_RD_CUS", rd_cus_dflt);
     if (p.rd_cus < 0 || p.rd_cus >= ctx->num_cu) p.rd_cus = rd_cus_dflt;         // 0: unmasked queues
     p.ring = std::max(2, std::min(env_int("MMW_CHAIN_RING", 3), (int)PIPE_RING_MAX));
