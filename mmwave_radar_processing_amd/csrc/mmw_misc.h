@@ -363,10 +363,11 @@ __device__ __forceinline__ void argmax_gather(const float2 *rd, long f, int V, i
 // magnitude among all other bins (ws2)
 template <int NA>
 __device__ __forceinline__ void argmax_eval(const float2 (&x)[NA], int n, int A, int shift, const float2 *twA, int lane,
-                                            float &wb, int &wi, float &ws2) {
+                                            float &wb, int &wi, float &ws2, float &lane_re, float &lane_im, int &lane_idx) {
     const float NEG = -__builtin_huge_valf();
     float best = NEG, second = NEG;
     int best_idx = 0x7fffffff;
+    lane_re = lane_im = 0.f;
     for (int k = lane; k < A; k += 64) {
         float re = 0.f, im = 0.f;
         int t = 0;
@@ -386,8 +387,11 @@ __device__ __forceinline__ void argmax_eval(const float2 (&x)[NA], int n, int A,
             if (best_idx != 0x7fffffff) second = best;
             best = m;
             best_idx = kk;
+            lane_re = re;
+            lane_im = im;
         } else if (mag_gt(m, second)) second = m;
     }
+    lane_idx = best_idx;
     // wave-wide first maximum, then the largest magnitude among everything else
     wb = best;
     wi = best_idx;
@@ -406,13 +410,60 @@ __device__ __forceinline__ void argmax_eval(const float2 (&x)[NA], int n, int A,
     }
 }
 
-// lane 0: append detection `id` to the refinement list unless best - second > 2 B (also taken for NaN / inf magnitudes)
-__device__ __forceinline__ void argmax_flag(const ArgmaxRefine &rf, float sum_l1, float sum_abs, float wb, float ws2, int id) {
-    const float B = rf.k_fft * sum_l1 + rf.k_ang * sum_abs;
-    if (!(wb - ws2 > 2.f * B)) {
-        const int pos = atomicAdd(rf.n_flag, 1);
-        if (pos < rf.list_cap) rf.list[pos] = id;
+// Second pass of the certainty test (lists of at most 8 antennas; same form as detect_argmax_list in mmw_detect.h): the
+// errors of two bins of one detection are the SAME per-antenna cell errors e_i seen through two steering vectors, so
+//   |(m1 - mk)_32 - (m1 - mk)_64| <= sum_i e_i |conj(u1) W^(i k1) - conj(uk) W^(i k)| + Be^2 / (2 min(m1, mk)) + 2 c_ang,
+// far below the independent-errors 2 (Be + c_ang) for neighbouring bins.  Every bin other than the winner is tested;
+// returns true when some bin is not provably below the winner.
+template <int NA>
+__device__ __forceinline__ bool argmax_pairwise(const float2 (&x)[NA], const float (&e)[NA], int A, int shift, const float2 *twA,
+                                                int lane, int wi, float m1, float re1, float im1, float be, float c_ang) {
+    const float inv1 = 1.f / m1, u1x = re1 * inv1, u1y = im1 * inv1, two_b = 2.f * (be + c_ang);
+    const int k1 = shift ? (wi + A - A / 2) % A : wi;
+    float2 t1[NA];                      // conj(u_1) W^(i k_1)
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const float2 w = twA[t];
+            t1[i] = make_float2(u1x * w.x + u1y * w.y, u1x * w.y - u1y * w.x);
+            t += k1;
+            if (t >= A) t -= A;
+        }
     }
+    bool bad = false;
+    for (int k = lane; k < A; k += 64) {
+        const int kk = shift ? (k + A / 2) % A : k;
+        if (kk == wi) continue;
+        float2 w[NA];
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            w[i] = twA[t];
+            t += k;
+            if (t >= A) t -= A;
+        }
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {      // (cells past the list are zero: same sums as the first pass)
+            re += x[i].x * w[i].x - x[i].y * w[i].y;
+            im += x[i].x * w[i].y + x[i].y * w[i].x;
+        }
+        const float m = hypotf(re, im), margin = m1 - m;
+        bool ok = margin > two_b;
+        if (!ok && m > 0.f) {
+            const float inv = 1.f / m, ux = re * inv, uy = im * inv;
+            float lin = 0.f;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const float dx = t1[i].x - (ux * w[i].x + uy * w[i].y), dy = t1[i].y - (ux * w[i].y - uy * w[i].x);
+                lin += e[i] * __fsqrt_rn(fmaf(dx, dx, dy * dy));
+            }
+            ok = margin > 1.001f * (lin + be * be / (2.f * fminf(m1, m))) + 2.f * c_ang;
+        }
+        bad |= !ok;
+    }
+    return __ballot(bad) != 0ull;
 }
 
 template <int NA>
@@ -423,20 +474,43 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
     const int f = blockIdx.y;
     int n_det = counts[f];
     if (n_det > cap) n_det = cap;
-    float sum_l1 = 0.f;
-    if (rf.l1)
-        for (int i = 0; i < ants.n; ++i) sum_l1 += rf.l1[(long)f * V + ants.idx[i]];
+    constexpr bool PAIR = NA <= 8;      // longer lists keep the independent-errors test (more of them are refined)
+    float sum_l1 = 0.f, e[PAIR ? NA : 1];
+    if (rf.l1) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const float l = i < ants.n ? rf.l1[(long)f * V + ants.idx[i]] : 0.f;
+            sum_l1 += l;
+            if constexpr (PAIR) e[i] = rf.k_fft * l;
+        }
+    }
     // grid.x covers the usual detection counts in one pass; a wave walks on for frames with more
     for (int det = blockIdx.x * 4 + wave; det < n_det; det += gridDim.x * 4) {
         const int r = dets[((long)f * cap + det) * 2], v = dets[((long)f * cap + det) * 2 + 1];
         float2 x[NA];
-        float sum_abs, wb, ws2;
-        int wi;
+        float sum_abs, wb, ws2, lre, lim;
+        int wi, lidx;
         argmax_gather<NA>(rd, f, V, S, C, r, v, ants, x, sum_abs);
-        argmax_eval<NA>(x, ants.n, A, shift, twA, lane, wb, wi, ws2);
+        argmax_eval<NA>(x, ants.n, A, shift, twA, lane, wb, wi, ws2, lre, lim, lidx);
+        bool flag = false;
+        if (rf.l1) {
+            const float be = rf.k_fft * sum_l1, c_ang = rf.k_ang * sum_abs;
+            flag = !(wb - ws2 > 2.f * (be + c_ang));             // (also for NaN / inf magnitudes)
+            if constexpr (PAIR) {
+                if (flag && wb == wb && wb > 0.f && wb < __builtin_huge_valf()) {
+                    const int l1 = __ffsll((long long)__ballot(lidx == wi)) - 1;
+                    const float re1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lre), l1));
+                    const float im1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lim), l1));
+                    flag = argmax_pairwise<NA>(x, e, A, shift, twA, lane, wi, wb, re1, im1, be, c_ang);
+                }
+            }
+        }
         if (lane == 0) {
             out_idx[(long)f * cap + det] = wi;
-            if (rf.l1) argmax_flag(rf, sum_l1, sum_abs, wb, ws2, f * cap + det);
+            if (flag) {
+                const int pos = atomicAdd(rf.n_flag, 1);
+                if (pos < rf.list_cap) rf.list[pos] = f * cap + det;
+            }
         }
     }
 }

@@ -1642,13 +1642,11 @@ static int fill_refine_args(mmw_ctx *ctx, RefineArgs *ra, int S, int C, int A) {
 }
 
 // The worst-case bound assumes every rounding error of every partial sum lines up; measured float32 errors stay below
-// 1.2 % of it (tools/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).  The argmax kernels use
-// 1/8 of the worst case -- still ~10x above anything observed -- which cuts the float64 re-evaluations (each reads
-// the antennas' whole planes) from 1.8 % to 0.2 % of the detections; MMW_ARGMAX_BOUND_DIV=1 restores the full bound
-// (the CFAR screening of mmw_detect_points always uses the full bound).
-static float argmax_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 8)); }
-// (mmw_detect_points tests every bin against the winner with the errors of the two treated as what they are -- the same
-//  cell errors seen through two steering vectors -- and flags ~10x fewer detections: it uses the worst-case bound itself)
+// 1.2 % of it (tools/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).  Rounds 1-2 used 1/8 of
+// it to keep the float64 re-evaluations (each reads the antennas' whole planes) at 0.2 % of the detections; since round 3
+// the kernels take the FULL worst-case bound and keep the rate low with the pairwise form of the test instead (lists of up
+// to 8 antennas; longer lists: the independent-errors test, ~2 % refined).  MMW_ARGMAX_BOUND_DIV=8 restores the old divisor.
+static float argmax_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 1)); }
 static float detect_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 1)); }
 
 int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1, const void *d_rd, const int32_t *d_dets,
