@@ -305,7 +305,8 @@ def main():
                     help="record a HIP event pair around every n-th launch of each kernel inside the timed region; 0 = "
                          "auto: every launch when a step is one launch per stage, else every 7th (coprime with the "
                          "launches per step, so a short tail chunk is sampled in proportion)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))
+    _tj = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")]
+    ap.add_argument("--traffic-json", default=next((t for t in _tj if os.path.exists(t)), _tj[-1]))
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -403,9 +404,19 @@ def main():
             if rd_n:
                 avg_s = rd_ms * 1e-3 / rd_n
                 achieved = F * 2 * CUBE_BYTES / avg_s / 1e9
+                traffic, traffic_src = None, None
+                if os.path.exists(args.traffic_json):
+                    with open(args.traffic_json) as fh:
+                        per_frame = (json.load(fh).get("detect") or {}).get("rd_bytes_per_frame")
+                    if per_frame:
+                        traffic = per_frame * F
+                        traffic_src = ("static: PMC bytes per frame of this kernel from " + os.path.relpath(args.traffic_json, ROOT) +
+                                       " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
+                                       "note) x frames per launch; not measured in this run")
                 rec["roofline"] = {"bound": "hbm", "kernel": "k_rd_fused_256x128_persist (range-Doppler of all 12 planes: the "
                                    "largest stage of the pipeline)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                                   "avg_launch_us": avg_s * 1e6,
                                    "launches": rd_n, "frames_per_launch": F,
                                    "algorithmic_bytes_per_launch": F * 2 * CUBE_BYTES}
         return rec

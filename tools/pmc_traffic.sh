@@ -1,0 +1,12 @@
+# HBM-side traffic of the headline kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in SEPARATE passes, program directly
+# after --; FETCH doubled per the gfx950 note of MI355X_MICROARCH.md).  GPU box, repo root: bash tools/pmc_traffic.sh
+#  * chain: `bench.py --steps 3 --warmup 0` under MMW_CHAIN_MODE=events MMW_ANGLE_QUEUES=1 (counter collection serialises
+#    dispatches; the device-synchronised schedule needs its two launches to overlap) -- same loads and stores per frame.
+#  * detection: `bench.py --workload detect --steps 3 --warmup 0` (one stream anyway).
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r03/pmc
+for c in FETCH_SIZE WRITE_SIZE; do
+  MMW_CHAIN_MODE=events MMW_ANGLE_QUEUES=1 timeout -k 10 300 rocprofv3 --pmc $c -d gpurun_out/r03/pmc/chain_$c -o p -- python3 bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-profile --no-detect-record > /dev/null 2> gpurun_out/r03/pmc/chain_$c.err || exit 1
+  timeout -k 10 300 rocprofv3 --pmc $c -d gpurun_out/r03/pmc/det_$c -o p -- python3 bench.py --workload detect --steps 3 --warmup 0 --no-cpu-baseline --no-profile > /dev/null 2> gpurun_out/r03/pmc/det_$c.err || exit 1
+done
+python3 tools/pmc_traffic_summary.py gpurun_out/r03/pmc gpurun_out/r03/pmc_traffic.json && rm -rf gpurun_out/r03/pmc
