@@ -737,40 +737,41 @@ __global__ __launch_bounds__(CE_NT) void k_cfar_cell_exact(CellExactArgs a) {
             const int ch = ch0 + tid / CE_SG;
             const bool live = ch < C;
             for (int row0 = 0; row0 < Wr; row0 += CE_RPT) {
-                // the pass's range bins are consecutive, k0 + j:  W^((k0 + j) s) = W^(k0 s) (W^s)^j -- two table reads per
-                // sample and a float64 recurrence over the rows (a table read per row and sample kept this loop waiting on
-                // the LDS: 140 k of the kernel's 160 k clocks)
-                cplx<double> acc[CE_RPT];
-#pragma unroll
-                for (int j = 0; j < CE_RPT; ++j) acc[j] = cplx<double>{0.0, 0.0};
+                // Horner over the lane's samples s = sg + CE_SG u, last one first:
+                //   sum_u x_u W^(k (sg + CE_SG u)) = W^(k sg) ( ... (x_last z + x_(last-1)) z + ... + x_0 ),   z = W^(k CE_SG)
+                // -- one complex multiply-add (4 FMAs) per sample and range bin, no table read in the loop.  (The form before
+                // rotated a twiddle from bin to bin: 8 FMAs per sample and bin, 118 k of the kernel's ~200 k clocks.)
+                cplx<double> acc[CE_RPT], z[CE_RPT];
                 const int k0 = r - hr + row0;                         // first range bin (inside the plane: valid region)
-                int idx0 = (int)(((long)k0 * sg) % S), idx1 = sg % S;
-                const int step0 = (int)(((long)k0 * CE_SG) % S), step1 = CE_SG % S;
-                constexpr int U = 16;            // cold HBM lines: ask for 16 samples before using the first
-                for (int s0 = sg; s0 < S; s0 += U * CE_SG) {
+#pragma unroll
+                for (int j = 0; j < CE_RPT; ++j) {
+                    acc[j] = cplx<double>{0.0, 0.0};
+                    z[j] = twS[(int)(((long)(k0 + j) * CE_SG) % S)];
+                }
+                constexpr int U = 8;             // samples requested before the first is used (16 spill beside 2 x 7 accumulators)
+                const int rounds = ((S + CE_SG - 1) / CE_SG + U - 1) / U;
+                for (int rb = rounds - 1; rb >= 0; --rb) {
+                    const int s0 = sg + rb * U * CE_SG;
                     float2 xv[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u)       // (unconditional, clamped: a guarded load is followed by its own wait)
                         xv[u] = x[(long)min(s0 + u * CE_SG, S - 1) * C + (live ? ch : 0)];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
+                    for (int u = U - 1; u >= 0; --u) {
                         const int sx = s0 + u * CE_SG;
                         if (live && sx < S) {
-                            const double w = wsl[sx];
-                            const cplx<double> xw = cplx<double>{(double)xv[u].x * w, (double)xv[u].y * w}, w1 = twS[idx1];
-                            cplx<double> t = twS[idx0];
+                            const double w = wsl[sx], xr = (double)xv[u].x * w, xi = (double)xv[u].y * w;
 #pragma unroll
                             for (int j = 0; j < CE_RPT; ++j) {
-                                acc[j] = acc[j] + cmul(xw, t);
-                                if (j + 1 < CE_RPT) t = cmul(t, w1);
+                                const double nr = fma(acc[j].x, z[j].x, fma(-acc[j].y, z[j].y, xr));
+                                acc[j].y = fma(acc[j].x, z[j].y, fma(acc[j].y, z[j].x, xi));
+                                acc[j].x = nr;
                             }
-                            idx0 += step0;
-                            if (idx0 >= S) idx0 -= S;
-                            idx1 += step1;
-                            if (idx1 >= S) idx1 -= S;
                         }
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < CE_RPT; ++j) acc[j] = cmul(acc[j], twS[(int)(((long)(k0 + j) * sg) % S)]);
 #pragma unroll
                 for (int j = 0; j < CE_RPT; ++j) {
                     for (int d = 1; d < CE_SG; d <<= 1) {             // the sample groups of a chirp sit in adjacent lanes
