@@ -1,6 +1,6 @@
 # copy the round-3 summaries that are kept into profiles/ (tracked)
 set -e
-for f in pmc_traffic beamform bench_line bench_detect_line bench_detect_float64_line bench_line_under_rocprof bench_detect_line_under_rocprof kbench kbench_63x100 shapes api_latency; do
+for f in mixed_pmc pmc_traffic beamform bench_line bench_detect_line bench_detect_float64_line bench_line_under_rocprof bench_detect_line_under_rocprof kbench kbench_63x100 shapes api_latency; do
   [ -s gpurun_out/r03/$f.json ] && cp gpurun_out/r03/$f.json profiles/r03_$f.json
 done
 for f in bench_kernel_stats detect_kernel_stats beamform_kernel_stats; do [ -s gpurun_out/r03/$f.csv ] && cp gpurun_out/r03/$f.csv profiles/r03_$f.csv; done

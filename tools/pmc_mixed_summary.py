@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 --pmc passes of tools/pmc_mixed.sh into profiles/r02_mixed_pmc.json.
+"""Condense the rocprofv3 --pmc passes of tools/pmc_mixed.sh into profiles/rNN_mixed_pmc.json.
 
-    python tools/pmc_mixed_summary.py gpurun_out/prof profiles/r02_mixed_pmc.json
+    [SHAPES="12,254,50 12,63,127"] python tools/pmc_mixed_summary.py gpurun_out/prof profiles/rNN_mixed_pmc.json
 """
 import glob
 import json
@@ -29,7 +29,8 @@ out = {"note": "rocprofv3 --pmc passes (tools/pmc_mixed.sh: FETCH_SIZE, WRITE_SI
                "separate runs, program directly after --) around tools/rd_prof.py: launches of mmw_range_doppler on 2048 frames "
                "of 12 planes; values are per launch.  FETCH_SIZE doubled per the gfx950 note (MI355X_MICROARCH.md, HBM).  "
                "SQ_* counters are sums over all waves; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES count quad-cycles."}
-for tag, (S, C) in (("12x63x100", (63, 100)), ("12x254x50", (254, 50))):
+SHAPES = os.environ.get("SHAPES", "12,63,100 12,254,50").split()
+for tag, (S, C) in ((sh.replace(",", "x"), tuple(int(x) for x in sh.split(",")[1:])) for sh in SHAPES):
     planes = FRAMES * V
     cells = planes * S * C
     alg = 2 * cells * 8
