@@ -352,28 +352,28 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
             MMW_HIP(hipStreamSynchronize(ctx->stream));
             MMW_HIP(hipMemcpy(h, d_clk, sizeof(h), hipMemcpyDeviceToHost));
             MMW_HIP(hipFree(d_clk));
-            std::fprintf(stderr, "bartlett tile clocks (workgroup 0 wave 0): loads issued %lld, positions landed + rows %lld, "
-                                 "phases %lld, MFMA loop %lld, reduce + store %lld\n",
-                         h[1] - h[0], 0LL, h[2] - h[1], h[3] - h[2], h[4] - h[3]);
+            std::fprintf(stderr, "bartlett tile clocks (workgroup 0 wave 0, last chunk): loads issued %lld, phase reduction %lld, "
+                                 "MFMA loop %lld, reduce + store %lld\n",
+                         h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3]);
         }
         MMW_TRY(check_launch("bartlett_tile"));
     } else {
-    const long nW = (long)E * Tp;
-    hipLaunchKernelGGL(k_steer, dim3((unsigned)((nW + 255) / 256), (unsigned)n_frames), dim3(256), 0, ctx->stream, W, d_P, d_dirs,
-                       (const float *)ham, E, T, Tp, 1.0 / lambda_m);
-    MMW_TRY(check_launch("steer"));
-    {
-        ProfScope pg(ctx, "cgemm");
-        dim3 grid((T + CG_TN - 1) / CG_TN, (S + CG_TM - 1) / CG_TM, (unsigned)(n_frames * ksplit));
-        const long n_c = (long)n_frames * S * T;
-        hipLaunchKernelGGL(k_cgemm_mfma, grid, dim3(256), 0, ctx->stream, (const cplx<float> *)d_X, W, ksplit > 1 ? Cparts : Cm, S, T, E,
-                           E, Tp, T, (long)S * E, (long)E * Tp, (long)S * T, ksplit, kc, n_c);
-        MMW_TRY(check_launch("cgemm_mfma"));
-        if (ksplit > 1) {
-            hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n_c + 255) / 256)), dim3(256), 0, ctx->stream, Cparts, Cm, n_c, ksplit);
-            MMW_TRY(check_launch("sum_parts"));
+        const long nW = (long)E * Tp;
+        hipLaunchKernelGGL(k_steer, dim3((unsigned)((nW + 255) / 256), (unsigned)n_frames), dim3(256), 0, ctx->stream, W, d_P, d_dirs,
+                           (const float *)ham, E, T, Tp, 1.0 / lambda_m);
+        MMW_TRY(check_launch("steer"));
+        {
+            ProfScope pg(ctx, "cgemm");
+            dim3 grid((T + CG_TN - 1) / CG_TN, (S + CG_TM - 1) / CG_TM, (unsigned)(n_frames * ksplit));
+            const long n_c = (long)n_frames * S * T;
+            hipLaunchKernelGGL(k_cgemm_mfma, grid, dim3(256), 0, ctx->stream, (const cplx<float> *)d_X, W, ksplit > 1 ? Cparts : Cm, S, T, E,
+                               E, Tp, T, (long)S * E, (long)E * Tp, (long)S * T, ksplit, kc, n_c);
+            MMW_TRY(check_launch("cgemm_mfma"));
+            if (ksplit > 1) {
+                hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n_c + 255) / 256)), dim3(256), 0, ctx->stream, Cparts, Cm, n_c, ksplit);
+                MMW_TRY(check_launch("sum_parts"));
+            }
         }
-    }
     }
     // hann(S) window and FFT along S for every steering column of every frame (:537-540)
     FftArgs a{};
