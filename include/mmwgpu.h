@@ -51,7 +51,7 @@ typedef struct mmw_ctx mmw_ctx;
 const char *mmw_version(void);
 /* Bumped whenever an exported signature changes: a binding checks it at load (the argtypes of a ctypes binding are
  * hard-coded, so a library of another revision would reinterpret ints as device pointers). */
-#define MMWGPU_ABI_VERSION 3
+#define MMWGPU_ABI_VERSION 4
 int mmw_abi_version(void);
 const char *mmw_last_error(void);
 int mmw_device_count(int *count);
@@ -128,6 +128,9 @@ int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_ma
                       int n_frames, int V, int S, int C);
 int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag,
                             int n_frames, int V, int S, int C, int rx_idx);
+/* mmw_fft2_mag64: d_mag[F][S][C] float64 = | fftshift_C fft2( x[rx_idx] ) | WITHOUT windows -- the spectrum
+ *   MicroDopplerProcessor.process takes its range-gated maximum of (processors/micro_doppler_resp.py:95-105). */
+int mmw_fft2_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S, int C, int rx_idx);
 /* flags of mmw_angle_fft / mmw_chain3d (0 = complex64 output, Hann(V) window, fftshift over angle) */
 #define MMW_ANGLE_MAGNITUDE 1   /* float32 |.| output                                                    */
 #define MMW_ANGLE_NO_WINDOW 2   /* no antenna window (DopplerAzimuthProcessor on "ods" geometry)         */

@@ -20,7 +20,7 @@ MMW_OK = 0
 MMW_ERR_INVALID = -1
 MMW_ERR_TRUNCATED = -4
 MMW_ERR_UNSUPPORTED = -5
-ABI_VERSION = 3          # include/mmwgpu.h MMWGPU_ABI_VERSION: the argtypes below are for exactly this revision
+ABI_VERSION = 4          # include/mmwgpu.h MMWGPU_ABI_VERSION: the argtypes below are for exactly this revision
 CFAR_CA, CFAR_OS, CFAR_GO, CFAR_SO = 0, 1, 2, 3
 ANGLE_MAGNITUDE, ANGLE_NO_WINDOW, ANGLE_NO_SHIFT = 1, 2, 4
 QUEUE_COMPUTE, QUEUE_COPY = 0, 1
@@ -63,6 +63,7 @@ _SIGNATURES = {
     "mmw_virtual_array_reformat_i16": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_doppler": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_range_doppler_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_fft2_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_angle_fft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_chain3d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_range_doppler_raw": [_vp, _vp, _vp, _i, _i, _i, _i, _i],

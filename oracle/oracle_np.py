@@ -461,6 +461,29 @@ def rd_detect_sequential(cube, rng_kind, rng_params, vel_kind, vel_params):
     return _rows_to_dets(np.abs(range_doppler(cube)[0]), rows, vel_kind, vel_params)
 
 
+def range_detector(cube, kind, params):
+    """RangeDetector.process -- processors/range_detector.py:59-82: chirp-0 range profile (mean over the antennas of the
+    Hann-windowed range FFT magnitude), then the 1-D CFAR of the registry key.  -> (detection indices, thresholds, profile)."""
+    prof = range_profile(cube, 0)
+    thr, _, dets = _CFAR_1D[kind](prof, params)
+    return np.array(dets, dtype=int), thr, prof
+
+
+def micro_doppler_column(cube, rx_idx, keep):
+    """The new column of MicroDopplerProcessor.process -- processors/micro_doppler_resp.py:92-105: |fftshift_C fft2(x[rx])|
+    WITHOUT windows (complex128, as the pinned numpy 1.26.4 computes it), maximum over the kept range bins."""
+    resp = np.abs(np.fft.fftshift(np.fft.fft2(np.asarray(cube[rx_idx], dtype=np.complex128), axes=(-2, -1)), axes=1))
+    return np.max(resp[np.asarray(keep, dtype=bool), :], axis=0)
+
+
+def micro_doppler_push(history, column):
+    """micro_doppler_resp.py:107-113: the history rolls one frame to the right, the new column goes to index 0."""
+    out = np.empty_like(history)
+    out[:, 1:] = history[:, :-1]
+    out[:, 0] = column
+    return out
+
+
 def find_peaks_db(resp_db, bins, max_peaks=3, threshold_db=20):
     """RangeProcessor.find_peaks -- processors/range_resp.py:104-149 (scipy.signal.find_peaks, prominence 6 dB; peaks
     within threshold_db of the strongest; strongest first; at most max_peaks)."""
