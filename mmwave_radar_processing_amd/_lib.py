@@ -64,6 +64,7 @@ _SIGNATURES = {
     "mmw_range_doppler": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_range_doppler_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_fft2_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "mmw_fft2_c128": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_angle_fft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_chain3d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_range_doppler_raw": [_vp, _vp, _vp, _i, _i, _i, _i, _i],

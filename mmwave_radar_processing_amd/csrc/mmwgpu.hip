@@ -493,8 +493,9 @@ int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_ma
 
 // windowed == false: the plain 2-D FFT magnitude (MicroDopplerProcessor, micro_doppler_resp.py:95-101: no windows), always
 // through the two-pass path
+// magnitude == false (un-windowed only): d_mag receives the complex128 spectrum instead ([F][S][C] pairs of doubles)
 static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S,
-                                   int C, int rx_idx, bool windowed = true) {
+                                   int C, int rx_idx, bool windowed = true, bool magnitude = true) {
     MMW_REQUIRE(ctx && d_cubes && d_mag, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && rx_idx >= 0 && rx_idx < V, "bad shape / rx_idx");
     if (n_frames == 0) return MMW_OK;
@@ -534,13 +535,13 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     b.in_axis_stride = b.out_axis_stride = 1;
     b.scale = 1.0;
     b.shift = 1;
-    b.magnitude = 1;
+    b.magnitude = magnitude ? 1 : 0;
     for (long f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = (int)std::min<long>(chunk, n_frames - f0);
         a.in = (const cplx<float> *)d_cubes + (f0 * V + rx_idx) * (long)S * C;
         a.outer = nf;
         MMW_TRY((launch_fft_axis<double, float>(ctx, a, S, false)));
-        b.out = d_mag + f0 * (long)S * C;
+        b.out = d_mag + f0 * (long)S * C * (magnitude ? 1 : 2);
         b.outer = nf * S;
         MMW_TRY((launch_fft_axis<double, double>(ctx, b, C, true)));
     }
@@ -558,6 +559,12 @@ int mmw_fft2_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frame
     MMW_REQUIRE(ctx, "ctx is null");
     MMW_JOIN(ctx);
     return range_doppler_mag64_impl(ctx, d_cubes, d_mag, n_frames, V, S, C, rx_idx, false);
+}
+
+int mmw_fft2_c128(mmw_ctx *ctx, const void *d_cubes, void *d_out, int n_frames, int V, int S, int C, int rx_idx) {
+    MMW_REQUIRE(ctx, "ctx is null");
+    MMW_JOIN(ctx);
+    return range_doppler_mag64_impl(ctx, d_cubes, (double *)d_out, n_frames, V, S, C, rx_idx, false, false);
 }
 
 static bool angle_fast_path(int V, long bins, int A, bool mag);

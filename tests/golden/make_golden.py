@@ -38,6 +38,7 @@ from mmwave_radar_processing.processors.simple_synthetic_array_beamformer_proces
 from mmwave_radar_processing.processors.doppler_azimuth_resp import DopplerAzimuthProcessor      # noqa: E402
 from mmwave_radar_processing.processors.range_detector import RangeDetector                        # noqa: E402
 from mmwave_radar_processing.processors.micro_doppler_resp import MicroDopplerProcessor            # noqa: E402
+from mmwave_radar_processing.processors.strip_map_SAR_processor import StripMapSARProcessor        # noqa: E402
 from mmwave_radar_processing.detectors import CaCFAR1D, CaCFAR2D, GoCFAR1D, SoCFAR1D, OsCFAR1D, OsCFAR2D  # noqa: E402
 
 from mmwave_radar_processing_amd import synth                                          # noqa: E402
@@ -377,6 +378,14 @@ def gen_small_processors():
     d["micro_doppler_keep"] = md.range_bin_idxs_to_keep
     md.reset()
     d["micro_doppler_after_reset"] = md.process(seq[1].astype(np.complex128)).copy()
+    # strip-map SAR image of one RAW frame (the processor de-interleaves it itself) at two platform speeds (again
+    # complex128 in: numpy 1.26.4 semantics)
+    for tag, vel, kw in (("a", 20.0, {}), ("b", 35.0, dict(sensor_height_m=0.3, rx_index=5, max_SAR_distance=9.5))):
+        sar = StripMapSARProcessor(cm, az_angle_range_rad=[-0.5, 0.4] if tag == "b" else np.deg2rad(np.array([-30, 30])))
+        d[f"sar_{tag}_image"] = sar.process(synth.synth_raw_cube(7).astype(np.complex128), vel_m_per_s=vel, **kw)
+        d[f"sar_{tag}_x"] = sar.x_s
+        d[f"sar_{tag}_y"] = sar.y_s
+        d[f"sar_{tag}_angle_bins"] = sar.angle_bins_rad
     np.savez_compressed(os.path.join(HERE, "small_processors.npz"), **d)
     print("small_processors.npz:", {k: v.shape for k, v in d.items()})
 

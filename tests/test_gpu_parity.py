@@ -529,6 +529,22 @@ def test_range_detector_and_micro_doppler_vs_reference_fixtures(golden):
     assert rel_err(md.process(seq[1]), g["micro_doppler_after_reset"]) <= 1e-12
     with pytest.raises(ValueError):
         RangeDetector(cms["256"], cfar_type="no_such_cfar")
+    # strip-map SAR: complex128 un-windowed 2-D FFT on the device (mmw_fft2_c128) of the de-interleaved raw frame, ground
+    # patch and grids of two platform speeds
+    from mmwave_radar_processing_amd.processors.strip_map_SAR_processor import StripMapSARProcessor
+    from test_oracle_golden import SAR_CASES
+    for tag, vel, kw in SAR_CASES:
+        args = dict(kw)
+        az = args.pop("az_range", None)
+        if "max_sar_distance" in args:
+            args["max_SAR_distance"] = args.pop("max_sar_distance")
+        sar = StripMapSARProcessor(cms["256"], **({"az_angle_range_rad": list(az)} if az else {}))
+        img = sar.process(synth.synth_raw_cube(7), vel_m_per_s=vel, **args)
+        assert img.dtype == np.complex128 and img.shape == g[f"sar_{tag}_image"].shape
+        assert rel_err(img, g[f"sar_{tag}_image"]) <= 1e-12
+        np.testing.assert_array_equal(sar.angle_bins_rad, g[f"sar_{tag}_angle_bins"])
+        np.testing.assert_array_equal(sar.x_s, g[f"sar_{tag}_x"])
+        np.testing.assert_array_equal(sar.y_s, g[f"sar_{tag}_y"])
 
 
 def test_capon_mfma_vs_own_oracle():

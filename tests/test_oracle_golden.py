@@ -254,6 +254,7 @@ def test_sequential_and_os2d_detectors_on_range_doppler_data():
 RANGE_DET = {"yaml": ("os_cfar_1d", {"num_train": 5, "num_guard": 3, "rho": 0.5, "alpha": 2}),
              "go": ("go_cfar_1d", {"num_train": 6, "num_guard": 2, "pfa": 1e-2})}
 MICRO_DOPPLER = dict(target_ranges=[0.5, 2.0], num_frames_history=6)
+SAR_CASES = (("a", 20.0, {}), ("b", 35.0, dict(az_range=(-0.5, 0.4), sensor_height_m=0.3, rx_index=5, max_sar_distance=9.5)))
 
 
 def test_range_detector_and_micro_doppler_fixtures():
@@ -280,6 +281,14 @@ def test_range_detector_and_micro_doppler_fixtures():
             close(hist, g[f"micro_doppler_f{f}"], 1e-12)
     fresh = O.micro_doppler_push(np.zeros_like(hist), O.micro_doppler_column(seq[1], 0, keep))
     close(fresh, g["micro_doppler_after_reset"], 1e-12)
+    # strip-map SAR patch of a raw frame at two platform speeds
+    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    for tag, vel, kw in SAR_CASES:
+        img, xs, ys, ang = O.strip_map_sar(synth.synth_raw_cube(7), sc, synth.SYNTH_CFG_256x128x12, vel, **kw)
+        close(img, g[f"sar_{tag}_image"], 1e-12)
+        np.testing.assert_array_equal(ang, g[f"sar_{tag}_angle_bins"])
+        np.testing.assert_array_equal(xs, g[f"sar_{tag}_x"])
+        np.testing.assert_array_equal(ys, g[f"sar_{tag}_y"])
 
 
 def test_ground_detector_sequence_with_altimeter_state():
