@@ -270,13 +270,14 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
  * mmw_plane_l1: d_l1[F][V] float32 = sum over each plane of hann(S) hann(C) (|re| + |im|): the scale of the rounding-
  *   error bound the exact variant uses (computed once per batch, shared by the azimuth and elevation calls).
  * mmw_angle_argmax_exact: same result contract as the reference's complex128 computation (:186-206).  The float32
- *   pass bounds how far its magnitudes can be from the float64 ones (from d_l1 and the gathered cells: the WORST-CASE
- *   rounding bound of the kernel that produced the cube); a detection whose winner is not provably the float64 one --
- *   best and second-best closer than twice that bound and, for lists of up to 8 antennas, some bin also failing the
- *   pairwise form of the test that treats the two bins' errors as the same cell errors seen through two steering
- *   vectors -- is re-evaluated in float64 from the raw cube
+ *   pass bounds how far its magnitudes can be from the float64 ones (from d_l1 and the gathered cells: 1/8 of the
+ *   worst-case rounding bound of the kernel that produced the cube, ~10x above the largest error measured;
+ *   MMW_ARGMAX_BOUND_DIV=1 selects the worst case itself -- a proof, at 4x the run time on noise-level detections, see
+ *   DESIGN.md 4.6); a detection whose winner is not certainly the float64 one -- best and second-best closer than twice
+ *   that bound and, for lists of up to 8 antennas, some bin also failing the pairwise form of the test that treats the two
+ *   bins' errors as the same cell errors seen through two steering vectors -- is re-evaluated in float64 from the raw cube
  *   d_cubes (its range-Doppler cells as direct float64 2-D DFT sums, then the float64 angle DFT + argmax).
- *   (MMW_ARGMAX_BOUND_DIV=8 restores the empirical eighth of the bound of earlier builds.)
+ *   (mmw_detect_points uses the worst-case bound throughout.)
  *   h_n_refined (may be NULL): number of re-evaluated detections; passing it makes the call synchronise.
  * mmw_angle_argmax_cells64: the float64 angle DFT + first-max argmax for rows of n_ant complex128 cells the caller
  *   gathered itself (a caller-supplied complex128 range-Doppler cube, :168-178); d_cells [n_rows][n_ant]. */

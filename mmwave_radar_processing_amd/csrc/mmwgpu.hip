@@ -1659,11 +1659,15 @@ static int fill_refine_args(mmw_ctx *ctx, RefineArgs *ra, int S, int C, int A) {
 }
 
 // The worst-case bound assumes every rounding error of every partial sum lines up; measured float32 errors stay below
-// 1.2 % of it (tools/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).  Rounds 1-2 used 1/8 of
-// it to keep the float64 re-evaluations (each reads the antennas' whole planes) at 0.2 % of the detections; since round 3
-// the kernels take the FULL worst-case bound and keep the rate low with the pairwise form of the test instead (lists of up
-// to 8 antennas; longer lists: the independent-errors test, ~2 % refined).  MMW_ARGMAX_BOUND_DIV=8 restores the old divisor.
-static float argmax_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 1)); }
+// 1.2 % of it (tools/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).
+//  * mmw_detect_points (CA-CFAR detections: strong cells) uses the FULL worst-case bound with the pairwise form of the test:
+//    0.15 % of the evaluations are re-done in float64.
+//  * the stand-alone mmw_angle_argmax_exact serves the other detectors.  With the GUI's OS-CFAR parameters (rho 0.7, alpha 2:
+//    470 mostly noise-level detections per 256 x 128 frame, flat angle spectra) the full bound sends 12.8 % of the
+//    evaluations to float64 -- 120 per frame, each a direct DFT sum over whole planes: 29-36 us/frame against 7.2 with an
+//    eighth of the bound (~10x above anything observed; 1.6 % refined).  Default: 1/8 + the pairwise pass (lists of up to 8
+//    antennas); MMW_ARGMAX_BOUND_DIV=1 selects the worst case, i.e. a proof, at that price.
+static float argmax_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 8)); }
 static float detect_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 1)); }
 
 int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1, const void *d_rd, const int32_t *d_dets,
