@@ -310,6 +310,10 @@ int mmw_capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d_ou
 
 /* ---------------------------------------------------------------- element-wise helpers */
 int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n);
+/* d_out[i] = (double) d_in[i], n floats (a complex64 array of m elements: n = 2 m): lets a caller that owes the reference's
+ *   complex128 / float64 dtypes (range_angle_resp_dbs_enhanced.py:196, range_doppler_resp.py:103) widen on the device and
+ *   download the result directly instead of converting on a host core. */
+int mmw_widen_f32_f64(mmw_ctx *ctx, const float *d_in, double *d_out, size_t n);
 
 /* ---------------------------------------------------------------- diagnostics
  * In-situ HBM ceiling on the same device: mode 0 = 16-B/lane copy, 1 = write only, 2 = read only,

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "mmw_bartlett": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _d],
     "mmw_capon": [_vp, _vp, C.POINTER(_d), _vp, _i, _i, _i, _i, _i, _d],
     "mmw_abs_c64": [_vp, _vp, _vp, _sz],
+    "mmw_widen_f32_f64": [_vp, _vp, _vp, _sz],
     "mmw_diag_membw": [_vp, _vp, _vp, _sz, _i, _i],
     "mmw_diag_mfma_peak": [_vp, _i, C.POINTER(_d)],
     "mmw_diag_rd_plan": [_i, _i, _i, _ip],
@@ -187,6 +188,20 @@ class DeviceBuffer:
         if byte_offset + out.nbytes > self.nbytes:
             raise ValueError("download exceeds device buffer")
         check(self.ctx.lib.mmw_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + byte_offset, out.nbytes))
+        return out
+
+    def download_widened(self, shape, dtype, byte_offset: int = 0, staging=None) -> np.ndarray:
+        """``download(shape, dtype).astype(wider)`` with the widening done on the device (float32 -> float64, complex64 ->
+        complex128) into ``staging`` (a DeviceBuffer of twice the bytes): for the multi-megabyte arrays the reference's
+        dtypes oblige, one host core converting costs more than twice the bytes over PCIe."""
+        narrow = np.dtype(dtype)
+        wide = np.dtype(np.complex128 if narrow == np.complex64 else np.float64)
+        out = np.empty(shape, dtype=wide)
+        n_f32 = out.size * (2 if narrow == np.complex64 else 1)
+        if byte_offset + n_f32 * 4 > self.nbytes or staging is None or staging.nbytes < out.nbytes:
+            raise ValueError("download_widened: source or staging buffer too small")
+        check(self.ctx.lib.mmw_widen_f32_f64(self.ctx.handle, self.ptr + byte_offset, staging.ptr, n_f32))
+        check(self.ctx.lib.mmw_memcpy_d2h(self.ctx.handle, out.ctypes.data, staging.ptr, out.nbytes))
         return out
 
     def zero(self):

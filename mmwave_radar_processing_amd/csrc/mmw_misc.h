@@ -98,6 +98,12 @@ __global__ __launch_bounds__(256) void k_abs_c64(const float2 *in, float *out, s
     }
 }
 
+// float32 -> float64, element by element (complex arrays as pairs): the reference hands back complex128 / float64 arrays,
+// and widening 16 MB on one host core (numpy astype, ~5 ms) costs more than moving twice the bytes over PCIe
+__global__ __launch_bounds__(256) void k_widen_f32_f64(const float *__restrict__ in, double *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (double)in[i];
+}
+
 // out[f][s] = mean_v |spec[f][v][s]|   (processors/range_resp.py:55-57; np.mean over axis 0 adds the
 // antenna rows in order, which the loop reproduces)
 template <typename T>

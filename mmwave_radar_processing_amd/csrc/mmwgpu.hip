@@ -2018,6 +2018,15 @@ int mmw_abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
     return abs_c64(ctx, d_in, d_out, n);
 }
 
+int mmw_widen_f32_f64(mmw_ctx *ctx, const float *d_in, double *d_out, size_t n) {
+    MMW_REQUIRE(ctx && (n == 0 || (d_in && d_out)), "null argument");
+    MMW_JOIN(ctx);
+    if (n == 0) return MMW_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 16);
+    hipLaunchKernelGGL(k_widen_f32_f64, dim3(grid), dim3(256), 0, ctx->stream, d_in, d_out, n);
+    return check_launch("widen_f32_f64");
+}
+
 int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]) {
     MMW_REQUIRE(plan && S > 0 && C > 0, "bad argument");
     for (int i = 0; i < 8; ++i) plan[i] = 0;

@@ -61,7 +61,8 @@ class RangeAngleProcessorDBSEnhanced(RangeAngleProcessor):
     def compute_3d_windowed_fft(self, adc_cube: np.ndarray) -> np.ndarray:
         """complex128 ``(num_angle_bins, samples, chirps)`` (reference :137-198)."""
         d_out, shape = self._chain3d_device(adc_cube, magnitude=False)
-        return d_out.download(shape, np.complex64).astype(np.complex128)
+        _, bufs = self._device()
+        return d_out.download_widened(shape, np.complex64, staging=bufs.get("widen", int(np.prod(shape)) * 16))
 
     def get_dop_vel(self, angle: float, ego_vel: np.ndarray) -> float:
         r = np.array([np.cos(angle), np.sin(angle), 0])
