@@ -527,6 +527,11 @@ def test_range_detector_and_micro_doppler_vs_reference_fixtures(golden):
             assert out.shape == g[f"micro_doppler_f{f}"].shape and rel_err(out, g[f"micro_doppler_f{f}"]) <= 1e-12
     md.reset()
     assert rel_err(md.process(seq[1]), g["micro_doppler_after_reset"]) <= 1e-12
+    # a non-power-of-two plane (63 x 70: direct-DFT kernels behind mmw_fft2_mag64) against the oracle pinned above
+    md2 = MicroDopplerProcessor(cms["np2"], target_ranges=[0.3, 1.5], num_frames_history=3)
+    cube2 = synth.synth_cube(202, (12, 63, 70))
+    col = O.micro_doppler_column(cube2, 3, md2.range_bin_idxs_to_keep)
+    assert rel_err(md2.process(cube2, rx_idx=3)[:, 0], col) <= 1e-12
     with pytest.raises(ValueError):
         RangeDetector(cms["256"], cfar_type="no_such_cfar")
     # strip-map SAR: complex128 un-windowed 2-D FFT on the device (mmw_fft2_c128) of the de-interleaved raw frame, ground
