@@ -1444,11 +1444,13 @@ def test_device_synchronised_chain_on_shipped_cfg_shapes(monkeypatch, S, C, F, V
     d_out.free()
 
 
-@pytest.mark.parametrize("S,C", [(512, 64), (128, 256), (1024, 32)])
+@pytest.mark.parametrize("S,C", [(512, 64), (128, 256), (1024, 32), (256, 256), (512, 128)])
 def test_split_range_doppler_kernel_for_planes_beyond_the_lds(S, C, monkeypatch):
     """k_rd_split2_ct: planes of 2 x 16384 cells in ONE pass over HBM (even chirps through the LDS, odd chirps and then the
     even half's spectrum carried in registers, radix-2 combine in the store pass) against the oracle and the two-kernel
-    path, and through the chain (Hann(V) end planes skipped there)."""
+    path, and through the chain (Hann(V) end planes skipped there).  k_rd_split4_ct: planes of 4 x 16384 cells (256 x 256,
+    512 x 128) -- four quarters of sample rows through the LDS, three of their spectra carried in registers, radix-4 combine
+    in the store pass."""
     ctx = _lib.default_context()
     L, h = ctx.lib, ctx.handle
     F, V, A = 3, 4, 64
