@@ -327,7 +327,8 @@ int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, i
  * kinds 4 / 5: the same with ONE wave per SIMD -- how much vector work hides under float32 MFMAs (it does not). */
 int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops);
 /* Which range-Doppler kernel mmw_range_doppler picks for an S x C plane, without touching a device (host logic
- * only): plan[0] = 0 fused 256x128 | 1 LDS-resident power of two | 2 mixed radix | 3 generic two-kernel path;
+ * only): plan[0] = 0 fused 256x128 | 1 LDS-resident power of two | 2 mixed radix | 3 generic two-kernel path |
+ * 4 single pass with half / three quarters of the plane carried in registers (planes of 32768 / 65536 cells);
  * for the mixed-radix kernel plan[1..7] = register class, has a run-time-radix level, S1, S2, C1, C2 (S = S1 S2,
  * C = C1 C2), dynamic LDS bytes.  float64 != 0 asks for the float64 CFAR-plane variant. */
 int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]);

@@ -2039,7 +2039,7 @@ int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]) {
     else if (rd_lds_supported(S, C))
         plan[0] = 1;
     else
-        plan[0] = rd_mixed_plan(S, C, sizeof(cplx<float>), &pl) ? 2 : 3;
+        plan[0] = rd_mixed_plan(S, C, sizeof(cplx<float>), &pl) ? 2 : (rd_split_ct_supported(S, C) ? 4 : 3);
     if (plan[0] == 2) {
         plan[1] = pl.cls;
         plan[2] = pl.big;

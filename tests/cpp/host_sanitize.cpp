@@ -30,7 +30,7 @@ int main() {
         for (int C : sizes)
             for (int f64 = 0; f64 < 2; ++f64) {
                 CHECK(mmw_diag_rd_plan(S, C, f64, plan) == MMW_OK);
-                CHECK(plan[0] >= 0 && plan[0] <= 3);
+                CHECK(plan[0] >= 0 && plan[0] <= 4);
                 if (plan[0] == 2) CHECK(plan[3] * plan[4] == S && plan[5] * plan[6] == C && plan[7] > 0);
                 ++planned;
             }

@@ -62,7 +62,8 @@ def test_rd_kernel_plan_covers_every_shipped_cfg_shape():
             assert all(r <= (16 if cls == 0 else 32) or big for r in (s1, c1))
             assert (S * (C | 1) + S + C) * 8 <= lds <= 160 * 1024
     assert kinds[(256, 128)] == 0 and kinds[(63, 70)] == 2
-    assert lib.mmw_diag_rd_plan(512, 128, 0, plan) == 0 and plan[0] == 3        # beyond the LDS
+    assert lib.mmw_diag_rd_plan(512, 128, 0, plan) == 0 and plan[0] == 4        # beyond the LDS: split kernel, one pass
+    assert lib.mmw_diag_rd_plan(1024, 256, 0, plan) == 0 and plan[0] == 3       # ... two-kernel path
     assert lib.mmw_diag_rd_plan(63, 100, 1, plan) == 0 and plan[0] == 2         # float64 CFAR plane
     assert lib.mmw_diag_rd_plan(256, 128, 1, plan) == 0 and plan[0] == 3
     assert lib.mmw_diag_rd_plan(0, 4, 0, plan) == _lib.MMW_ERR_INVALID
