@@ -143,3 +143,36 @@ def test_sequential_detector_all_1d_kinds_over_many_frames(shape):
                 cases += 1
     print(f"sequential sweep {shape}: {cases} detector pairings x {n_frames} frames, {total} detections, {bad} frames with any difference")
     assert bad == 0 and total > 0
+
+
+def _oracle_argmax(args):
+    cube, dets = args
+    from oracle import oracle_np as O
+    raw = O.range_doppler(cube)
+    r, v = dets[:, 0].astype(int), dets[:, 1].astype(int)
+    return O.angle_argmax(raw, r, v, AZ, 64, True)[0], O.angle_argmax(raw, r, v, EL, 64, False)[0]
+
+
+def test_standalone_exact_argmax_on_os_detections():
+    """The stand-alone exact argmax (mmw_angle_argmax_exact through FramePipeline.point_clouds: the path of every detector
+    but CA-CFAR 2-D) on OS-CFAR detections with the GUI's parameters -- ~470 mostly noise-level cells per 256 x 128 frame, flat
+    angle spectra: the hard case for the certainty test -- against the float64 oracle's argmax on the same detections.
+    MMW_ARGMAX_BOUND_DIV=1 in the environment runs the worst-case bound instead of the default eighth."""
+    n_frames = max(8, int(os.environ.get("MMW_SWEEP_FRAMES", "96")) // 4)
+    procs = int(os.environ.get("MMW_SWEEP_PROCS", "4"))
+    cm = ConfigManager()
+    cm.load_cfg_text(synth.SYNTH_CFG_256x128x12)
+    pipe = FramePipeline(cm, max_frames=n_frames, shape=(12, 256, 128), cfar=OsCFAR2D((5, 5), (3, 2), rho=0.7, alpha=2.0),
+                         az_antenna_idxs=AZ, el_antenna_idxs=EL, det_capacity=2048)
+    pipe.synth(n_frames, seed0=880_000)
+    assert not pipe._fused_supported(True)
+    pipe.point_clouds()
+    cubes = pipe.cubes(0, n_frames)
+    with get_context("spawn").Pool(procs) as pool:
+        ref = pool.map(_oracle_argmax, [(cubes[f], pipe.dets[f]) for f in range(n_frames)], chunksize=2)
+    bad_az = sum(int(np.count_nonzero(pipe.az_idx[f] != ref[f][0])) for f in range(n_frames))
+    bad_el = sum(int(np.count_nonzero(pipe.el_idx[f] != ref[f][1])) for f in range(n_frames))
+    n = sum(len(d) for d in pipe.dets)
+    print(f"stand-alone exact argmax (bound divisor {os.environ.get('MMW_ARGMAX_BOUND_DIV', '8')} + pairwise pass) on OS-CFAR detections: "
+          f"{n_frames} frames, {n} detections, {bad_az} azimuth / {bad_el} elevation index differences, {pipe.n_refined} evaluations refined")
+    assert n > 100 * n_frames and bad_az == 0 and bad_el == 0
