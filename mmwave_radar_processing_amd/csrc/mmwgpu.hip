@@ -1659,7 +1659,7 @@ static int fill_refine_args(mmw_ctx *ctx, RefineArgs *ra, int S, int C, int A) {
 }
 
 // The worst-case bound assumes every rounding error of every partial sum lines up; measured float32 errors stay below
-// 1.2 % of it (tools/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).
+// 1.2 % of it (tests/argmax_margin.py: 68 000 evaluations on the 256 x 128 and 63 x 100 planes).
 //  * mmw_detect_points (CA-CFAR detections: strong cells) uses the FULL worst-case bound with the pairwise form of the test:
 //    0.15 % of the evaluations are re-done in float64.
 //  * the stand-alone mmw_angle_argmax_exact serves the other detectors.  With the GUI's OS-CFAR parameters (rho 0.7, alpha 2:
