@@ -1158,7 +1158,7 @@ def test_mixed_radix_rd_kernel_all_shipped_shapes(S, C, monkeypatch):
 
 
 @pytest.mark.parametrize("nrx,ntx,S,C", [(4, 3, 256, 128), (4, 3, 64, 32), (4, 3, 63, 70), (4, 2, 100, 30), (2, 2, 512, 64),
-                                         (4, 3, 63, 127)])
+                                         (4, 3, 63, 127), (2, 2, 256, 256)])
 def test_raw_cube_entry_points_fold_the_virtual_array_reformat(nrx, ntx, S, C):
     """mmw_range_doppler_raw / mmw_chain3d_raw == mmw_virtual_array_reformat followed by the plain calls, on the
     fused 256x128 kernel, an LDS-resident power-of-two plane, mixed-radix planes and the two-kernel fallback; and
