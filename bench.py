@@ -282,6 +282,8 @@ def host_stream_record(ctx, chunk_frames: int = 128, n_chunks: int = 8):
         frames = n_chunks * chunk_frames
         out[name] = {"frames_per_s": frames / dt, "host_bytes_per_frame": host.nbytes // chunk_frames,
                      "h2d_GBs": frames * (host.nbytes / chunk_frames) / dt / 1e9, "detections": dets}
+        for p in pin:
+            ctx.host_free(p)
     pipe.bufs.free()
     return out
 

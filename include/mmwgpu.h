@@ -128,12 +128,6 @@ int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_ma
                       int n_frames, int V, int S, int C);
 int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag,
                             int n_frames, int V, int S, int C, int rx_idx);
-/* mmw_fft2_mag64: d_mag[F][S][C] float64 = | fftshift_C fft2( x[rx_idx] ) | WITHOUT windows -- the spectrum
- *   MicroDopplerProcessor.process takes its range-gated maximum of (processors/micro_doppler_resp.py:95-105). */
-int mmw_fft2_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S, int C, int rx_idx);
-/* mmw_fft2_c128: d_out[F][S][C] complex128 = fftshift_C fft2( x[rx_idx] ), no windows -- the image
- *   StripMapSARProcessor.process cuts its ground patch out of (processors/strip_map_SAR_processor.py:181-193). */
-int mmw_fft2_c128(mmw_ctx *ctx, const void *d_cubes, void *d_out, int n_frames, int V, int S, int C, int rx_idx);
 /* flags of mmw_angle_fft / mmw_chain3d (0 = complex64 output, Hann(V) window, fftshift over angle) */
 #define MMW_ANGLE_MAGNITUDE 1   /* float32 |.| output                                                    */
 #define MMW_ANGLE_NO_WINDOW 2   /* no antenna window (DopplerAzimuthProcessor on "ods" geometry)         */

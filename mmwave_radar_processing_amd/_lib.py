@@ -63,8 +63,6 @@ _SIGNATURES = {
     "mmw_virtual_array_reformat_i16": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_range_doppler": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_range_doppler_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
-    "mmw_fft2_mag64": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
-    "mmw_fft2_c128": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
     "mmw_angle_fft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_chain3d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "mmw_range_doppler_raw": [_vp, _vp, _vp, _i, _i, _i, _i, _i],
@@ -250,9 +248,16 @@ class Context:
         check(self.lib.mmw_host_alloc(self.handle, C.byref(p), nbytes))
         buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-        self._pinned = getattr(self, "_pinned", [])
-        self._pinned.append(p.value)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.__array_interface__["data"][0]] = p.value
         return arr
+
+    def host_free(self, arr: np.ndarray) -> None:
+        """Release a ``host_array`` block now (the caller drops every view of it); blocks never freed go with the context."""
+        p = getattr(self, "_pinned", {}).pop(arr.__array_interface__["data"][0], None)
+        if p is None:
+            raise ValueError("not a block of this context's host_array()")
+        check(self.lib.mmw_host_free(self.handle, C.c_void_p(p)))
 
     def event(self):
         e = C.c_void_p()

@@ -143,8 +143,11 @@ class FramePipeline:
         frame_bytes = self.cube_bytes // 2 if i16 else self.cube_bytes
         dev = [self.bufs.get("stream_in0", self.max_frames * frame_bytes), self.bufs.get("stream_in1", self.max_frames * frame_bytes)]
         ev_up, ev_free = [ctx.event(), ctx.event()], [ctx.event(), ctx.event()]
-        stage = [None, None]
+        # pinned staging blocks live with the pipeline (grow-only, like its device buffers): a per-file loop calling stream()
+        # again and again re-uses them instead of pinning max_frames * frame_bytes twice per call
+        stage = self.__dict__.setdefault("_stage", [None, None])
         d_cubes_own = self.d_in
+        saved_raw = (getattr(self, "d_raw", None), getattr(self, "d_raw_i16", None), getattr(self, "_raw_tx", 0))
         it = iter(chunks)
 
         def upload(k, chunk):
@@ -162,7 +165,9 @@ class FramePipeline:
             if not pinned:
                 if k >= 2:
                     ctx.event_sync(ev_up[b])                 # copy k - 2 has left staging block b
-                if stage[b] is None:
+                if stage[b] is None or stage[b].nbytes < self.max_frames * frame_bytes:
+                    if stage[b] is not None:
+                        ctx.host_free(stage[b])
                     stage[b] = ctx.host_array((self.max_frames * frame_bytes,), np.uint8)
                 src = stage[b][:a.nbytes]
                 src[:] = a.reshape(-1).view(np.uint8)
@@ -189,14 +194,18 @@ class FramePipeline:
                     self.d_in = d_cubes_own
                     _lib.check(ctx.lib.mmw_virtual_array_reformat_i16(ctx.handle, dev[b].ptr, self.d_in.ptr, n, self.V // num_tx,
                                                                       num_tx, self.S, self.C))
+                    # work() may call chain3d_raw(): it reads THIS chunk's raw samples
+                    self.d_raw, self.d_raw_i16, self._raw_tx = None, dev[b], num_tx
                 else:
                     self.d_in = dev[b]
+                    self.d_raw = self.d_raw_i16 = None     # no raw cube behind a streamed virtual-array chunk
                 out = work(self)
                 ctx.record(ev_free[b], Q.QUEUE_COMPUTE)
                 yield out
                 k += 1
         finally:
             self.d_in = d_cubes_own
+            self.d_raw, self.d_raw_i16, self._raw_tx = saved_raw
             ctx.sync()
             for e in ev_up + ev_free:
                 _lib.check(ctx.lib.mmw_event_destroy(ctx.handle, e))
@@ -206,6 +215,8 @@ class FramePipeline:
         F, A, S, C = self.n_frames, self.A, self.S, self.C
         self.d_cube3d = self.bufs.get("cube3d", max(F, 1) * A * S * C * (4 if magnitude else 8))
         self._cube3d_mag = magnitude
+        if getattr(self, "d_raw_i16", None) is None and getattr(self, "d_raw", None) is None:
+            raise ValueError("chain3d_raw() needs the raw cubes of load_raw() / load_raw_i16() (or an int16 stream() chunk)")
         if getattr(self, "d_raw_i16", None) is not None:        # int16 cells: converted inside the first kernel's loads
             _lib.check(self.ctx.lib.mmw_chain3d_raw_i16(self.ctx.handle, self.d_raw_i16.ptr, None, self.d_cube3d.ptr, F,
                                                         self.V // self._raw_tx, self._raw_tx, S, C, A, int(magnitude)))

@@ -623,10 +623,12 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
         if (st) atomicOr(a.status + f * DET_LINE, st);
     }
     // The last tile of the frame to get here finishes the frame.  Everything tiles tell each other travels in device-scope
-    // atomics (mask words, status, ticket) and is read back with coherent loads; a thread's atomics are complete before it
-    // passes the barrier (the barrier waits for vmcnt(0)), and thread 0 draws the ticket after the barrier.  No
-    // __threadfence(): on this multi-XCD part a device-scope release writes the XCD's whole L2 back -- with one per tile
-    // the kernel took 4.3 ms instead of 0.3.
+    // atomics (mask words, status, ticket) and is read back with coherent loads.  The atomics above return nothing, and
+    // s_barrier does NOT wait for them (gfx950 has back-off barriers: no implicit s_waitcnt in front of it): every wave
+    // drains its own vector-memory counter before the barrier, so all of the tile's atomics have been performed at the L2
+    // before thread 0 draws the ticket.  No __threadfence(): on this multi-XCD part a device-scope release writes the
+    // XCD's whole L2 back -- with one per tile the kernel took 4.3 ms instead of 0.3.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) ws[46] = atomicAdd(a.done + f * DET_LINE, 1);
     __syncthreads();

@@ -491,11 +491,8 @@ int mmw_range_doppler(mmw_ctx *ctx, const void *d_cubes, void *d_out, void *d_ma
     return range_doppler_impl(ctx, d_cubes, d_out, d_mag_f32, n_frames, V, S, C);
 }
 
-// windowed == false: the plain 2-D FFT magnitude (MicroDopplerProcessor, micro_doppler_resp.py:95-101: no windows), always
-// through the two-pass path
-// magnitude == false (un-windowed only): d_mag receives the complex128 spectrum instead ([F][S][C] pairs of doubles)
 static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S,
-                                   int C, int rx_idx, bool windowed = true, bool magnitude = true) {
+                                   int C, int rx_idx) {
     MMW_REQUIRE(ctx && d_cubes && d_mag, "null argument");
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && rx_idx >= 0 && rx_idx < V, "bad shape / rx_idx");
     if (n_frames == 0) return MMW_OK;
@@ -503,7 +500,7 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     RdMixedPlan mp;
     // LDS-resident single-pass kernel for every plane that fits in float64 except small power-of-two ones, where the
     // two-kernel register-FFT path is as fast (64 x 64, 512 x 8: equal; 128 x 64, 256 x 32: single pass +18 %)
-    if (windowed && (!is_pow2(S) || !is_pow2(C) || (long)S * C >= 8192))
+    if (!is_pow2(S) || !is_pow2(C) || (long)S * C >= 8192)
         if (rd_mixed_plan(S, C, sizeof(cplx<double>), &mp) && !env_int("MMW_NO_MIXED_RD", 0))
             return launch_rd_mixed<double, true>(ctx, (const cplx<float> *)d_cubes + (long)rx_idx * S * C,
                                                  (long)V * S * C, d_mag, n_frames, S, C);
@@ -522,10 +519,8 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     a.out_outer_stride = (long)S * C;
     a.in_axis_stride = a.out_axis_stride = C;
     a.in_inner_stride = a.out_inner_stride = 1;
-    if (windowed) {
-        MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &a.win_axis));
-        MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &a.win_inner));
-    }
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &a.win_axis));
+    MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &a.win_inner));
     a.scale = 1.0;
     FftArgs b{};
     b.in = ctx->scratch;
@@ -535,13 +530,13 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     b.in_axis_stride = b.out_axis_stride = 1;
     b.scale = 1.0;
     b.shift = 1;
-    b.magnitude = magnitude ? 1 : 0;
+    b.magnitude = 1;
     for (long f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = (int)std::min<long>(chunk, n_frames - f0);
         a.in = (const cplx<float> *)d_cubes + (f0 * V + rx_idx) * (long)S * C;
         a.outer = nf;
         MMW_TRY((launch_fft_axis<double, float>(ctx, a, S, false)));
-        b.out = d_mag + f0 * (long)S * C * (magnitude ? 1 : 2);
+        b.out = d_mag + f0 * (long)S * C;
         b.outer = nf * S;
         MMW_TRY((launch_fft_axis<double, double>(ctx, b, C, true)));
     }
@@ -553,18 +548,6 @@ int mmw_range_doppler_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, in
     MMW_REQUIRE(ctx, "ctx is null");
     MMW_JOIN(ctx);
     return range_doppler_mag64_impl(ctx, d_cubes, d_mag, n_frames, V, S, C, rx_idx);
-}
-
-int mmw_fft2_mag64(mmw_ctx *ctx, const void *d_cubes, double *d_mag, int n_frames, int V, int S, int C, int rx_idx) {
-    MMW_REQUIRE(ctx, "ctx is null");
-    MMW_JOIN(ctx);
-    return range_doppler_mag64_impl(ctx, d_cubes, d_mag, n_frames, V, S, C, rx_idx, false);
-}
-
-int mmw_fft2_c128(mmw_ctx *ctx, const void *d_cubes, void *d_out, int n_frames, int V, int S, int C, int rx_idx) {
-    MMW_REQUIRE(ctx, "ctx is null");
-    MMW_JOIN(ctx);
-    return range_doppler_mag64_impl(ctx, d_cubes, (double *)d_out, n_frames, V, S, C, rx_idx, false, false);
 }
 
 static bool angle_fast_path(int V, long bins, int A, bool mag);

@@ -12,3 +12,11 @@ _REGISTRY = {
 
 def get_detector_registry():
     return dict(_REGISTRY)
+
+
+def make_detector(cfar_type: str, cfar_params=None):
+    """Instance for a registry key; an unknown key is the ValueError every caller of the reference's registry raises."""
+    cls = _REGISTRY.get(cfar_type)
+    if cls is None:
+        raise ValueError(f"Unknown CFAR type: {cfar_type}. Available: {list(_REGISTRY)}")
+    return cls(**(cfar_params or {}))

@@ -7,10 +7,6 @@ from .range_angle_resp import RangeAngleProcessor
 from .range_angle_resp_dbs_enhanced import RangeAngleProcessorDBSEnhanced
 from .point_cloud_generator import PointCloudGenerator
 from .doppler_azimuth_resp import DopplerAzimuthProcessor
-from .range_detector import RangeDetector
-from .micro_doppler_resp import MicroDopplerProcessor
-from .strip_map_SAR_processor import StripMapSARProcessor
 
 __all__ = ["_Processor", "VirtualArrayReformatter", "RangeProcessor", "Altimeter", "RangeDopplerProcessor",
-           "RangeAngleProcessor", "RangeAngleProcessorDBSEnhanced", "PointCloudGenerator", "DopplerAzimuthProcessor",
-           "RangeDetector", "MicroDopplerProcessor", "StripMapSARProcessor"]
+           "RangeAngleProcessor", "RangeAngleProcessorDBSEnhanced", "PointCloudGenerator", "DopplerAzimuthProcessor"]

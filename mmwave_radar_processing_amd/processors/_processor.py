@@ -25,11 +25,9 @@ def as_cube_c64(adc_cube: np.ndarray) -> np.ndarray:
 class _Processor:
     def __init__(self, config_manager, **kwargs) -> None:
         self.config_manager = config_manager
-        self.history_estimated = []
-        self.history_gt = []
         self.logger = get_logger(__name__)
-        self._ctx = None
-        self._bufs = None
+        self._ctx = self._bufs = None
+        _Processor.reset(self)              # the two history lists
         self.configure()
 
     # device plumbing ---------------------------------------------------
@@ -52,14 +50,12 @@ class _Processor:
         pass
 
     def reset(self):
-        self.history_estimated = []
-        self.history_gt = []
+        self.history_estimated, self.history_gt = [], []
 
     def update_history(self, estimated: np.ndarray = np.empty(0), ground_truth: np.ndarray = np.empty(0)) -> None:
-        if estimated.size > 0:
-            self.history_estimated.append(estimated.copy())
-        if ground_truth.size > 0:
-            self.history_gt.append(ground_truth.copy())
+        for log, sample in ((self.history_estimated, estimated), (self.history_gt, ground_truth)):
+            if np.size(sample):             # empty = nothing to record this frame
+                log.append(np.array(sample))
 
     def process(self, adc_cube: np.ndarray, **kwargs) -> np.ndarray:
         raise NotImplementedError

@@ -1,11 +1,22 @@
-"""Altitude (range to ground) from the chirp-0 range profile
-(reference: mmwave_radar_processing/processors/altimeter.py:6-140).
+"""Range to ground from the chirp-0 range profile, tracked from frame to frame.
 
-STATEFUL: the last measured altitude gates the next frame's ground peak (:42-65), so an instance belongs to ONE frame
-sequence and stays out of the batch API.  The transforms run on the device (float64 range profile,
-chirp-z zoom transform); the peak picking is the reference's scipy call on the host.
+Behaviour pinned on sequences run by the reference (mmwave_radar_processing/processors/altimeter.py, fixtures
+``tests/golden/detectors_rd.npz: ground_*``; a restatement of the reference's control flow exists only in the test
+infrastructure).  Here the tracker is a small state machine:
+
+* ``GroundLock`` holds the gate (lowest admissible range, how far a new measurement may lie from the last one) and the
+  two altitudes the callers read;
+* a frame is a list of *look stages* -- coarse profile, then optionally a zoom around the coarse hit -- each turning the
+  cube into candidate ranges on the device (float64 range profile / chirp-z zoom) + one scipy peak pick on the host;
+* every stage's candidates pass through ``GroundLock.admit``; the first stage with no admissible candidate ends the frame
+  with the previous altitude, the last stage's hit is accepted.
+
+STATEFUL: one instance per frame sequence, not part of the batch API.
 """
 from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
 
 import numpy as np
 
@@ -13,65 +24,78 @@ from .. import _lib
 from .range_resp import RangeProcessor
 
 
+@dataclass
+class GroundLock:
+    floor_m: float                      # nothing nearer than this is ground
+    reach_m: float                      # a new measurement lies within this of the last one
+    bias_m: float = 0.0                 # added to what is reported, never to the gate
+    measured_m: float = field(init=False)
+    reported_m: float = field(init=False)
+
+    def __post_init__(self):
+        self.measured_m = self.reported_m = self.floor_m
+
+    def admit(self, candidates_m: np.ndarray) -> Optional[float]:
+        """The nearest candidate inside the gate, or None."""
+        c = np.asarray(candidates_m, dtype=float)
+        inside = c[(c >= self.floor_m) & (np.abs(c - self.measured_m) <= self.reach_m)]
+        return float(inside.min()) if inside.size else None
+
+    def accept(self, range_m: float) -> None:
+        self.measured_m = range_m
+        self.reported_m = range_m + self.bias_m
+
+    def release(self) -> None:
+        """Forget the last measurement (the gate re-centres on the floor); the reported altitude stands until the next
+        accepted frame, which is what the reference's reset leaves behind."""
+        self.measured_m = self.floor_m
+
+
 class Altimeter(RangeProcessor):
     def __init__(self, config_manager, min_altitude_m: float, zoom_search_region_m: float, altitude_search_limit_m: float,
                  range_bias: float = 0.0, **kwargs) -> None:
         super().__init__(config_manager)
-        self.min_altitude_m = float(min_altitude_m)
-        self.zoom_search_region_m = float(zoom_search_region_m)
-        self.altitude_search_limit_m = float(altitude_search_limit_m)
-        self.range_bias = float(range_bias)
+        self.lock = GroundLock(float(min_altitude_m), float(altitude_search_limit_m), float(range_bias))
+        self.zoom_half_width_m = float(zoom_search_region_m)
         self.coarse_fft_data = None
-        self.current_altitude_measured_m = self.min_altitude_m      # measured by the radar
-        self.current_altitude_corrected_m = self.min_altitude_m     # corrected for the bias
+
+    # the names callers of the reference class read ---------------------------------------------------------------
+    current_altitude_measured_m = property(lambda self: self.lock.measured_m)
+    current_altitude_corrected_m = property(lambda self: self.lock.reported_m)
+    min_altitude_m = property(lambda self: self.lock.floor_m)
+    altitude_search_limit_m = property(lambda self: self.lock.reach_m)
+    range_bias = property(lambda self: self.lock.bias_m)
+    zoom_search_region_m = property(lambda self: self.zoom_half_width_m)
+
+    def find_ground_peak(self, detected_peaks_m: np.ndarray) -> float:
+        hit = self.lock.admit(detected_peaks_m)
+        return -1.0 if hit is None else hit
 
     def reset(self):
-        self.current_altitude_measured_m = self.min_altitude_m      # (the corrected value is kept, as in the reference :37-40)
+        self.lock.release()
         return super().reset()
 
-    def find_ground_peak(self, detected_peaks_m: np.ndarray):
-        """Nearest valid peak: at or above the minimum altitude and within the search limit of the current one; -1.0 when
-        there is none (reference :42-65)."""
-        if detected_peaks_m.size > 0:
-            valid = detected_peaks_m[(detected_peaks_m >= self.min_altitude_m) &
-                                     (np.abs(detected_peaks_m - self.current_altitude_measured_m) <= self.altitude_search_limit_m)]
-            if valid.size > 0:
-                return np.min(valid)
-        return -1.0
-
-    def _perform_coarse_fft(self, adc_cube: np.ndarray) -> np.ndarray:
-        # float64 on the device: the 6-dB prominence test of find_peaks then sees the reference's numbers to ~1e-15
+    # look stages: (cube, previous hit) -> candidate ranges ---------------------------------------------------------
+    def _look_coarse(self, adc_cube: np.ndarray, _prev) -> np.ndarray:
+        # float64 on the device: the 6-dB prominence test then sees the reference's numbers to ~1e-15
         ctx, bufs, d_cube, (V, S, C) = self._upload_cube(adc_cube)
-        d_out = bufs.get("profile64", S * 8)
-        _lib.check(ctx.lib.mmw_range_profile_f64(ctx.handle, d_cube.ptr, d_out.ptr, 1, V, S, C, 0))
-        return d_out.download((S,), np.float64)
+        d_prof = bufs.get("profile64", S * 8)
+        _lib.check(ctx.lib.mmw_range_profile_f64(ctx.handle, d_cube.ptr, d_prof.ptr, 1, V, S, C, 0))
+        self.coarse_fft_data = d_prof.download((S,), np.float64)
+        return self.find_peaks(20 * np.log10(self.coarse_fft_data), self.range_bins, max_peaks=3)[0]
 
-    def _get_coarse_peaks(self, coarse_fft: np.ndarray) -> np.ndarray:
-        peaks, _ = self.find_peaks(rng_resp_db=20 * np.log10(coarse_fft), rng_bins=self.range_bins, max_peaks=3)
-        return peaks
+    def _look_zoom(self, adc_cube: np.ndarray, prev_m: float) -> np.ndarray:
+        lo = max(1e-6, prev_m - self.zoom_half_width_m)
+        hi = min(self.range_bins.max() - 1e-6, prev_m + self.zoom_half_width_m)
+        spectrum, bins = self.zoom_fft(adc_cube, lo, hi, 0)
+        return self.find_peaks(20 * np.log10(spectrum), bins, max_peaks=2)[0]
 
-    def _refine_altitude_estimate(self, adc_cube: np.ndarray, ground_peak: float) -> float:
-        range_start_m = max(1e-6, ground_peak - self.zoom_search_region_m)
-        range_end_m = min(np.max(self.range_bins) - 1e-6, ground_peak + self.zoom_search_region_m)
-        zoom_avg, zoom_bins = self.zoom_fft(adc_cube=adc_cube, range_start_m=range_start_m, range_stop_m=range_end_m,
-                                            chirp_idx=0)
-        peaks, _ = self.find_peaks(rng_resp_db=20 * np.log10(zoom_avg), rng_bins=zoom_bins, max_peaks=2)
-        return self.find_ground_peak(detected_peaks_m=peaks) if peaks.size > 0 else -1.0
-
-    def process(self, adc_cube: np.ndarray, precise_est_enabled: bool = True, **kwargs):
-        self.coarse_fft_data = self._perform_coarse_fft(adc_cube)
-        peaks = self._get_coarse_peaks(self.coarse_fft_data)
-        if peaks.size == 0:
-            return self.current_altitude_corrected_m
-        ground_peak = self.find_ground_peak(detected_peaks_m=peaks)
-        if ground_peak < 0:
-            return self.current_altitude_corrected_m
-        if not precise_est_enabled:
-            self.current_altitude_measured_m = ground_peak
-            self.current_altitude_corrected_m = ground_peak + self.range_bias
-            return self.current_altitude_corrected_m
-        refined = self._refine_altitude_estimate(adc_cube, ground_peak)
-        if refined > 0:
-            self.current_altitude_measured_m = refined
-            self.current_altitude_corrected_m = refined + self.range_bias
-        return self.current_altitude_corrected_m
+    def process(self, adc_cube: np.ndarray, precise_est_enabled: bool = True, **kwargs) -> float:
+        stages: List[Callable] = [self._look_coarse] + ([self._look_zoom] if precise_est_enabled else [])
+        hit = None
+        for look in stages:
+            hit = self.lock.admit(look(adc_cube, hit))
+            if hit is None:
+                return self.lock.reported_m
+        self.lock.accept(hit)
+        return self.lock.reported_m

@@ -8,19 +8,18 @@ import numpy as np
 
 from ... import _lib
 from ..._lazy import LazyAttrs
-from ...detectors.detector_registry import get_detector_registry
+from ...detectors.detector_registry import make_detector
 from .range_doppler_detector import RangeDopplerDetector
+from .registry import rd_detector
 
 
+@rd_detector("range_doppler_detector_2d")
 class RangeDopplerDetector2D(RangeDopplerDetector):
     _device_detect = True
 
     def __init__(self, config_manager, cfar_type: str = "ca_cfar_2d", cfar_params: Dict = {}, **kwargs):
         super().__init__(config_manager, **kwargs)
-        registry = get_detector_registry()
-        if cfar_type not in registry:
-            raise ValueError(f"Unknown CFAR type: {cfar_type}. Available: {list(registry.keys())}")
-        self.detector = registry[cfar_type](**cfar_params)
+        self.detector = make_detector(cfar_type, cfar_params)
         self.points = None      # (az_idx, el_idx) of the last frame when process_points() produced them
         self.logger.info(f"RangeDopplerDetector initialized with {cfar_type} and params {cfar_params}")
 
@@ -32,6 +31,8 @@ class RangeDopplerDetector2D(RangeDopplerDetector):
 
     def _fused_supported(self, S, C, n_az=0, n_el=0) -> bool:
         det = self.detector
+        if type(self)._detect is not RangeDopplerDetector2D._detect:
+            return False        # a subclass with its own _detect (the reference's extension point) is never bypassed
         if not hasattr(det, "_launch_device") or not hasattr(det, "num_train_cells"):
             return False
         kind, tr, td, gr, gd, _, _ = self._cfar_args()
@@ -92,6 +93,14 @@ class RangeDopplerDetector2D(RangeDopplerDetector):
         det._lazy_set("thresholds", lambda: run()["thr"])
         det._lazy_set("noise_estimates", lambda: run()["noise"])
         det._lazy_set("detections", lambda: run()["det"])
+
+    def reset(self):
+        super().reset()
+        self.points = None
+        det = self.detector
+        if isinstance(det, LazyAttrs):      # the thunks point at the frame that has just been dropped
+            det._lazy_clear("thresholds", "noise_estimates", "detections")
+            det.thresholds = det.noise_estimates = det.detections = None
 
     def process(self, adc_cube: np.ndarray, **kwargs) -> np.ndarray:
         self.points = None

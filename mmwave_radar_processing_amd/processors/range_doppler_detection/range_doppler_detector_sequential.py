@@ -7,21 +7,19 @@ from typing import Dict
 import numpy as np
 
 from ... import _lib
-from ...detectors.detector_registry import get_detector_registry
+from ...detectors.detector_registry import make_detector
 from ..range_resp import RangeProcessor
 from .range_doppler_detector import RangeDopplerDetector
+from .registry import rd_detector
 
 
+@rd_detector("range_doppler_detector_sequential")
 class RangeDopplerDetectorSequential(RangeDopplerDetector):
     def __init__(self, config_manager, rng_cfar_type: str = "os_cfar_1d", rng_cfar_params: Dict = {},
                  vel_cfar_type: str = "os_cfar_1d", vel_cfar_params: Dict = {}, **kwargs):
         super().__init__(config_manager, **kwargs)
-        registry = get_detector_registry()
-        for key in (rng_cfar_type, vel_cfar_type):
-            if key not in registry:
-                raise ValueError(f"Unknown CFAR type: {key}. Available: {list(registry.keys())}")
-        self.rng_detector = registry[rng_cfar_type](**rng_cfar_params)
-        self.vel_detector = registry[vel_cfar_type](**vel_cfar_params)
+        self.rng_detector = make_detector(rng_cfar_type, rng_cfar_params)
+        self.vel_detector = make_detector(vel_cfar_type, vel_cfar_params)
         self.range_processor = RangeProcessor(config_manager)
         self.logger.info(f"RangeDopplerDetectorSequential initialized with Range CFAR: {rng_cfar_type}, "
                          f"Velocity CFAR: {vel_cfar_type}")

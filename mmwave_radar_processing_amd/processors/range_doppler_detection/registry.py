@@ -1,15 +1,19 @@
-"""String keys -> range-Doppler detector classes
-(reference: mmwave_radar_processing/processors/range_doppler_detection/registry.py:10-23)."""
-from .range_doppler_detector_2d import RangeDopplerDetector2D
-from .range_doppler_detector_sequential import RangeDopplerDetectorSequential
-from .range_doppler_ground_detector import RangeDopplerGroundDetector
+"""String keys -> range-Doppler detector classes (the keys of the reference's
+mmwave_radar_processing/processors/range_doppler_detection/registry.py:10-23).
 
-_REGISTRY = {
-    "range_doppler_detector_2d": RangeDopplerDetector2D,
-    "range_doppler_detector_sequential": RangeDopplerDetectorSequential,
-    "range_doppler_ground_detector": RangeDopplerGroundDetector,        # stateful (Altimeter): single-frame API only
-}
+A detector class announces its key with ``@rd_detector("key")`` where it is defined; importing the package registers the
+three shipped ones, and a user class can join the same table (``PointCloudGenerator(detector_type=...)`` looks keys up here).
+"""
+_BY_KEY = {}
+
+
+def rd_detector(key: str):
+    def register(cls):
+        _BY_KEY[key] = cls
+        return cls
+    return register
 
 
 def get_range_doppler_detector_registry():
-    return dict(_REGISTRY)
+    from . import range_doppler_detector_2d, range_doppler_detector_sequential, range_doppler_ground_detector  # noqa: F401
+    return dict(_BY_KEY)

@@ -461,52 +461,6 @@ def rd_detect_sequential(cube, rng_kind, rng_params, vel_kind, vel_params):
     return _rows_to_dets(np.abs(range_doppler(cube)[0]), rows, vel_kind, vel_params)
 
 
-def range_detector(cube, kind, params):
-    """RangeDetector.process -- processors/range_detector.py:59-82: chirp-0 range profile (mean over the antennas of the
-    Hann-windowed range FFT magnitude), then the 1-D CFAR of the registry key.  -> (detection indices, thresholds, profile)."""
-    prof = range_profile(cube, 0)
-    thr, _, dets = _CFAR_1D[kind](prof, params)
-    return np.array(dets, dtype=int), thr, prof
-
-
-def micro_doppler_column(cube, rx_idx, keep):
-    """The new column of MicroDopplerProcessor.process -- processors/micro_doppler_resp.py:92-105: |fftshift_C fft2(x[rx])|
-    WITHOUT windows (complex128, as the pinned numpy 1.26.4 computes it), maximum over the kept range bins."""
-    resp = np.abs(np.fft.fftshift(np.fft.fft2(np.asarray(cube[rx_idx], dtype=np.complex128), axes=(-2, -1)), axes=1))
-    return np.max(resp[np.asarray(keep, dtype=bool), :], axis=0)
-
-
-def micro_doppler_push(history, column):
-    """micro_doppler_resp.py:107-113: the history rolls one frame to the right, the new column goes to index 0."""
-    out = np.empty_like(history)
-    out[:, 1:] = history[:, :-1]
-    out[:, 0] = column
-    return out
-
-
-def strip_map_sar(raw_cube, sc, cfg_text, vel_m_per_s, az_range=(-np.pi / 6, np.pi / 6), sensor_height_m=0.24, rx_index=0,
-                  max_sar_distance=1.5, num_tx=3, num_rx=4):
-    """StripMapSARProcessor.process -- processors/strip_map_SAR_processor.py:60-196 on a RAW cube (virtual antennas enabled:
-    de-interleaved first, virtual_array_reformater.py:44-65).  -> (image patch, x grid, y grid, angle bins)."""
-    import scipy.constants as constants
-    cube = virtual_array_reformat(raw_cube, num_rx, 0, num_tx - 1, raw_cube.shape[2] // num_tx)
-    S, C = cube.shape[1], cube.shape[2]
-    prof = [l.split() for l in cfg_text.splitlines() if l.startswith("profileCfg")][0]
-    lam = constants.c / (float(prof[2]) * 1e9)                                # :76-78 startFreq_GHz
-    chirp_period_us = float(prof[3]) + float(prof[5])                         # :92-94 idleTime + rampEndTime
-    range_bins = np.linspace(start=0, stop=sc["range_max_m"], num=S)          # :70-74
-    phase = np.linspace(start=np.pi, stop=-np.pi, num=C)                      # :86-90 (one per loop)
-    d_rx = 2 * chirp_period_us * 1e-6 * vel_m_per_s                           # :104
-    ang = np.arcsin(phase * lam) / (2 * np.pi * d_rx)                         # :107-109
-    e0 = int(np.argmin(np.abs(ang - np.min(az_range)))), int(np.argmin(np.abs(ang - np.max(az_range))))
-    a_sl = slice(min(e0), max(e0))                                            # :112-123
-    r_sl = slice(np.nonzero(range_bins > sensor_height_m)[0][0], np.nonzero(range_bins < max_sar_distance)[0][-1])   # :128-133
-    ground = np.sqrt(np.power(range_bins[r_sl], 2) - np.power(d_rx, 2))       # :135-138
-    thetas, rhos = np.meshgrid(ang[a_sl], ground, indexing="xy")
-    img = np.fft.fftshift(np.fft.fft2(np.asarray(cube[rx_index], dtype=np.complex128), axes=(-2, -1)), axes=1)      # :181-188
-    return img[r_sl, a_sl], rhos * np.cos(thetas), rhos * np.sin(thetas), ang
-
-
 def find_peaks_db(resp_db, bins, max_peaks=3, threshold_db=20):
     """RangeProcessor.find_peaks -- processors/range_resp.py:104-149 (scipy.signal.find_peaks, prominence 6 dB; peaks
     within threshold_db of the strongest; strongest first; at most max_peaks)."""

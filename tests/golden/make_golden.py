@@ -36,9 +36,6 @@ from mmwave_radar_processing.processors.range_doppler_detection.range_doppler_gr
 from mmwave_radar_processing.processors.point_cloud_generator import PointCloudGenerator  # noqa: E402
 from mmwave_radar_processing.processors.simple_synthetic_array_beamformer_processor_multiFrame import SyntheticArrayBeamformerProcessor  # noqa: E402
 from mmwave_radar_processing.processors.doppler_azimuth_resp import DopplerAzimuthProcessor      # noqa: E402
-from mmwave_radar_processing.processors.range_detector import RangeDetector                        # noqa: E402
-from mmwave_radar_processing.processors.micro_doppler_resp import MicroDopplerProcessor            # noqa: E402
-from mmwave_radar_processing.processors.strip_map_SAR_processor import StripMapSARProcessor        # noqa: E402
 from mmwave_radar_processing.detectors import CaCFAR1D, CaCFAR2D, GoCFAR1D, SoCFAR1D, OsCFAR1D, OsCFAR2D  # noqa: E402
 
 from mmwave_radar_processing_amd import synth                                          # noqa: E402
@@ -348,57 +345,12 @@ def gen_detectors_rd():
     print("detectors_rd.npz:", {k: (v.shape if v.ndim else v.item()) for k, v in d.items()})
 
 
-YAML_RANGE_DET = dict(cfar_type="os_cfar_1d", cfar_params={"num_train": 5, "num_guard": 3, "rho": 0.5, "alpha": 2})   # gui_configs/processor_params.yaml:28-34
-GO_RANGE_DET = dict(cfar_type="go_cfar_1d", cfar_params={"num_train": 6, "num_guard": 2, "pfa": 1e-2})
-MICRO_DOPPLER = dict(target_ranges=[0.5, 2.0], num_frames_history=6)
-
-
-def gen_small_processors():
-    """RangeDetector (range profile + 1-D CFAR) and MicroDopplerProcessor (stateful spectrogram) run by the reference.
-    The micro-Doppler input is handed over as complex128: the reference pins numpy 1.26.4, whose fft2 computes a complex64
-    input in double precision; numpy 2.x in this container would keep it single."""
-    d = {}
-    cm = load_cm(synth.SYNTH_CFG_256x128x12)
-    with open(os.path.join(REF, "configs", "6843_RadVel_ods_20Hz.cfg")) as f:
-        cm2 = load_cm(f.read())
-    cases = [(f"s{s}", cm, synth.synth_cube(s)) for s in (0, 1, 2)] + [("np2", cm2, synth.synth_cube(202, (12, 63, 70)))]
-    for tag, c, cube in cases:
-        for name, params in (("yaml", YAML_RANGE_DET), ("go", GO_RANGE_DET)):
-            det = RangeDetector(c, **params)
-            d[f"{tag}_rangedet_{name}_dets"] = np.asarray(det.process(cube)).astype(int)
-            d[f"{tag}_rangedet_{name}_thr"] = np.asarray(det.thresholds)
-            d[f"{tag}_rangedet_{name}_resp"] = np.asarray(det.range_resp)
-    seq = synth.synth_ground_sequence(606, 5)
-    md = MicroDopplerProcessor(cm, **MICRO_DOPPLER)
-    for f in range(seq.shape[0]):
-        out = md.process(seq[f].astype(np.complex128), rx_idx=0 if f < 3 else 2)
-        if f in (0, 4):
-            d[f"micro_doppler_f{f}"] = out.copy()
-    d["micro_doppler_vel_bins"] = md.vel_bins
-    d["micro_doppler_keep"] = md.range_bin_idxs_to_keep
-    md.reset()
-    d["micro_doppler_after_reset"] = md.process(seq[1].astype(np.complex128)).copy()
-    # strip-map SAR image of one RAW frame (the processor de-interleaves it itself) at two platform speeds (again
-    # complex128 in: numpy 1.26.4 semantics)
-    for tag, vel, kw in (("a", 20.0, {}), ("b", 35.0, dict(sensor_height_m=0.3, rx_index=5, max_SAR_distance=9.5))):
-        sar = StripMapSARProcessor(cm, az_angle_range_rad=[-0.5, 0.4] if tag == "b" else np.deg2rad(np.array([-30, 30])))
-        d[f"sar_{tag}_image"] = sar.process(synth.synth_raw_cube(7).astype(np.complex128), vel_m_per_s=vel, **kw)
-        d[f"sar_{tag}_x"] = sar.x_s
-        d[f"sar_{tag}_y"] = sar.y_s
-        d[f"sar_{tag}_angle_bins"] = sar.angle_bins_rad
-    np.savez_compressed(os.path.join(HERE, "small_processors.npz"), **d)
-    print("small_processors.npz:", {k: v.shape for k, v in d.items()})
-
-
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "doppler_azimuth":
         gen_doppler_azimuth()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "detectors_rd":
         gen_detectors_rd()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "small_processors":
-        gen_small_processors()
         sys.exit(0)
     gen_cfgs()
     gen_small_chain()
@@ -407,4 +359,3 @@ if __name__ == "__main__":
     gen_bartlett()
     gen_doppler_azimuth()
     gen_detectors_rd()
-    gen_small_processors()

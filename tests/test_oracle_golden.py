@@ -250,47 +250,6 @@ def test_sequential_and_os2d_detectors_on_range_doppler_data():
     assert total > 2000
 
 
-# parameters of tests/golden/make_golden.py::gen_small_processors (gui_configs/processor_params.yaml:28-34 and a GO variant)
-RANGE_DET = {"yaml": ("os_cfar_1d", {"num_train": 5, "num_guard": 3, "rho": 0.5, "alpha": 2}),
-             "go": ("go_cfar_1d", {"num_train": 6, "num_guard": 2, "pfa": 1e-2})}
-MICRO_DOPPLER = dict(target_ranges=[0.5, 2.0], num_frames_history=6)
-SAR_CASES = (("a", 20.0, {}), ("b", 35.0, dict(az_range=(-0.5, 0.4), sensor_height_m=0.3, rx_index=5, max_sar_distance=9.5)))
-
-
-def test_range_detector_and_micro_doppler_fixtures():
-    """RangeDetector (chirp-0 range profile + 1-D CFAR) and the MicroDopplerProcessor spectrogram over a 5-frame sequence
-    (antenna 0 for three frames, antenna 2 for two; then reset() and one frame), both run by the imported reference:
-    oracle == reference -- detections identical, thresholds / profile / spectrogram to 1e-12."""
-    g = np.load(os.path.join(GOLDEN, "small_processors.npz"))
-    for tag, _, cube in _rd_cases():
-        if tag == "s3":
-            continue
-        for name, (kind, params) in RANGE_DET.items():
-            dets, thr, prof = O.range_detector(cube, kind, params)
-            np.testing.assert_array_equal(dets, g[f"{tag}_rangedet_{name}_dets"])
-            close(prof, g[f"{tag}_rangedet_{name}_resp"], 1e-12)
-            fin = np.isfinite(thr)
-            np.testing.assert_array_equal(fin, np.isfinite(g[f"{tag}_rangedet_{name}_thr"]))
-            close(thr[fin], g[f"{tag}_rangedet_{name}_thr"][fin], 1e-12)
-    seq = synth.synth_ground_sequence(606, 5)
-    keep = g["micro_doppler_keep"]
-    hist = np.zeros((seq.shape[3], MICRO_DOPPLER["num_frames_history"]))
-    for f in range(5):
-        hist = O.micro_doppler_push(hist, O.micro_doppler_column(seq[f], 0 if f < 3 else 2, keep))
-        if f in (0, 4):
-            close(hist, g[f"micro_doppler_f{f}"], 1e-12)
-    fresh = O.micro_doppler_push(np.zeros_like(hist), O.micro_doppler_column(seq[1], 0, keep))
-    close(fresh, g["micro_doppler_after_reset"], 1e-12)
-    # strip-map SAR patch of a raw frame at two platform speeds
-    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
-    for tag, vel, kw in SAR_CASES:
-        img, xs, ys, ang = O.strip_map_sar(synth.synth_raw_cube(7), sc, synth.SYNTH_CFG_256x128x12, vel, **kw)
-        close(img, g[f"sar_{tag}_image"], 1e-12)
-        np.testing.assert_array_equal(ang, g[f"sar_{tag}_angle_bins"])
-        np.testing.assert_array_equal(xs, g[f"sar_{tag}_x"])
-        np.testing.assert_array_equal(ys, g[f"sar_{tag}_y"])
-
-
 def test_ground_detector_sequence_with_altimeter_state():
     """RangeDopplerGroundDetector over a 5-frame sequence (the altimeter keeps its last altitude), reset(), one more frame:
     detections and the altitude track of the oracle == reference, for the YAML parameters (never locks on: the ground return
