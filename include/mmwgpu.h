@@ -313,6 +313,9 @@ int mmw_widen_f32_f64(mmw_ctx *ctx, const float *d_in, double *d_out, size_t n);
  * In-situ HBM ceiling on the same device: mode 0 = 16-B/lane copy, 1 = write only, 2 = read only,
  * grid-stride over `blocks` workgroups of 256 (0 = 8 per CU).  Used by tools/kbench.py to state what
  * a known-good streaming kernel reaches next to the hot-path kernels. */
+/* mmw_diag_set_option: a tuning / test switch of THIS context (the names INTEGRATION.md lists; the same names are read
+ *   from the environment when the context has no value of its own).  value == INT_MIN removes the context's value. */
+int mmw_diag_set_option(mmw_ctx *ctx, const char *name, int value);
 int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int mode, int blocks);
 /* Matrix-core peak of this device, measured: back-to-back MFMAs on independent accumulators with register operands,
  * two waves per SIMD.  kind 0 = v_mfma_f32_32x32x2_f32 (the Bartlett GEMM's instruction), 1 = v_mfma_f64_16x16x4_f64

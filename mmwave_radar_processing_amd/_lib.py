@@ -48,6 +48,7 @@ _SIGNATURES = {
     "mmw_memcpy_h2d": [_vp, _vp, _vp, _sz],
     "mmw_memcpy_d2h": [_vp, _vp, _vp, _sz],
     "mmw_memset": [_vp, _vp, _i, _sz],
+    "mmw_diag_set_option": [_vp, C.c_char_p, _i],
     "mmw_host_alloc": [_vp, C.POINTER(_vp), _sz],
     "mmw_host_free": [_vp, _vp],
     "mmw_memcpy_async": [_vp, _vp, _vp, _sz, _i, _i],
@@ -241,6 +242,11 @@ class Context:
         check(self.lib.mmw_sync(self.handle))
 
     # host streaming ------------------------------------------------------
+    def set_option(self, name: str, value=None) -> None:
+        """A tuning / test switch of this context (``mmw_diag_set_option``; INTEGRATION.md lists the names).  ``None`` removes
+        the context's value again (the environment / the default applies)."""
+        check(self.lib.mmw_diag_set_option(self.handle, name.encode(), -2**31 if value is None else int(value)))
+
     def host_array(self, shape, dtype) -> np.ndarray:
         """Pinned host memory as an ndarray (freed with the context)."""
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize

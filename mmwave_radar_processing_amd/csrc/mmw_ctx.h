@@ -104,6 +104,11 @@ struct mmw_ctx {
     bool chain_settling = false;             // inside mmw_chain_settle (its own entry-point calls must not recurse)
     bool rd_attr_set = false;    // hipFuncSetAttribute(max dynamic LDS) done for this context's device
     bool pipe_pending = false;   // chain work in flight on q_rd/q_ang that the context stream has not joined yet
+    // overlapped detection pipeline (mmw_detect.h): producer / consumer queues on disjoint CU sets + their join events
+    hipStream_t q_drd = nullptr, q_dscr = nullptr;
+    int q_drd_cus = 0;
+    hipEvent_t det_begin = nullptr, det_rd_done = nullptr, det_scr_done = nullptr;
+    bool det_unavailable = false;
     hipStream_t q_copy = nullptr;               // copy queue of the host-streaming API (mmw_memcpy_async), created lazily
     std::vector<void *> host_owned;             // mmw_host_alloc'ed pinned blocks still alive
     hipEvent_t t0 = nullptr, t1 = nullptr;      // mmw_timer_*
@@ -118,6 +123,7 @@ struct mmw_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     std::vector<void *> owned;  // mmw_malloc'ed blocks still alive (freed at destroy)
+    std::map<std::string, int> opts;            // mmw_diag_set_option: per-context tuning / test switches (before the environment)
     std::deque<mmw::CztPlan> czt_plans;         // (deque: pointers to cached plans survive later insertions)
     void *capon_z = nullptr;                    // exp(-j pi sin(theta_t)) of the last Capon angle grid ...
     std::vector<double> capon_key;              // ... and the grid it was built from
@@ -276,6 +282,16 @@ inline int tune_int(const char *name, int dflt) {
     const int v = (s && *s) ? std::atoi(s) : dflt;
     cache[name] = v;
     return v;
+}
+
+// per-context option (mmw_diag_set_option), else the process environment, else the default
+inline int opt_int(const mmw_ctx *ctx, const char *name, int dflt) {
+    if (ctx) {
+        auto it = ctx->opts.find(name);
+        if (it != ctx->opts.end()) return it->second;
+    }
+    const char *s = std::getenv(name);
+    return (s && *s) ? std::atoi(s) : dflt;
 }
 
 inline int check_launch(const char *what) {

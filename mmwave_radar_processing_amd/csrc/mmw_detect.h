@@ -37,6 +37,7 @@
 #pragma once
 #include "mmw_ctx.h"
 #include "mmw_misc.h"
+#include "mmw_fft_fused.h"
 
 namespace mmw {
 
@@ -77,10 +78,23 @@ struct DetectArgs {
     const float2 *twA;
     ArgmaxRefine rf_az, rf_el;
     long long *clk;            // diagnostics (MMW_PHASE_CLOCKS=1): s_memtime at the phase boundaries of a mid-batch workgroup
+    // overlapped schedule (k_detect_screen<..., true>): persistent workgroups draw frames from ctl[CTL_ANG_TICKET] and wait
+    // until the producer (k_rd_fused_256x128_persist<DET>) has published all V planes of the frame in frame_cnt[f]
+    unsigned *sy_ctl, *sy_frame_cnt;
+    unsigned long long sy_timeout;      // s_memrealtime ticks a wait may last
+    int sy_naps, n_frames;
 };
 
 __device__ __forceinline__ void det_mark(const DetectArgs &a, int i) {
     if (a.clk && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) a.clk[i] = (long long)__builtin_amdgcn_s_memtime();
+}
+// persistent form: phase i of the frame in hand ends now -- clk[i - 1] accumulates its clocks (workgroup 0; clk[6] = last mark)
+__device__ __forceinline__ void det_mark_acc(const DetectArgs &a, int i) {
+    if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long now = (long long)__builtin_amdgcn_s_memtime();
+        if (i > 0) a.clk[i - 1] += now - a.clk[6];
+        a.clk[6] = now;
+    }
 }
 
 // exclusive prefix of v over the workgroup (thread order), total in *total; ws: 40 ints of LDS
@@ -284,6 +298,7 @@ __device__ __forceinline__ void detect_argmax_lanes(const DetectArgs &a, const f
 // Ordered compaction of the frame's bit mask (bit r * C + c, LDS) into dets / counts, then the angle argmax of every
 // detection.  ws: 96 ints of LDS ([48, 80) = antenna table), tw: W_A^m in LDS.  Ends with every thread past its last
 // use of bits / ws.
+template <bool SYNC = false>
 __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const unsigned *bits, int *ws, const float2 *tw) {
     const int tid = threadIdx.x, C = a.C;
     int base = 0;
@@ -305,7 +320,7 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
         base += total;
     }
     if (tid == 0) a.counts[f] = base;           // exact even beyond cap (MMW_ERR_TRUNCATED is the caller's check)
-    det_mark(a, 3);
+    if constexpr (SYNC) det_mark_acc(a, 3); else det_mark(a, 3);
     const int n_az = a.az.n, n_el = a.el.n;
     if (n_az == 0 && n_el == 0) return;
     __syncthreads();                            // the workgroup's own dets are visible to all of its waves
@@ -315,15 +330,23 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
     // lanes [0, n_az): azimuth list, lanes [DET_LIST2, DET_LIST2 + n_el): elevation list
     const bool mine = (lane < n_az) || (lane >= DET_LIST2 && lane < DET_LIST2 + n_el);
     const long ant = mine ? tab[lane] : 0;
-    const float l1v = mine ? a.l1[f * a.V + ant] : 0.f;
+    // SYNC: the cube and the norms were written by the producer kernel that is still running on other XCDs: coherent
+    // (sc1) loads, never the XCD-local L2's copy of a line
+    float l1v = 0.f;
+    if (mine) l1v = SYNC ? __hip_atomic_load(a.l1 + f * a.V + ant, MMW_RLX_AGENT) : a.l1[f * a.V + ant];
     const float2 *plane = a.rd + (f * a.V + ant) * (long)a.S * C;
+    [[maybe_unused]] const auto frame_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.rd + f * a.V * (long)a.S * C), 0,
+                                                                              (int)((unsigned)a.V * (unsigned)a.S * (unsigned)C * 8u), 0x00020000);
     constexpr int NW = DET_NT / 64;
     // the cells of the wave's next detection travel while it works on this one
     auto fetch = [&](int det) {
         float2 v = make_float2(0.f, 0.f);
         if (det < n_det && mine) {
             const long slot = f * a.cap + det;
-            v = plane[(long)a.dets[slot * 2] * C + a.dets[slot * 2 + 1]];
+            const long cell = (long)a.dets[slot * 2] * C + a.dets[slot * 2 + 1];
+            if constexpr (SYNC)
+                v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(frame_rs, (unsigned)((ant * a.S * C + cell) * 8), 0, 16));
+            else v = plane[cell];
         }
         return v;
     };
@@ -338,9 +361,10 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
 }
 
 // A tile of a frame: cells under test in rows [r_lo, r_hi), magnitudes of rows [x_lo, x_hi) = [r_lo - hr, r_hi + hr) in LDS
-// (Xs row 0 = plane row x_lo), detection bit of cell (r, c) at tile bit (r - r_lo) * C + c.
+// (Xs row 0 = plane row x_lo), detection bit of cell (r, c) at mask bit (r - b_lo) * C + c: b_lo = r_lo for one of several
+// tiles (the tile's own mask), 0 when the tile is the whole frame (the mask is the frame's, no shift afterwards).
 struct DetTile {
-    int r_lo, r_hi, x_lo, x_hi;
+    int r_lo, r_hi, x_lo, x_hi, b_lo;
 };
 
 __device__ __forceinline__ void det_undecided(const DetectArgs &a, long f, int cell, int *ws) {
@@ -407,7 +431,7 @@ __device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const
             }
             const unsigned long long m = __ballot(det);
             if (m && lane == 0) {
-                const long b0 = (long)(r0 - tl.r_lo) * C + i0;
+                const long b0 = (long)(r0 - tl.b_lo) * C + i0;
                 const int wd = (int)(b0 >> 5), sh = (int)(b0 & 31);
                 const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
                 const unsigned w0 = lo << sh, w1 = (sh ? lo >> (32 - sh) : 0u) | (hi << sh), w2 = sh ? hi >> (32 - sh) : 0u;
@@ -506,7 +530,7 @@ __device__ __forceinline__ void cfar_bands_ct(const DetectArgs &a, long f, const
                 }
             }
             if (nib) {
-                const long b0 = (long)(r - tl.r_lo) * C + c0;
+                const long b0 = (long)(r - tl.b_lo) * C + c0;
                 const unsigned long long m = (unsigned long long)nib << (b0 & 31);
                 atomicOr(&bits[b0 >> 5], (unsigned)m);
                 if (m >> 32) atomicOr(&bits[(b0 >> 5) + 1], (unsigned)(m >> 32));
@@ -526,13 +550,15 @@ inline size_t detect_screen_lds(int x_rows, int C, int band_rows, int band_pitch
 
 // TR, TD, GR, GD >= 0: the window is a compile-time constant (every loop over it unrolls: all of a cell's LDS reads are
 // issued before the first add); -1: taken from the arguments at run time.
-template <int TR, int TD, int GR, int GD>
-__global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
+// SYNC: the consumer of the overlapped schedule -- a persistent grid on its own CU set; a workgroup draws a frame ticket,
+// waits for the producer to publish the frame's V planes, and screens it while the producer is still transforming later
+// frames on the other CUs (one tile per frame: planes whose magnitudes fit the LDS).  A wait that times out (the two
+// launches did not run side by side) raises the abort word: the frame in hand and every ticket still to be drawn get
+// counts[f] = -1, i.e. they are handed back to the caller's float64 path like any other frame the screening cannot decide.
+template <int TR, int TD, int GR, int GD, bool SYNC>
+__device__ __forceinline__ void detect_screen_frame(const DetectArgs &a, const long f, const int t, char *smem) {
     constexpr bool CT = TR >= 0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = a.S, C = a.C, tid = threadIdx.x;
-    const long f = blockIdx.x / a.tiles;
-    const int t = blockIdx.x - (int)f * a.tiles;
     const int hr = CT ? TR + GR : a.tr + a.gr, hd = CT ? TD + GD : a.td + a.gd;
     const bool window_fits = S > 2 * hr && C > 2 * hd;
     DetTile tl;
@@ -540,6 +566,7 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
     tl.r_hi = window_fits ? min(tl.r_lo + a.tile_rows, S - hr) : 0;
     tl.x_lo = window_fits ? tl.r_lo - hr : 0;
     tl.x_hi = window_fits ? tl.r_hi + hr : S;                   // (no valid cell: one tile that only writes the magnitudes)
+    tl.b_lo = a.tiles == 1 ? 0 : tl.r_lo;
     const int x_rows_max = a.tile_rows + 2 * hr;
     float *Xs = reinterpret_cast<float *>(smem);
     size_t off = ((size_t)(window_fits ? x_rows_max : 0) * C * 4 + 15) & ~(size_t)15;
@@ -549,15 +576,15 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
     off += 2 * band_bytes;
     unsigned *bits = reinterpret_cast<unsigned *>(smem + off);     // a.words words: tile mask now, frame mask in the last tile
     off += ((size_t)a.words * 4 + 15) & ~(size_t)15;
-    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, 46 ticket, [48, 80) antennas
+    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, 46 ticket, 47 abort, [48, 80) antennas
     float2 *tw = reinterpret_cast<float2 *>(smem + off + 96 * 4);
-    det_mark(a, 0);
+    if constexpr (SYNC) det_mark_acc(a, 0); else det_mark(a, 0);
     if (tid < 2) ws[44 + tid] = 0;
     const int t_cells = (tl.r_hi - tl.r_lo) * C, t_words = (t_cells + 31) / 32;
-    for (int w = tid; w < t_words + 1 && w < a.words; w += DET_NT) bits[w] = 0u;
+    for (int w = tid; w < (a.tiles == 1 ? a.words : t_words + 1) && w < a.words; w += DET_NT) bits[w] = 0u;
 
     // error band scale; 1.0001 covers the float32 summation of the L1 norm itself
-    const float l1v = a.l1[f * a.V];
+    const float l1v = SYNC ? __hip_atomic_load(a.l1 + f * a.V, MMW_RLX_AGENT) : a.l1[f * a.V];
     const double Bf = (double)a.k_fft * (double)l1v * 1.0001;
     // NaN / inf samples in antenna 0, or a scale at which float32 squares over- / underflow (an all-zero plane is fine)
     const bool degenerate = !(l1v == 0.f || (l1v >= 1e-10f && l1v <= 1e18f));
@@ -571,11 +598,16 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
         if ((C & 1) == 0) {
             typedef float f4 __attribute__((ext_vector_type(4)));
             const f4 *p4 = reinterpret_cast<const f4 *>(p);
+            [[maybe_unused]] const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p), 0, n * 8, 0x00020000);
             constexpr int U = 16;                           // loads in flight per thread (a whole 256 x 128 plane in one trip)
             for (int i0 = tid; i0 < n / 2; i0 += DET_NT * U) {
                 f4 v[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) v[u] = p4[min(i0 + u * DET_NT, n / 2 - 1)];
+                for (int u = 0; u < U; ++u) {
+                    const int i = min(i0 + u * DET_NT, n / 2 - 1);
+                    if constexpr (SYNC) v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(prs, (unsigned)i * 16u, 0, 16));
+                    else v[u] = p4[i];
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = i0 + u * DET_NT;
@@ -588,8 +620,11 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
                 }
             }
         } else {
+            [[maybe_unused]] const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p), 0, n * 8, 0x00020000);
             for (int i = tid; i < n; i += DET_NT) {
-                const float2 v = p[i];
+                float2 v;
+                if constexpr (SYNC) v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(prs, (unsigned)i * 8u, 0, 16));
+                else v = p[i];
                 const float m = __fsqrt_rn(fmaf(v.x, v.x, v.y * v.y));
                 if (window_fits) Xs[i] = m;
                 if (mg && i >= keep_lo && i < keep_hi) mg[i] = m;
@@ -597,14 +632,38 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
         }
     }
     __syncthreads();
-    det_mark(a, 1);
+    if constexpr (SYNC) det_mark_acc(a, 1); else det_mark(a, 1);
 
     if (!degenerate && window_fits) {
         if constexpr (CT) cfar_bands_ct<TR, TD, GR, GD>(a, f, tl, Xs, Vt, Vg, bits, ws, Bf);
         else cfar_bands_rt(a, f, tl, Xs, Vt, Vg, bits, ws, Bf);
     }
     __syncthreads();
-    det_mark(a, 2);
+    if constexpr (SYNC) det_mark_acc(a, 2); else det_mark(a, 2);
+    if (a.tiles == 1) {
+        // one tile = the whole frame: its mask is complete in the LDS, nothing to tell other workgroups.  Only a frame with
+        // undecided cells leaves its mask in global memory, for k_cfar_cell_exact to complete (whoever finishes it reads the
+        // mask in a later launch).
+        const int st = (degenerate ? DST_DEGENERATE : 0) | (ws[45] ? DST_OVERFLOW : 0) | (ws[44] ? DST_UNDECIDED : 0);
+        if (st & (DST_DEGENERATE | DST_OVERFLOW)) {             // the float64 path decides this frame
+            if (tid == 0) {
+                a.counts[f] = -1;
+                atomicAdd(a.ctl + DCTL_FALLBACK, 1);
+            }
+            return;
+        }
+        if (st & DST_UNDECIDED) {                               // compaction after k_cfar_cell_exact
+            for (int w = tid; w < a.words; w += DET_NT) a.bits[f * a.words + w] = bits[w];
+            if (tid == 0) a.flag_frames[atomicAdd(a.ctl + DCTL_FLAG_FRAMES, 1)] = (int)f;
+            return;
+        }
+        detect_ant_table(a, ws + 48);
+        for (int i = tid; i < a.A; i += DET_NT) tw[i] = a.twA[i];
+        __syncthreads();
+        detect_finish<SYNC>(a, f, bits, ws, tw);
+        if constexpr (SYNC) det_mark_acc(a, 4); else det_mark(a, 4);
+        return;
+    }
     // the tile's bits into the frame's mask (zeroed before the launch); tiles need not start on a word boundary
     {
         const long b0 = (long)tl.r_lo * C;
@@ -651,6 +710,48 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
     __syncthreads();
     detect_finish(a, f, bits, ws, tw);
     det_mark(a, 4);
+}
+
+template <int TR, int TD, int GR, int GD>
+__global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long f = blockIdx.x / a.tiles;
+    detect_screen_frame<TR, TD, GR, GD, false>(a, f, blockIdx.x - (int)f * a.tiles, smem);
+}
+
+template <int TR, int TD, int GR, int GD>
+__global__ __launch_bounds__(DET_NT) void k_detect_screen_sync(DetectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int sy[2];       // ticket, abort
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) {
+            const long long t_wait = a.clk ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            const int f = (int)__hip_atomic_fetch_add(a.sy_ctl + CTL_ANG_TICKET, 1u, MMW_RLX_AGENT);
+            bool dead = false;
+            if (f < a.n_frames) {
+                unsigned *cnt = a.sy_frame_cnt + f;
+                dead = __hip_atomic_load(a.sy_ctl + CTL_ABORT, MMW_RLX_AGENT) != 0u ||
+                       !chain_wait(cnt, (unsigned)a.V, __hip_atomic_load(cnt, MMW_RLX_AGENT), a.sy_ctl, a.sy_timeout, a.sy_naps);
+                if (dead) {                     // handed back: the caller's float64 path decides this frame
+                    a.counts[f] = -1;
+                    atomicAdd(a.ctl + DCTL_FALLBACK, 1);
+                }
+            }
+            sy[0] = f;
+            sy[1] = dead ? 1 : 0;
+            if (a.clk && blockIdx.x == 0 && f < a.n_frames) {
+                a.clk[5] += (long long)__builtin_amdgcn_s_memtime() - t_wait;
+                a.clk[7] += 1;
+            }
+        }
+        __syncthreads();        // between the poll and EVERY load of the published bytes; also: the previous frame's LDS is dead
+        const int f = __builtin_amdgcn_readfirstlane(sy[0]);
+        const bool dead = __builtin_amdgcn_readfirstlane(sy[1]) != 0;
+        if (f >= a.n_frames) return;
+        if (!dead) detect_screen_frame<TR, TD, GR, GD, true>(a, f, 0, smem);
+        __syncthreads();
+    }
 }
 
 // Frames whose masks were completed by k_cfar_cell_exact: compaction + argmax.  Persistent over the flagged list.

@@ -53,6 +53,7 @@ struct ChainSync {
                                 // a packed word, not an array: indexing an array in the argument block spills it to scratch
     int ntx, nrx;               // ntx > 1: the RD input is the raw [F][nrx][S][ntx * C] cube
     int i16;                    // ... of int16 (I, Q) cells (256 x 128 producer only)
+    unsigned *frame_cnt;        // DET producers: [n_frames] planes published per frame (the detection stage's hand-off, mmw_detect.h)
 };
 #define MMW_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 // one lane: wait until (int)(*cnt - target) >= 0; false on timeout / abort (and the abort flag is raised).
@@ -734,7 +735,10 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
 // same quantity as k_plane_l1, here for free while the samples are in registers).
 // RAWIN (SYNC only): the input is the raw cube; the de-interleave is folded into the row loads (two 8-B loads per lane).
 // I16 (RAWIN only): the raw cube holds int16 (I, Q) cells: one 4-byte load per cell, converted when the plane is windowed.
-template <bool NTIN, int PF, bool SYNC = false, bool L1N = false, bool RAWIN = false, bool I16 = false>
+// DET (SYNC + L1N): the producer of the device-synchronised DETECTION pipeline (mmw_detect.h: DetSync).  `out` is the caller's
+// plain [F][V][256][128] cube, not a ring -- nothing is ever overwritten, so the producer never waits --, item = frame * V +
+// antenna; every store (the plane AND its L1 norm) is sc1, and a published plane adds one to cs.frame_cnt[frame].
+template <bool NTIN, int PF, bool SYNC = false, bool L1N = false, bool RAWIN = false, bool I16 = false, bool DET = false>
 __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *__restrict__ in, cplx<float> *__restrict__ out,
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
             }
         } else {
             long plane_in = item;
-            if constexpr (SYNC) {
+            if constexpr (SYNC && !DET) {
                 const int f = item / cs.v_live;
                 plane_in = (long)f * cs.V + live_antenna(item - f * cs.v_live);
             }
@@ -798,6 +802,7 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
         }
     };
     int first = blockIdx.x, iter = 0;
+    [[maybe_unused]] int unpublished = -1;      // DET: the plane stored last, not yet published (see the end of the loop body)
     if constexpr (SYNC) {
         if (t0 == 0) {
             lds_ctl[0] = (int)(__hip_atomic_fetch_add(cs.ctl + CTL_RD_TICKET, 1u, MMW_RLX_AGENT) - cs.rd_base);
@@ -812,7 +817,10 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
         // SYNC: slot bookkeeping and (thread 0) the early, un-waited poll of the slot's consumer counter + next ticket
         int slot = 0;
         unsigned free_target = 0, free_seen = 0, next_ticket = 0;
-        if constexpr (SYNC) {
+        if constexpr (DET) {
+            // (asked for here, un-waited; it has arrived with the rows that step 0 waits for anyway, and goes to the LDS there)
+            if (t0 == 0) next_ticket = __hip_atomic_fetch_add(cs.ctl + CTL_RD_TICKET, 1u, MMW_RLX_AGENT) - cs.rd_base;
+        } else if constexpr (SYNC) {
             const int f = plane / cs.v_live, vi = plane - f * cs.v_live;
             const unsigned g = cs.s0 + (unsigned)f;
             slot = (int)(g % (unsigned)cs.ring);
@@ -849,6 +857,9 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
             y1[n1] = cplx<float>{v.z, v.w} * (hs * hc1);
             if constexpr (L1N) l1_acc += (fabsf(y0[n1].x) + fabsf(y0[n1].y)) + (fabsf(y1[n1].x) + fabsf(y1[n1].y));
         }
+        if constexpr (DET) {
+            if (t == 0) lds_ctl[(iter + 1) & 1] = (int)next_ticket;     // read behind this plane's barriers
+        }
         if constexpr (L1N) {
             for (int d = 32; d >= 1; d >>= 1) l1_acc += __shfl_xor(l1_acc, d, 64);
             if (l == 0) lds_l1[w] = l1_acc;      // read by thread 0 after this plane's first barrier
@@ -858,7 +869,9 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
         bool dead = false;      // SYNC: hand-off timed out / aborted: no stores, leave after this plane's barriers
         unsigned ring_soff = 0;
         auto ring_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0, 0x00020000);      // SYNC: set once the slot is free
-        if constexpr (SYNC) ring_soff = (unsigned)(dst - out) * 8u;
+        if constexpr (SYNC && !DET) ring_soff = (unsigned)(dst - out) * 8u;
+        // DET: one descriptor per plane (its base is wave-uniform; a cube of many frames exceeds 32-bit offsets)
+        if constexpr (DET) ring_rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, RD_S * RD_C * 8, 0x00020000);
         static_for<2>([&](auto H) {
             constexpr int h = decltype(H)::value;
             // ---- X1: [k1l][j = w][c], twiddle applied on the way out
@@ -877,24 +890,36 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
             if constexpr (h == 0 && SYNC) {
                 // the slot must be free before this plane's first store (end of this half); the next ticket goes to
                 // the other waves through LDS at the same barrier
-                if (t == 0) {
-                    if (!chain_wait(cs.ctl + CTL_CNT + CTL_RING_MAX + slot, free_target, free_seen, cs.ctl, cs.timeout, cs.naps_rd)) lds_ctl[2] = 1;
-                    lds_ctl[(iter + 1) & 1] = (int)next_ticket;
+                if constexpr (!DET) {
+                    if (t == 0) {
+                        if (!chain_wait(cs.ctl + CTL_CNT + CTL_RING_MAX + slot, free_target, free_seen, cs.ctl, cs.timeout, cs.naps_rd)) lds_ctl[2] = 1;
+                        lds_ctl[(iter + 1) & 1] = (int)next_ticket;
+                    }
                 }
             }
             __syncthreads();
+            if constexpr (DET && h == 0) {
+                // Deferred publication of the PREVIOUS plane: vmcnt retires in issue order, loads and stores alike, so a wave
+                // that has the rows of THIS plane it asked for after its last stores (rows PF..15, waited for in step 0) has
+                // those stores behind it; every wave is past step 0 here.  The producer never stalls on a store drain.
+                if (t == 0 && unpublished >= 0) __hip_atomic_fetch_add(cs.frame_cnt + unpublished / cs.V, 1u, MMW_RLX_AGENT);
+            }
             if constexpr (L1N && h == 0) {
                 if (t == 0) {               // fixed summation order: the value does not depend on timing
                     float a = 0.f;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) a += lds_l1[i];
-                    l1[plane] = a;
+                    // DET: the consumer reads it from another XCD: write-through, drained with this wave's plane stores
+                    if constexpr (DET) __hip_atomic_store(l1 + plane, a, MMW_RLX_AGENT);
+                    else l1[plane] = a;
                 }
             }
             if constexpr (SYNC) {
                 if constexpr (h == 0) {
-                    dead = __builtin_amdgcn_readfirstlane(lds_ctl[2]) != 0;
-                    ring_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, dead ? 0 : (int)((unsigned)cs.ring * (unsigned)cs.V * (RD_S * RD_C * 8u)), 0x00020000);
+                    if constexpr (!DET) {
+                        dead = __builtin_amdgcn_readfirstlane(lds_ctl[2]) != 0;
+                        ring_rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, dead ? 0 : (int)((unsigned)cs.ring * (unsigned)cs.V * (RD_S * RD_C * 8u)), 0x00020000);
+                    }
                 } else {
                     const int next = __builtin_amdgcn_readfirstlane(lds_ctl[(iter + 1) & 1]);
                     if (next < planes) issue_loads(next, std::integral_constant<int, 0>{}, std::integral_constant<int, PF>{});
@@ -947,14 +972,24 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
                     } else dst[kr * RD_C + kk] = e[bitrev<8>(k2d)];
                 });
             }
-            if constexpr (SYNC && h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
+            if constexpr (SYNC && !DET && h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
             __syncthreads();
         });
-        if constexpr (SYNC) {
+        if constexpr (DET) {
+            unpublished = plane;
+            plane = __builtin_amdgcn_readfirstlane(lds_ctl[(iter + 1) & 1]);
+        } else if constexpr (SYNC) {
             if (dead) return;
             if (t == 0) __hip_atomic_fetch_add(cs.ctl + CTL_CNT + slot, 1u, MMW_RLX_AGENT);   // plane published
             plane = __builtin_amdgcn_readfirstlane(lds_ctl[(iter + 1) & 1]);
         } else plane += gridDim.x;
+    }
+    if constexpr (DET) {
+        if (unpublished >= 0) {                 // the last plane of this workgroup: drain, then publish
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t0 == 0) __hip_atomic_fetch_add(cs.frame_cnt + unpublished / cs.V, 1u, MMW_RLX_AGENT);
+        }
     }
 }
 
@@ -1148,6 +1183,8 @@ int launch_rd_lds(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S
 inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
 // the chain's device-synchronised RD stage: `grid` persistent workgroups, n_items = frames * live planes
 int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid);   // cs.ntx > 1: raw input
+// the detection pipeline's producer: plain output cube + L1 norms, planes published per frame in cs.frame_cnt
+int launch_rd_fused_det(mmw_ctx *ctx, const void *d_in, void *d_out, float *d_l1, int n_planes, ChainSync cs, int grid);
 
 #ifdef MMW_TU_RD
 int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid) {
@@ -1167,6 +1204,19 @@ int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_ite
     else if (cs.ntx > 1) MMW_TRY(go(k_rd_fused_256x128_persist<false, 4, true, false, true>));
     else MMW_TRY(go(k_rd_fused_256x128_persist<true, 6, true>));
     return check_launch("rd_fused_sync");
+}
+
+int launch_rd_fused_det(mmw_ctx *ctx, const void *d_in, void *d_out, float *d_l1, int n_planes, ChainSync cs, int grid) {
+    const void *hs, *hc, *t256, *t128;
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_S, &hs));
+    MMW_TRY(get_table<float>(ctx, TAB_HANN, RD_C, &hc));
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 256, &t256));
+    MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, 128, &t128));
+    auto kern = k_rd_fused_256x128_persist<true, 4, true, true, false, false, true>;
+    MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in, (cplx<float> *)d_out, n_planes,
+                       (const float *)hs, (const float *)hc, (const cplx<float> *)t256, (const cplx<float> *)t128, cs, d_l1);
+    return check_launch("rd_fused_det");
 }
 
 int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int S, int C, RawView rv, float *d_l1, bool *l1_done) {

@@ -8,6 +8,7 @@
 #include "mmw_detect.h"
 
 #include <algorithm>
+#include <climits>
 #include <chrono>
 #include <memory>
 #include <cstdlib>
@@ -190,6 +191,14 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
         }
         (void)hipEventDestroy(ctx->pipe_begin);
     }
+    if (ctx->q_drd) {
+        (void)hipStreamSynchronize(ctx->q_drd);
+        (void)hipStreamSynchronize(ctx->q_dscr);
+        (void)hipStreamDestroy(ctx->q_drd);
+        (void)hipStreamDestroy(ctx->q_dscr);
+    }
+    for (hipEvent_t e : {ctx->det_begin, ctx->det_rd_done, ctx->det_scr_done})
+        if (e) (void)hipEventDestroy(e);
     if (ctx->q_copy) {
         (void)hipStreamSynchronize(ctx->q_copy);
         (void)hipStreamDestroy(ctx->q_copy);
@@ -1705,6 +1714,40 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
 }
 
 // ------------------------------------------------------------------ fused detection + point-cloud indices (mmw_detect.h)
+// The two queues of the overlapped detection schedule: the range-Doppler producer owns the first rd_cus CU-mask bits, the
+// screening consumer the rest (mask bit i belongs to XCD i % 8, and to that XCD's shader engines in turn: multiples of 32
+// keep every engine of every XCD equally populated -- an engine with fewer CUs than its neighbours paces the whole launch).
+static int ensure_det_queues(mmw_ctx *ctx, int rd_cus) {
+    if (ctx->det_unavailable) return set_error(MMW_ERR_UNSUPPORTED, "detection queues unavailable on this runtime");
+    if (ctx->q_drd && ctx->q_drd_cus == rd_cus) return MMW_OK;
+    if (ctx->q_drd) {
+        MMW_HIP(hipStreamSynchronize(ctx->q_drd));
+        MMW_HIP(hipStreamSynchronize(ctx->q_dscr));
+        MMW_HIP(hipStreamDestroy(ctx->q_drd));
+        MMW_HIP(hipStreamDestroy(ctx->q_dscr));
+        ctx->q_drd = ctx->q_dscr = nullptr;
+    }
+    if (!ctx->det_begin) {
+        MMW_HIP(hipEventCreateWithFlags(&ctx->det_begin, hipEventDisableTiming));
+        MMW_HIP(hipEventCreateWithFlags(&ctx->det_rd_done, hipEventDisableTiming));
+        MMW_HIP(hipEventCreateWithFlags(&ctx->det_scr_done, hipEventDisableTiming));
+    }
+    const int words = (ctx->num_cu + 31) / 32;
+    std::vector<uint32_t> m_rd(words, 0u), m_scr(words, 0u);
+    for (int i = 0; i < ctx->num_cu; ++i) ((i < rd_cus) ? m_rd : m_scr)[i / 32] |= 1u << (i % 32);
+    hipError_t e1 = hipExtStreamCreateWithCUMask(&ctx->q_drd, (uint32_t)words, m_rd.data()), e2 = hipSuccess;
+    if (e1 == hipSuccess) e2 = hipExtStreamCreateWithCUMask(&ctx->q_dscr, (uint32_t)words, m_scr.data());
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        if (ctx->q_drd) (void)hipStreamDestroy(ctx->q_drd);
+        ctx->q_drd = ctx->q_dscr = nullptr;
+        ctx->det_unavailable = true;
+        (void)hipGetLastError();
+        return set_error(MMW_ERR_UNSUPPORTED, "detection queue creation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    }
+    ctx->q_drd_cus = rd_cus;
+    return MMW_OK;
+}
+
 namespace {
 struct DetectPlan {
     bool ok, ct_window;
@@ -1823,7 +1866,18 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     const int n_split2 = std::min(list_cap2, n_split);
     const size_t b_list2 = up((size_t)std::max(list_cap2, 1) * sizeof(int));
     const size_t b_part = up((size_t)n_split2 * REFINE_PARTS * std::max(std::max(n_az, n_el), 1) * sizeof(cplx<double>));
-    size_t total = b_ctl + b_ff + b_cells + b_bits;
+    // Overlapped schedule (256 x 128 planes, one tile per frame, batches that fill the chip): the range-Doppler producer and the
+    // screening consumer run side by side on disjoint CU sets, frames handed over through counters in device memory.
+    // MMW_DETECT_OVERLAP=0 / 1 forces the serial / overlapped schedule; MMW_DETECT_SCR_CUS = CUs of the consumer (a multiple
+    // of 32); MMW_DETECT_TAIL=0: no second consumer launch behind the producer on the producer's CUs.
+    const int want_overlap = opt_int(ctx, "MMW_DETECT_OVERLAP", -1);
+    int scr_cus = opt_int(ctx, "MMW_DETECT_SCR_CUS", 32);
+    if (scr_cus < 1 || scr_cus >= ctx->num_cu) scr_cus = 32;
+    const bool overlap = fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && plan.tiles == 1 && want_overlap != 0 &&
+                         (want_overlap == 1 || n_frames >= 2 * ctx->num_cu) &&
+                         ensure_det_queues(ctx, ctx->num_cu - scr_cus) == MMW_OK;
+    const size_t b_sync = overlap ? up((CTL_CNT + (size_t)n_frames) * sizeof(unsigned)) : 0;
+    size_t total = b_ctl + b_ff + b_cells + b_bits + b_sync;
     if (n_az || n_el) total += b_list2 + b_part;
     MMW_TRY(ensure_scratch(ctx, total));
     char *base = (char *)ctx->scratch;
@@ -1831,15 +1885,18 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.flag_frames = (int *)(base + b_ctl);
     a.cells = (int *)(base + b_ctl + b_ff);
     a.bits = (unsigned *)(base + b_ctl + b_ff + b_cells);
-    char *next = base + b_ctl + b_ff + b_cells + b_bits;
+    unsigned *sync_words = (unsigned *)(base + b_ctl + b_ff + b_cells + b_bits);      // tickets, abort word | planes published per frame
+    char *next = base + b_ctl + b_ff + b_cells + b_bits + b_sync;
     int *list = (n_az || n_el) ? (int *)next : nullptr;
     cplx<double> *part = (n_az || n_el) ? (cplx<double> *)(next + b_list2) : nullptr;
     a.done = a.ctl + DCTL_WORDS;
     a.status = a.done + (size_t)n_frames * DET_LINE;
     MMW_HIP(hipMemsetAsync(a.ctl, 0, (DCTL_WORDS + 2 * (size_t)n_frames * DET_LINE) * sizeof(int), ctx->stream));      // counters, done, status
-    MMW_HIP(hipMemsetAsync(a.bits, 0, (size_t)n_frames * plan.words * sizeof(unsigned), ctx->stream));       // tiles OR their bits in
+    if (plan.tiles > 1)
+        MMW_HIP(hipMemsetAsync(a.bits, 0, (size_t)n_frames * plan.words * sizeof(unsigned), ctx->stream));       // tiles OR their bits in
+    if (overlap) MMW_HIP(hipMemsetAsync(sync_words, 0, b_sync, ctx->stream));
     // range-Doppler of every antenna (float32) with the planes' L1 norms
-    MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
+    if (!overlap) MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
     const float eps = 5.9604645e-8f, div = detect_bound_div();
     const int ulps = rd_error_ulps(S, C);
     a.rd = (const float2 *)d_rd;
@@ -1876,7 +1933,76 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.twA = (const float2 *)twA;
     a.rf_az = ArgmaxRefine{d_l1, a.ctl + DCTL_ARGMAX, list, list_cap2, (float)ulps * eps / div, 4.f * (float)(n_az + 4) * eps / div};
     a.rf_el = ArgmaxRefine{d_l1, a.ctl + DCTL_ARGMAX, list, list_cap2, (float)ulps * eps / div, 4.f * (float)(n_el + 4) * eps / div};
-    {
+    a.n_frames = n_frames;
+    if (overlap) {
+        a.sy_ctl = sync_words;
+        a.sy_frame_cnt = sync_words + CTL_CNT;
+        a.sy_timeout = (unsigned long long)std::max(1, opt_int(ctx, "MMW_CHAIN_TIMEOUT_MS", 2000)) * 100000ull;       // 100 MHz ticks
+        a.sy_naps = std::max(0, opt_int(ctx, "MMW_DETECT_NAPS", 4));
+        ChainSync cs{};
+        cs.ctl = sync_words;
+        cs.frame_cnt = a.sy_frame_cnt;
+        cs.V = cs.v_live = V;
+        cs.n_frames = n_frames;
+        cs.ntx = 1;
+        const int n_planes = n_frames * V, rd_cus = ctx->num_cu - scr_cus;
+        hipStream_t main_stream = ctx->stream;
+        MMW_HIP(hipEventRecord(ctx->det_begin, main_stream));
+        MMW_HIP(hipStreamWaitEvent(ctx->q_drd, ctx->det_begin, 0));
+        MMW_HIP(hipStreamWaitEvent(ctx->q_dscr, ctx->det_begin, 0));
+        auto screen = [&](int grid) -> int {
+            auto go = [&](auto kern) -> int {
+                MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_screen));
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(DET_NT), plan.lds_screen, ctx->stream, a);
+                return check_launch("detect_screen_sync");
+            };
+            if (train_r == 4 && train_d == 4 && guard_r == 2 && guard_d == 2) return go(k_detect_screen_sync<4, 4, 2, 2>);
+            if (train_r == 5 && train_d == 5 && guard_r == 3 && guard_d == 2) return go(k_detect_screen_sync<5, 5, 3, 2>);
+            return go(k_detect_screen_sync<-1, -1, -1, -1>);
+        };
+        long long *d_clk = nullptr;
+        if (opt_int(ctx, "MMW_PHASE_CLOCKS", 0)) {              // diagnostics: phase clocks of one consumer workgroup, summed over its frames
+            MMW_HIP(hipMalloc((void **)&d_clk, 8 * sizeof(long long)));
+            MMW_HIP(hipMemsetAsync(d_clk, 0, 8 * sizeof(long long), main_stream));
+            MMW_HIP(hipStreamSynchronize(main_stream));
+            a.clk = d_clk;
+        }
+        int rc = MMW_OK;
+        if (!opt_int(ctx, "MMW_DETECT_DIAG_SKIP_RD", 0)) {      // (test hook: no producer -- the consumer's bounded wait must give up)
+            ctx->stream = ctx->q_drd;
+            ProfScope ps(ctx, "rd");
+            rc = launch_rd_fused_det(ctx, d_cubes, d_rd, d_l1, n_planes, cs, std::min(rd_cus, n_planes));
+        }
+        if (rc == MMW_OK) {
+            ctx->stream = ctx->q_dscr;
+            ProfScope ps(ctx, "detect");
+            rc = screen(std::min(scr_cus, n_frames));
+        }
+        if (rc == MMW_OK && opt_int(ctx, "MMW_DETECT_TAIL", 1)) {
+            // frames the consumer's CUs have not reached when the producer drains: the same kernel (same ticket counter) on
+            // the producer's CUs, behind it in its queue
+            ctx->stream = ctx->q_drd;
+            ProfScope ps(ctx, "detect_tail");
+            rc = screen(std::min(rd_cus, n_frames));
+        }
+        ctx->stream = main_stream;
+        // join in any case: whatever was enqueued runs to its end (bounded waits) before the context's next work
+        MMW_HIP(hipEventRecord(ctx->det_rd_done, ctx->q_drd));
+        MMW_HIP(hipEventRecord(ctx->det_scr_done, ctx->q_dscr));
+        MMW_HIP(hipStreamWaitEvent(main_stream, ctx->det_rd_done, 0));
+        MMW_HIP(hipStreamWaitEvent(main_stream, ctx->det_scr_done, 0));
+        if (d_clk) {
+            long long h[8] = {0};
+            MMW_HIP(hipStreamSynchronize(main_stream));
+            MMW_HIP(hipMemcpy(h, d_clk, sizeof(h), hipMemcpyDeviceToHost));
+            MMW_HIP(hipFree(d_clk));
+            a.clk = nullptr;
+            std::fprintf(stderr, "detect_screen_sync %dx%d, workgroup 0 of the consumer: %lld frames; clocks per frame: wait %lld load %lld cfar %lld "
+                         "compact %lld argmax %lld\n", S, C, h[7], h[5] / std::max(1LL, h[7]), h[0] / std::max(1LL, h[7]), h[1] / std::max(1LL, h[7]),
+                         h[2] / std::max(1LL, h[7]), h[3] / std::max(1LL, h[7]));
+        }
+        MMW_TRY(rc);
+    } else {
         ProfScope ps(ctx, "detect");
         auto go = [&](auto kern) -> int {
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_screen));
@@ -2008,6 +2134,13 @@ int mmw_widen_f32_f64(mmw_ctx *ctx, const float *d_in, double *d_out, size_t n) 
     const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)ctx->num_cu * 16);
     hipLaunchKernelGGL(k_widen_f32_f64, dim3(grid), dim3(256), 0, ctx->stream, d_in, d_out, n);
     return check_launch("widen_f32_f64");
+}
+
+int mmw_diag_set_option(mmw_ctx *ctx, const char *name, int value) {
+    MMW_REQUIRE(ctx && name && *name, "null argument");
+    if (value == INT_MIN) ctx->opts.erase(name);
+    else ctx->opts[name] = value;
+    return MMW_OK;
 }
 
 int mmw_diag_rd_plan(int S, int C, int float64, int plan[8]) {

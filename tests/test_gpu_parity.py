@@ -1735,6 +1735,119 @@ def test_detect_points_edge_cases_and_pipeline_fallback(monkeypatch):
             np.testing.assert_allclose(pcs[f], pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
 
 
+def test_detect_points_overlapped_schedule(monkeypatch):
+    """The device-synchronised form of mmw_detect_points (range-Doppler producer and screening consumer side by side on
+    disjoint CU sets, frames handed over through counters; the default for large batches of 256 x 128 planes, forced here
+    on a small one): identical to the serial schedule and to the float64 path -- counts, detections, both argmax arrays,
+    and the range-Doppler cube and L1 norms it leaves behind -- for every CU split / tail setting, with the band widened
+    (cells through k_cfar_cell_exact), with frames the screening hands back, and for batches shorter than the grids."""
+    shape, F = (12, 256, 128), 150
+    V, S, C = shape
+    ctx = _lib.Context(0)
+    cfar = CaCFAR2D((4, 4), (2, 2), 1e-5)
+    az, el = list(range(8)), [8, 9, 10, 11]
+    d_in = ctx.alloc(F * V * S * C * 8)
+    _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 9090, 8, 30.0))
+    bad = synth.synth_cube(77, shape).copy()
+    bad[0, 100, 3] = np.nan                                      # frame 5: handed back by the screening
+    d_in.upload(bad, 5 * V * S * C * 8)
+    ctx.set_option("MMW_DETECT_OVERLAP", 0)
+    serial = _detect_points_raw(ctx, d_in, F, shape, cfar, 1024, az, el)
+    ref = _detect_float64_raw(ctx, d_in, F, shape, cfar, 1024, az, el)
+    keep = serial[0] >= 0
+    assert (~keep).sum() == 1 and not keep[5]
+    _same_points(tuple(x[keep] for x in serial[:4]), tuple(x[keep] for x in ref))
+    ctx.set_option("MMW_DETECT_OVERLAP", 1)
+    for scr_cus, tail in ((32, 1), (32, 0), (64, 1), (128, 0)):
+        ctx.set_option("MMW_DETECT_SCR_CUS", scr_cus)
+        ctx.set_option("MMW_DETECT_TAIL", tail)
+        got = _detect_points_raw(ctx, d_in, F, shape, cfar, 1024, az, el)
+        np.testing.assert_array_equal(got[0], serial[0])
+        _same_points(tuple(x[keep] for x in got[:4]), tuple(x[keep] for x in serial[:4]))
+        assert got[4] == serial[4], (got[4], serial[4])
+    # the cube and the norms the producer leaves behind are the serial kernel's
+    d_rd, d_l1, d_rd2, d_l12 = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * V * 4), ctx.alloc(F * V * S * C * 8), ctx.alloc(F * V * 4)
+    d_dets, d_cnt = ctx.alloc(F * 64 * 8), ctx.alloc(F * 4)
+    for ov, rd, l1 in ((1, d_rd, d_l1), (0, d_rd2, d_l12)):
+        ctx.set_option("MMW_DETECT_OVERLAP", ov)
+        _lib.check(ctx.lib.mmw_detect_points(ctx.handle, d_in.ptr, rd.ptr, l1.ptr, None, d_dets.ptr, d_cnt.ptr, None, None, F, V, S, C,
+                                             cfar.kind, 4, 4, 2, 2, float(cfar._scale()), 0, 64, None, 0, 1, None, 0, 0, 64, None))
+    for f in (0, 5, 77, F - 1):
+        np.testing.assert_array_equal(d_rd.download((V, S, C), np.complex64, f * V * S * C * 8).view(np.uint32),
+                                      d_rd2.download((V, S, C), np.complex64, f * V * S * C * 8).view(np.uint32))
+    np.testing.assert_array_equal(d_l1.download((F, V), np.float32), d_l12.download((F, V), np.float32))
+    # wide band: hundreds of cells decided in float64, some frames handed back -- same as the serial schedule's
+    monkeypatch.setenv("MMW_DETECT_BAND_MULT", "50")
+    ctx.set_option("MMW_DETECT_OVERLAP", 0)
+    wide_s = _detect_points_raw(ctx, d_in, F, shape, cfar, 1024, az, el)
+    ctx.set_option("MMW_DETECT_OVERLAP", 1)
+    ctx.set_option("MMW_DETECT_SCR_CUS", 32)
+    ctx.set_option("MMW_DETECT_TAIL", 1)
+    wide_o = _detect_points_raw(ctx, d_in, F, shape, cfar, 1024, az, el)
+    both = (wide_s[0] >= 0) & (wide_o[0] >= 0)                   # (which frames lose the race for the cell list may differ)
+    assert wide_o[4][1] > 100 and both.sum() > F // 2
+    _same_points(tuple(x[both] for x in wide_o[:4]), tuple(x[both] for x in ref))
+    _same_points(tuple(x[both] for x in wide_s[:4]), tuple(x[both] for x in ref))
+    monkeypatch.delenv("MMW_DETECT_BAND_MULT")
+    # batches shorter than either grid
+    for n in (1, 3, 40):
+        got = _detect_points_raw(ctx, d_in, n, shape, cfar, 1024, az, el)
+        np.testing.assert_array_equal(got[0], serial[0][:n])
+        k = got[0] >= 0
+        _same_points(tuple(x[k] for x in got[:4]), tuple(x[:n][k] for x in serial[:4]))
+    print(f"overlapped detection schedule: {int(serial[0][keep].sum())} detections in {F} frames identical across schedules")
+    ctx.close()
+
+
+def test_detect_handoff_timeout_hands_the_frames_back():
+    """The overlapped detection schedule with its producer withheld (test switch): the consumer's bounded wait gives up,
+    every frame gets count -1 (the status of a frame the screening cannot decide), the call returns normally, and
+    FramePipeline runs those frames through the float64 path -- results equal the oracle's; the next call is fine."""
+    from mmwave_radar_processing_amd.batch import FramePipeline
+    shape, F = (12, 256, 128), 24
+    V, S, C = shape
+    ctx = _lib.Context(0)
+    cfar = CaCFAR2D((4, 4), (2, 2), 1e-5)
+    az, el = list(range(8)), [8, 9, 10, 11]
+    cubes = np.stack([synth.synth_cube(4400 + f, shape) for f in range(F)])
+    d_in = ctx.alloc(cubes.nbytes)
+    d_in.upload(cubes)
+    ctx.set_option("MMW_DETECT_OVERLAP", 1)
+    ctx.set_option("MMW_CHAIN_TIMEOUT_MS", 20)
+    ctx.set_option("MMW_DETECT_DIAG_SKIP_RD", 1)
+    import time
+    t0 = time.perf_counter()
+    got = _detect_points_raw(ctx, d_in, F, shape, cfar, 1024, az, el)
+    dt = time.perf_counter() - t0
+    assert np.all(got[0] == -1) and got[4][2] == F and dt < 2.0
+    ctx.set_option("MMW_DETECT_DIAG_SKIP_RD", None)
+    ok = _detect_points_raw(ctx, d_in, F, shape, cfar, 1024, az, el)
+    assert np.all(ok[0] >= 0) and ok[4][2] == 0
+    sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
+    for f in (0, F - 1):
+        _, dets_ref, az_i, el_i = O.point_cloud(cubes[f], sc, az, el)
+        k = int(ok[0][f])
+        np.testing.assert_array_equal(ok[1][f, :k], dets_ref)
+        np.testing.assert_array_equal(ok[2][f, :k], az_i)
+        np.testing.assert_array_equal(ok[3][f, :k], el_i)
+    # the pipeline: frames handed back by the timed-out hand-off take the float64 path
+    cm = make_cm(synth.SYNTH_CFG_256x128x12)
+    pipe = FramePipeline(cm, max_frames=F, shape=shape, cfar=cfar, az_antenna_idxs=az, el_antenna_idxs=el, ctx=ctx)
+    pipe.load(cubes)
+    ctx.set_option("MMW_DETECT_DIAG_SKIP_RD", 1)
+    pcs = pipe.point_clouds()
+    ctx.set_option("MMW_DETECT_DIAG_SKIP_RD", None)
+    assert pipe.screen_stats[2] == F
+    for f in (0, 7, F - 1):
+        pc_ref, dets_ref, az_i, el_i = O.point_cloud(cubes[f], sc, az, el)
+        np.testing.assert_array_equal(pipe.dets[f], dets_ref)
+        np.testing.assert_array_equal(pipe.az_idx[f], az_i)
+        np.testing.assert_array_equal(pipe.el_idx[f], el_i)
+        np.testing.assert_allclose(pcs[f], pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
+    print(f"detection hand-off timeout: {F} frames handed back in {dt * 1e3:.0f} ms and decided by the float64 path")
+    ctx.close()
+
+
 def test_chain_handoff_timeout_is_detected_and_rerun(monkeypatch):
     """The device-synchronised chain with its producer withheld (diagnostic hook): the consumer's bounded spin gives up,
     the next host-synchronising entry point notices, resets the hand-off state and re-runs the call on the event
