@@ -342,8 +342,8 @@ int mmw_diag_chain_plan(mmw_ctx *ctx, int n_frames, int V, int S, int C, int A, 
 
 /* Host logic without a device (planning only; what tests/cpp/host_sanitize.cpp runs under ASan / UBSan):
  * mmw_diag_chain_plan_nodev = mmw_diag_chain_plan for a device of num_cu CUs (raw != 0: mmw_chain3d_raw);
- * mmw_diag_detect_plan: tiling of mmw_detect_points -- plan[0] supported, [1] row tiles per frame, [2] rows per tile,
- *   [3] band rows, [4] band pitch, [5] LDS bytes, [6] compile-time window, [7] rounding-error budget of the range-Doppler
+ * mmw_diag_detect_plan: banding of mmw_detect_points -- plan[0] supported, [1] workgroups per frame (1), [2] plane rows one
+ *   band's loads can carry (band + halo rows), [3] band rows, [4] band pitch, [5] LDS bytes, [6] compile-time window, [7] rounding-error budget of the range-Doppler
  *   kernel for this plane in units of 2^-24 of the plane's L1 norm;
  * mmw_diag_czt_runs: the uniform runs (offset, length, zero-filled) a zoom frequency list of M bins is cut into. */
 int mmw_diag_chain_plan_nodev(int num_cu, int raw, int n_frames, int V, int S, int C, int A, int flags, int plan[8]);

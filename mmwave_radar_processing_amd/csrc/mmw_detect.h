@@ -45,7 +45,6 @@ constexpr int DET_NT = 1024;             // threads of the per-frame (per-tile) 
 constexpr int DET_MAX_ANT = 8;           // antennas per list inside the fused kernels (cells, twiddles and error scales of a
                                          // list live in registers; lists of 9+ antennas take mmw_angle_argmax_exact)
 constexpr int DET_LIST2 = 16;            // first lane of the second list's cells
-constexpr int DET_LINE = 32;             // ints per frame in the done / status arrays
 enum { DST_UNDECIDED = 1, DST_OVERFLOW = 2, DST_DEGENERATE = 4 };
 enum { DCTL_FLAG_FRAMES = 0, DCTL_CELLS = 1, DCTL_FALLBACK = 2, DCTL_ARGMAX = 16, DCTL_EL = 32, DCTL_WORDS = 64 };   // ARGMAX: flagged
                                                     // evaluations of both lists (the refinement list's length), EL: those of the second
@@ -67,9 +66,6 @@ struct DetectArgs {
     int *cells;                // [cell_cap][2] undecided cells: (frame, r * C + c)
     int cell_cap;
     int V, S, C, cap, words, band_rows, band_pitch;   // band buffers: band_rows x band_pitch floats each
-    int tiles, tile_rows;      // row tiles per frame; valid rows (cells under test) per tile
-    int *done, *status;        // [F][DET_LINE] (one 128-byte line per frame: device-scope atomics on neighbouring words of a line
-                               // serialise at one memory channel): tiles finished; DST_* bits of the frame
     int kind, tr, td, gr, gd, n_train, k_rank;
     double scale;
     float k_fft;               // ulps * 2^-24 of the RD kernel that ran
@@ -89,6 +85,14 @@ __device__ __forceinline__ void det_mark(const DetectArgs &a, int i) {
     if (a.clk && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) a.clk[i] = (long long)__builtin_amdgcn_s_memtime();
 }
 // persistent form: phase i of the frame in hand ends now -- clk[i - 1] accumulates its clocks (workgroup 0; clk[6] = last mark)
+// (diagnostics) clocks since the previous mark into clk[slot] (slots 8..15: inside the band loop)
+__device__ __forceinline__ void det_lap(const DetectArgs &a, int slot) {
+    if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long now = (long long)__builtin_amdgcn_s_memtime();
+        a.clk[slot] += now - a.clk[6];
+        a.clk[6] = now;
+    }
+}
 __device__ __forceinline__ void det_mark_acc(const DetectArgs &a, int i) {
     if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long now = (long long)__builtin_amdgcn_s_memtime();
@@ -98,8 +102,8 @@ __device__ __forceinline__ void det_mark_acc(const DetectArgs &a, int i) {
 }
 
 // exclusive prefix of v over the workgroup (thread order), total in *total; ws: 40 ints of LDS
-__device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     int incl = v;
     for (int d = 1; d < 64; d <<= 1) {
         const int t = __shfl_up(incl, d, 64);
@@ -151,6 +155,15 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = max(v, dpp_u32<0x143, 0xc>(v, v));      // row_bcast:31 into rows 2, 3
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {     // the minimum of the wave, in every lane's return value
+    v = min(v, dpp_u32<0xB1, 0xf>(v, v));
+    v = min(v, dpp_u32<0x4E, 0xf>(v, v));
+    v = min(v, dpp_u32<0x124, 0xf>(v, v));
+    v = min(v, dpp_u32<0x128, 0xf>(v, v));
+    v = min(v, dpp_u32<0x142, 0xa>(v, v));
+    v = min(v, dpp_u32<0x143, 0xc>(v, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ float wave_sum_f32(float x) {
     auto f = [](unsigned u) { return __builtin_bit_cast(float, u); };
     auto u = [](float v) { return __builtin_bit_cast(unsigned, v); };
@@ -181,9 +194,12 @@ __device__ __forceinline__ float key_mag(unsigned k) {
 // For the neighbours of the peak of a plane wave the bracket is ~0.1 instead of 2, so a detection is flagged (and read
 // again, whole planes, by the float64 kernels) an order of magnitude less often at the same e_i.  A bin passes if
 // either form of the bound clears its margin; any bin that does not flags the detection.
+// wk (one_bin: A == 64, the lane's only bin is k = lane): W_A^(i lane), i < DET_MAX_ANT, held in registers by the caller for
+// the whole frame -- the table walk (an LDS read and three index instructions per antenna) was a third of an evaluation.
 template <int NMAX>
 __device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const float2 *tw, float2 xl, float l1v, int base, int n,
-                                                   int shift, int32_t *out_idx, const ArgmaxRefine &rf, long slot, int lane, int tag) {
+                                                   int shift, int32_t *out_idx, const ArgmaxRefine &rf, long slot, int lane, int tag,
+                                                   const float2 (&wk)[DET_MAX_ANT], bool one_bin) {
     const int A = a.A;
     float xr[NMAX], xi[NMAX], e[NMAX], be = 0.f, sum_abs = 0.f;
 #pragma unroll
@@ -196,12 +212,17 @@ __device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const fl
     }
     // the bin's sum S_k and the twiddles it used
     auto bin = [&](int k, float2 (&w)[NMAX], float &re, float &im) {
-        int t = 0;
+        if (one_bin) {
 #pragma unroll
-        for (int i = 0; i < NMAX; ++i) {        // W_A^(i k mod A); the table reads are issued before the first use
-            w[i] = tw[t];
-            t += k;
-            if (t >= A) t -= A;
+            for (int i = 0; i < NMAX; ++i) w[i] = wk[i];
+        } else {
+            int t = 0;
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i) {        // W_A^(i k mod A); the table reads are issued before the first use
+                w[i] = tw[t];
+                t += k;
+                if (t >= A) t -= A;
+            }
         }
         re = im = 0.f;
 #pragma unroll
@@ -290,23 +311,23 @@ __device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const fl
 
 __device__ __forceinline__ void detect_argmax_lanes(const DetectArgs &a, const float2 *tw, float2 xl, float l1v, int base, int n,
                                                     int shift, int32_t *out_idx, const ArgmaxRefine &rf, long slot, int lane,
-                                                    int tag) {
-    if (n <= 4) detect_argmax_list<4>(a, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag);
-    else detect_argmax_list<DET_MAX_ANT>(a, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag);
+                                                    int tag, const float2 (&wk)[DET_MAX_ANT], bool one_bin) {
+    if (n <= 4) detect_argmax_list<4>(a, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag, wk, one_bin);
+    else detect_argmax_list<DET_MAX_ANT>(a, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag, wk, one_bin);
 }
 
 // Ordered compaction of the frame's bit mask (bit r * C + c, LDS) into dets / counts, then the angle argmax of every
 // detection.  ws: 96 ints of LDS ([48, 80) = antenna table), tw: W_A^m in LDS.  Ends with every thread past its last
 // use of bits / ws.
 template <bool SYNC = false>
-__device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const unsigned *bits, int *ws, const float2 *tw) {
-    const int tid = threadIdx.x, C = a.C;
+__device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const unsigned *bits, int *ws, const float2 *tw, int tid) {
+    const int C = a.C;
     int base = 0;
     for (int w0 = 0; w0 < a.words; w0 += DET_NT) {
         const int w = w0 + tid;
         unsigned word = w < a.words ? bits[w] : 0u;
         int total;
-        int pos = base + block_excl_scan(__popc(word), ws, &total);
+        int pos = base + block_excl_scan(__popc(word), ws, &total, tid);
         while (word) {
             const int b = __ffs(word) - 1;
             word &= word - 1;
@@ -350,23 +371,36 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
         }
         return v;
     };
-    float2 nxt = fetch(wave);
+    // The cells of the wave's next PD detections travel while it works on this one (each fetch is a cold, strided read --
+    // 2-4 k clocks from the memory side under load, against ~1 k clocks of arithmetic per detection: with one detection of
+    // look-ahead the phase was latency bound, 33 k clocks for ~5 detections per wave).
+    const bool one_bin = a.A == 64;
+    float2 wk[DET_MAX_ANT];
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < DET_MAX_ANT; ++i) {
+            wk[i] = one_bin ? tw[t] : make_float2(0.f, 0.f);
+            t = (t + lane) & 63;
+        }
+    }
+    constexpr int PD = 4;
+    float2 q[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) q[i] = fetch(wave + i * NW);
     for (int det = wave; det < n_det; det += NW) {
-        const float2 xl = nxt;
-        nxt = fetch(det + NW);
+        const float2 xl = q[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PD; ++i) q[i] = q[i + 1];
+        q[PD - 1] = fetch(det + PD * NW);
         const long slot = f * a.cap + det;
-        if (n_az) detect_argmax_lanes(a, tw, xl, l1v, 0, n_az, a.shift_az, a.az_idx, a.rf_az, slot, lane, 0);
-        if (n_el) detect_argmax_lanes(a, tw, xl, l1v, DET_LIST2, n_el, a.shift_el, a.el_idx, a.rf_el, slot, lane, REFINE_SECOND);
+        if (n_az) detect_argmax_lanes(a, tw, xl, l1v, 0, n_az, a.shift_az, a.az_idx, a.rf_az, slot, lane, 0, wk, one_bin);
+        if (n_el) detect_argmax_lanes(a, tw, xl, l1v, DET_LIST2, n_el, a.shift_el, a.el_idx, a.rf_el, slot, lane, REFINE_SECOND, wk, one_bin);
     }
 }
 
-// A tile of a frame: cells under test in rows [r_lo, r_hi), magnitudes of rows [x_lo, x_hi) = [r_lo - hr, r_hi + hr) in LDS
-// (Xs row 0 = plane row x_lo), detection bit of cell (r, c) at mask bit (r - b_lo) * C + c: b_lo = r_lo for one of several
-// tiles (the tile's own mask), 0 when the tile is the whole frame (the mask is the frame's, no shift afterwards).
-struct DetTile {
-    int r_lo, r_hi, x_lo, x_hi, b_lo;
-};
-
+// One band of a frame: cells under test in plane rows [r0, r0 + nb), their magnitudes and the halo rows [r0 - hr, r0 + nb + hr)
+// in the LDS (Xs row 0 = plane row r0 - hr); the detection bit of cell (r, c) is bit r * C + c of the frame mask.
 __device__ __forceinline__ void det_undecided(const DetectArgs &a, long f, int cell, int *ws) {
     const int pos = atomicAdd(a.ctl + DCTL_CELLS, 1);
     if (pos < a.cell_cap) {
@@ -377,13 +411,13 @@ __device__ __forceinline__ void det_undecided(const DetectArgs &a, long f, int c
         ws[45] = 1;
 }
 
-// CFAR decision of every cell of the tile, band by band (run-time window, one cell per thread and pass): column sums
-// over the training / guard rows of the window into Vt / Vg, then the row-wise combination, the band test, detection bits
-// into `bits` and undecided cells into the global list (ws[44] / ws[45] = has undecided cells / list overflow).
-__device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const DetTile &tl, const float *Xs, float *Vt, float *Vg,
-                                              unsigned *bits, int *ws, double Bf) {
-    const int C = a.C, tid = threadIdx.x, lane = tid & 63;
-    const int tr = a.tr, td = a.td, gr = a.gr, gd = a.gd, hr = tr + gr, hd = td + gd;
+// CFAR decision of every cell of the band (run-time window, one cell per thread and pass): column sums over the training /
+// guard rows of the window into Vt / Vg, then the row-wise combination, the band test, detection bits into `bits` and
+// undecided cells into the global list (ws[44] / ws[45] = has undecided cells / list overflow).
+__device__ __forceinline__ void cfar_band_rt(const DetectArgs &a, long f, int r0, int nb, const float *Xs, float *Vt, float *Vg,
+                                             unsigned *bits, int *ws, double Bf, int tid) {
+    const int C = a.C, lane = tid & 63;
+    const int tr = a.tr, td = a.td, gr = a.gr, gd = a.gd, hd = td + gd, hr = tr + gr;
     const float inv_n = (float)(1.0 / (double)a.n_train);
     const double alpha = a.scale, band0 = (1.0 + fabs(alpha)) * Bf;
     // cell i = tid, tid + NT, ... of a band as (row rr, column c) without a division per cell
@@ -391,55 +425,17 @@ __device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const
     const int g_lo = tr, g_hi = tr + 2 * gr;                // guard rows / columns inside the window
     const int Wr = 2 * hr + 1, Wd = 2 * hd + 1;
     const int gc_lo = td, gc_hi = td + 2 * gd;
-    for (int r0 = tl.r_lo; r0 < tl.r_hi; r0 += a.band_rows) {
-        const int nb = min(a.band_rows, tl.r_hi - r0), cells = nb * C;
-        {
-            int rr = rr_t, c = c_t;
-            for (int i = tid; i < cells; i += DET_NT) {
-                const float *col = Xs + (r0 + rr - hr - tl.x_lo) * C + c;
-                float t = 0.f, g = 0.f;
-                for (int dr = 0; dr < g_lo; ++dr) t += col[dr * C];
-                for (int dr = g_lo; dr <= g_hi; ++dr) g += col[dr * C];
-                for (int dr = g_hi + 1; dr < Wr; ++dr) t += col[dr * C];
-                Vt[i] = t;
-                Vg[i] = g;
-                c += dm;
-                rr += dq;
-                if (c >= C) {
-                    c -= C;
-                    ++rr;
-                }
-            }
-        }
-        __syncthreads();
+    const int cells = nb * C;
+    {
         int rr = rr_t, c = c_t;
-        for (int i0 = tid - lane; i0 < cells; i0 += DET_NT) {        // wave-uniform trip count (ballot below)
-            const int i = i0 + lane;
-            bool det = false, unc = false;
-            const int r = r0 + rr;
-            if (i < cells && c >= hd && c < C - hd) {
-                // training cells = training rows of every window column + guard rows of the columns outside the guard
-                const float *pt = Vt + i - hd, *pg = Vg + i - hd;
-                float tot = 0.f;
-                for (int dc = 0; dc < gc_lo; ++dc) tot += pt[dc] + pg[dc];
-                for (int dc = gc_lo; dc <= gc_hi; ++dc) tot += pt[dc];
-                for (int dc = gc_hi + 1; dc < Wd; ++dc) tot += pt[dc] + pg[dc];
-                const double X = (double)Xs[(r - tl.x_lo) * C + c], T = alpha * (double)(tot * inv_n);
-                const double d = X - T, band = band0 + 3.0e-6 * (X + fabs(T));
-                det = d > band;
-                unc = !det && !(d <= -band);
-            }
-            const unsigned long long m = __ballot(det);
-            if (m && lane == 0) {
-                const long b0 = (long)(r0 - tl.b_lo) * C + i0;
-                const int wd = (int)(b0 >> 5), sh = (int)(b0 & 31);
-                const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
-                const unsigned w0 = lo << sh, w1 = (sh ? lo >> (32 - sh) : 0u) | (hi << sh), w2 = sh ? hi >> (32 - sh) : 0u;
-                if (w0) atomicOr(&bits[wd], w0);
-                if (w1) atomicOr(&bits[wd + 1], w1);
-                if (w2) atomicOr(&bits[wd + 2], w2);
-            }
-            if (unc) det_undecided(a, f, r * C + c, ws);
+        for (int i = tid; i < cells; i += DET_NT) {
+            const float *col = Xs + rr * C + c;             // window rows rr .. rr + Wr - 1 of the band buffer
+            float t = 0.f, g = 0.f;
+            for (int dr = 0; dr < g_lo; ++dr) t += col[dr * C];
+            for (int dr = g_lo; dr <= g_hi; ++dr) g += col[dr * C];
+            for (int dr = g_hi + 1; dr < Wr; ++dr) t += col[dr * C];
+            Vt[i] = t;
+            Vg[i] = g;
             c += dm;
             rr += dq;
             if (c >= C) {
@@ -447,276 +443,330 @@ __device__ __forceinline__ void cfar_bands_rt(const DetectArgs &a, long f, const
                 ++rr;
             }
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    int rr = rr_t, c = c_t;
+    for (int i0 = tid - lane; i0 < cells; i0 += DET_NT) {        // wave-uniform trip count (ballot below)
+        const int i = i0 + lane;
+        bool det = false, unc = false;
+        const int r = r0 + rr;
+        if (i < cells && c >= hd && c < C - hd) {
+            // training cells = training rows of every window column + guard rows of the columns outside the guard
+            const float *pt = Vt + i - hd, *pg = Vg + i - hd;
+            float tot = 0.f;
+            for (int dc = 0; dc < gc_lo; ++dc) tot += pt[dc] + pg[dc];
+            for (int dc = gc_lo; dc <= gc_hi; ++dc) tot += pt[dc];
+            for (int dc = gc_hi + 1; dc < Wd; ++dc) tot += pt[dc] + pg[dc];
+            const double X = (double)Xs[(rr + hr) * C + c], T = alpha * (double)(tot * inv_n);
+            const double d = X - T, band = band0 + 3.0e-6 * (X + fabs(T));
+            det = d > band;
+            unc = !det && !(d <= -band);
+        }
+        const unsigned long long m = __ballot(det);
+        if (m && lane == 0) {
+            const long b0 = (long)r0 * C + i0;
+            const int wd = (int)(b0 >> 5), sh = (int)(b0 & 31);
+            const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+            const unsigned w0 = lo << sh, w1 = (sh ? lo >> (32 - sh) : 0u) | (hi << sh), w2 = sh ? hi >> (32 - sh) : 0u;
+            if (w0) atomicOr(&bits[wd], w0);
+            if (w1) atomicOr(&bits[wd + 1], w1);
+            if (w2) atomicOr(&bits[wd + 2], w2);
+        }
+        if (unc) det_undecided(a, f, r * C + c, ws);
+        c += dm;
+        rr += dq;
+        if (c >= C) {
+            c -= C;
+            ++rr;
+        }
     }
 }
 
-// The same with the window a compile-time constant.  The one-cell-per-thread form reads 13 + 21 LDS words per cell and is
-// bound by the LDS pipe (37 k clocks per 256 x 128 plane); here a thread owns FOUR consecutive rows of a column in the
-// first pass (WR + 3 reads for 4 column sums) and FOUR consecutive columns of a row in the second: its WD + 3 column sums
-// of either kind arrive as aligned 16-byte reads (consecutive lanes read consecutive 16 bytes: no bank conflicts; four
-// 4-byte reads at a 16-byte lane stride were 8-way conflicts and slower than the simple form).  Column c of a band row
-// sits at float offset HD + 4 + c of a row of pitch P (a multiple of 4): the read of cell group c0 = 4 g starts at
-// 4 g + 4, and reads past the row ends land in the padding (read, never used).  All sums still add non-negative numbers
-// only (no sliding differences).
+// The same with the window a compile-time constant -- and a pre-screen that leaves almost nothing to sum.
+//
+// Round 3 summed the window of EVERY cell (a thread: four rows of a column, then four columns of a row; ~75 vector
+// instructions per cell, 53 k of a 256 x 128 frame's 112 k clocks -- the phase was bound by vector-instruction issue, not by the
+// LDS).  But a cell can only be a detection, or undecided, if X is not far below its threshold, and every term of the
+// training sum is non-negative, so ANY partial sum bounds the threshold from below:
+//   tot(r, c) = sum over the 2 HD + 1 window columns of Vt[r][c + dc] + (guard rows of the outer columns)
+//             >= (2 HD + 1) * min over the row of Vt[r][.]            Vt[r][c] = training rows of window column c
+// Pass 1 computes Vt only (a thread: four rows of a column, WR + 3 reads) and the row minima (wave reduction + one LDS
+// atomic per wave and row); pass 2 compares each cell with theta_r = alpha / N * (2 HD + 1) * min_r and appends the few
+// that are not CERTAINLY below their threshold to a list (noise cells of the synthetic workload: ~2 %); pass 3 sums the
+// windows of the listed cells only, one per thread (2 HD + 1 reads of Vt + the guard rows of the outer columns out of Xs),
+// and applies the band test.  A cell is dropped by pass 2 only if   X (1 + 3e-6) + band0 <= theta (1 - 4e-6):   theta is a
+// float32 lower bound of the float32 threshold T' the full sum would give (its 21-term float32 sum is >= (1 - 21 * 2^-24)
+// times the exact sum of the same float32 terms >= their 13-term minimum bound; the factor covers that and theta's own three
+// roundings), so d = X - T' <= -(band0 + 3e-6 (X + T')): the very condition under which the full test says "certainly none".
+// alpha <= 0 (a pfa >= 1): no cell is dropped.
 constexpr int det_band_pitch(int C, int hd) { return (C + 2 * hd + 4 + 4 + 3) / 4 * 4; }
 template <int TR, int TD, int GR, int GD>
-__device__ __forceinline__ void cfar_bands_ct(const DetectArgs &a, long f, const DetTile &tl, const float *Xs, float *Vt, float *Vg,
-                                              unsigned *bits, int *ws, double Bf) {
-    constexpr int HR = TR + GR, HD = TD + GD, WR = 2 * HR + 1, WD = 2 * HD + 1, R = 4, OFF = HD + 4, NQ = (WD + R - 1 + 3) / 4;
+__device__ __forceinline__ void cfar_band_ct(const DetectArgs &a, long f, int r0, int nb, int xs_rows, const float *Xs, float *Vt, float *Vg,
+                                             unsigned *bits, int *ws, double Bf, int tid) {
+    constexpr int HR = TR + GR, HD = TD + GD, WR = 2 * HR + 1, WD = 2 * HD + 1, R = 4, OFF = HD + 4;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int C = a.C, tid = threadIdx.x, P = a.band_pitch, cg_n = (C + R - 1) / R;
+    const int C = a.C, P = a.band_pitch, cg_n = (C + R - 1) / R;
     // the test itself in float32: alpha / N and the band are rounded once (and the band widened by 1e-6 for it), the
     // product and the difference add two more roundings of T -- all inside the 3e-6 (X + |T|) term
     const float alpha_n = (float)(a.scale / (double)a.n_train), band0 = (float)((1.0 + fabs(a.scale)) * Bf * 1.000001);
-    for (int r0 = tl.r_lo; r0 < tl.r_hi; r0 += a.band_rows) {
-        const int nb = min(a.band_rows, tl.r_hi - r0);
-        for (int i = tid; i < ((nb + R - 1) / R) * C; i += DET_NT) {
-            const int rg = i / C, c = i - rg * C, top = r0 + R * rg - HR;       // first plane row this thread reads
-            const int last = tl.x_hi - 1 - top;                                 // rows of a ragged last group: re-read, unused
-            const float *col = Xs + (top - tl.x_lo) * C + c;
-            float v[WR + R - 1];
+    int *rowmin = reinterpret_cast<int *>(Vg);              // [64] bit patterns of the row minima of Vt (non-negative floats order as ints)
+    int *cand = rowmin + 64;                                // band cells (rr * C + c) that need their window summed
+    const int cand_cap = a.band_rows * P - 64;              // >= band_rows * C
+    if (tid < 64) rowmin[tid] = 0x7f800000;
+    if (tid == 0) ws[46] = 0;
+    __syncthreads();
+    // ---- pass 1: training-row sums of every window column (a thread: four columns of one row, the 2 TR training rows as 16-byte
+    //      reads), row minima (the two halves of a wave hold a row each when C % 128 == 0: one DPP reduction serves both)
+    const bool vec = (C & 3) == 0, halves_uniform = (cg_n & 31) == 0;
+    for (int i0 = tid & ~63; i0 < nb * cg_n; i0 += DET_NT) {
+        const int i = i0 + (tid & 63);
+        const bool live = i < nb * cg_n;
+        const int ii = live ? i : 0, rr = ii / cg_n, c0 = R * (ii - rr * cg_n);
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int dr = 0; dr < WR + R - 1; ++dr) v[dr] = col[min(dr, last) * C];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                float t = 0.f, g = 0.f;
-#pragma unroll
-                for (int dr = 0; dr < WR; ++dr) {
-                    if (dr >= TR && dr <= TR + 2 * GR) g += v[j + dr];
-                    else t += v[j + dr];
-                }
-                Vt[(R * rg + j) * P + OFF + c] = t;
-                Vg[(R * rg + j) * P + OFF + c] = g;
-            }
+        for (int dr = 0; dr < WR; ++dr) {
+            if (dr >= TR && dr <= TR + 2 * GR) continue;
+            const float *row = Xs + (rr + dr) * C + c0;
+            if (vec) acc += *reinterpret_cast<const f4 *>(row);
+            else acc += f4{row[0], c0 + 1 < C ? row[1] : 0.f, c0 + 2 < C ? row[2] : 0.f, c0 + 3 < C ? row[3] : 0.f};
         }
-        __syncthreads();
-        for (int i = tid; i < nb * cg_n; i += DET_NT) {
-            const int rr = i / cg_n, c0 = R * (i - rr * cg_n), r = r0 + rr;
-            const f4 *pt = reinterpret_cast<const f4 *>(Vt + rr * P + OFF + c0 - HD);       // float offset 4 g + 4: aligned
-            const f4 *pg = reinterpret_cast<const f4 *>(Vg + rr * P + OFF + c0 - HD);
-            f4 qt[NQ], qg[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                qt[q] = pt[q];
-                qg[q] = pg[q];
-            }
-            float x[R];
-            const float *xrow = Xs + (r - tl.x_lo) * C + c0;
-            if ((C & 3) == 0) {                 // one aligned 16-byte read (four 4-byte reads at this lane stride conflict)
-                const f4 q = *reinterpret_cast<const f4 *>(xrow);
-#pragma unroll
-                for (int j = 0; j < R; ++j) x[j] = q[j];
+        if (live) {
+            float *dst = Vt + rr * P + OFF + c0;            // (float offset 4 g + OFF: 8-byte aligned when OFF is even)
+            if constexpr (OFF % 2 == 0) {
+                *reinterpret_cast<float2 *>(dst) = make_float2(acc.x, acc.y);
+                *reinterpret_cast<float2 *>(dst + 2) = make_float2(acc.z, acc.w);
             } else {
-#pragma unroll
-                for (int j = 0; j < R; ++j) x[j] = c0 + j < C ? xrow[j] : 0.f;
-            }
-            unsigned nib = 0;
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const int c = c0 + j;
-                // training cells = training rows of every window column + guard rows of the columns outside the guard
-                float tot = 0.f;
-#pragma unroll
-                for (int dc = 0; dc < WD; ++dc) {
-                    const int e = j + dc;
-                    tot += (dc < TD || dc > TD + 2 * GD) ? qt[e / 4][e % 4] + qg[e / 4][e % 4] : qt[e / 4][e % 4];
-                }
-                if (c >= HD && c < C - HD) {
-                    const float X = x[j], T = alpha_n * tot;
-                    const float d = X - T, band = band0 + 3.0e-6f * (X + fabsf(T));
-                    if (d > band) nib |= 1u << j;
-                    else if (!(d <= -band)) det_undecided(a, f, r * C + c, ws);
-                }
-            }
-            if (nib) {
-                const long b0 = (long)(r - tl.b_lo) * C + c0;
-                const unsigned long long m = (unsigned long long)nib << (b0 & 31);
-                atomicOr(&bits[b0 >> 5], (unsigned)m);
-                if (m >> 32) atomicOr(&bits[(b0 >> 5) + 1], (unsigned)(m >> 32));
+                dst[0] = acc.x;
+                dst[1] = acc.y;
+                dst[2] = acc.z;
+                dst[3] = acc.w;
             }
         }
-        __syncthreads();
+        float m = acc.x;
+        if (c0 + 1 < C) m = fminf(m, acc.y);
+        if (c0 + 2 < C) m = fminf(m, acc.z);
+        if (c0 + 3 < C) m = fminf(m, acc.w);
+        int key = live ? __builtin_bit_cast(int, m) : 0x7f800000;
+        if (key < 0 || key > 0x7f800000) key = 0;           // NaN (a degenerate plane is not screened; belt and braces): no drop
+        if (halves_uniform) {               // (DPP network: a __shfl_xor butterfly is six dependent LDS round trips)
+            unsigned v = (unsigned)key;
+            v = min(v, dpp_u32<0xB1, 0xf>(v, v));
+            v = min(v, dpp_u32<0x4E, 0xf>(v, v));
+            v = min(v, dpp_u32<0x124, 0xf>(v, v));
+            v = min(v, dpp_u32<0x128, 0xf>(v, v));
+            v = min(v, dpp_u32<0x142, 0xa>(v, v));          // row_bcast:15: lanes 31 / 63 hold the minima of lanes 0..31 / 32..63
+            if ((tid & 31) == 31 && live && rr < 64) atomicMin(&rowmin[rr], (int)v);
+        } else if (live && rr < 64)
+            atomicMin(&rowmin[rr], key);
     }
+    __syncthreads();
+    det_lap(a, 11);
+    // ---- pass 2: cells that may reach their threshold
+    for (int i = tid; i < nb * cg_n; i += DET_NT) {
+        const int rr = i / cg_n, c0 = R * (i - rr * cg_n);
+        const float theta = a.scale > 0.0 && rr < 64 ? alpha_n * (float)WD * __builtin_bit_cast(float, rowmin[rr]) * (1.f - 4e-6f) : 0.f;
+        const float *xrow = Xs + (rr + HR) * C + c0;
+        float x[R];
+        if ((C & 3) == 0) {                 // one aligned 16-byte read (four 4-byte reads at this lane stride conflict)
+            const f4 q = *reinterpret_cast<const f4 *>(xrow);
+#pragma unroll
+            for (int j = 0; j < R; ++j) x[j] = q[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) x[j] = c0 + j < C ? xrow[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int c = c0 + j;
+            if (c >= HD && c < C - HD && !(fmaf(x[j], 1.f + 3e-6f, band0) <= theta)) {
+                const int pos = atomicAdd(&ws[46], 1);
+                if (pos < cand_cap) cand[pos] = rr * C + c;
+            }
+        }
+    }
+    __syncthreads();
+    det_lap(a, 12);
+    // ---- pass 3: the listed cells, one per thread
+    const int n_cand = min(ws[46], cand_cap);
+    if (a.clk && blockIdx.x == 0 && threadIdx.x == 0) a.clk[14] += n_cand;
+    for (int i = tid; i < n_cand; i += DET_NT) {
+        const int cell = cand[i], rr = cell / C, c = cell - rr * C, r = r0 + rr;
+        // training cells = training rows of every window column + guard rows of the columns outside the guard
+        const float *pt = Vt + rr * P + OFF + c - HD;
+        float tot = 0.f;
+#pragma unroll
+        for (int dc = 0; dc < WD; ++dc) tot += pt[dc];
+        const float *px = Xs + (rr + TR) * C + c - HD;      // first guard row of the window, first window column
+#pragma unroll
+        for (int dc = 0; dc < WD; ++dc) {
+            if (dc >= TD && dc <= TD + 2 * GD) continue;
+            float g = 0.f;
+#pragma unroll
+            for (int dr = 0; dr <= 2 * GR; ++dr) g += px[dr * C + dc];
+            tot += g;
+        }
+        const float X = Xs[(rr + HR) * C + c], T = alpha_n * tot;
+        const float d = X - T, band = band0 + 3.0e-6f * (X + fabsf(T));
+        if (d > band) atomicOr(&bits[((long)r * C + c) >> 5], 1u << (((long)r * C + c) & 31));
+        else if (!(d <= -band)) det_undecided(a, f, r * C + c, ws);
+    }
+    det_lap(a, 13);
 }
 
-// LDS of k_detect_screen: float32 magnitudes of the tile's rows + halo, two float32 band buffers, the tile's bit mask
-// (the whole frame's when the tile turns out to be the last one), 96 ints, W_A^m table
+// LDS of k_detect_screen: two band buffers of float32 magnitudes (band rows + halo), two float32 column-sum buffers, the frame's
+// bit mask, 96 ints, W_A^m table
 inline size_t detect_tail_lds(int words, int A) { return (((size_t)words * 4 + 15) & ~(size_t)15) + 96 * 4 + (size_t)A * 8; }
-inline size_t detect_screen_lds(int x_rows, int C, int band_rows, int band_pitch, int words, int A) {
-    return (((size_t)x_rows * C * 4 + 15) & ~(size_t)15) + 2 * (((size_t)band_rows * band_pitch * 4 + 15) & ~(size_t)15) +
+inline size_t detect_screen_lds(int xs_rows, int C, int band_rows, int band_pitch, int words, int A) {
+    return 2 * (((size_t)xs_rows * C * 4 + 15) & ~(size_t)15) + 2 * (((size_t)band_rows * band_pitch * 4 + 15) & ~(size_t)15) +
            detect_tail_lds(words, A);
 }
+constexpr int DET_LOADS = 4;        // 16-byte loads a thread has in flight for the next band (two cells each)
 
 // TR, TD, GR, GD >= 0: the window is a compile-time constant (every loop over it unrolls: all of a cell's LDS reads are
 // issued before the first add); -1: taken from the arguments at run time.
+//
+// The frame's plane of antenna 0 STREAMS through the LDS in bands of a.band_rows rows: while the workgroup works on band b
+// (magnitudes in one of two band buffers), the complex cells of band b + 1 -- its rows and the 2 hr halo rows around them,
+// so halo rows are read twice, from cache -- are in flight into registers (at most DET_LOADS 16-byte loads per thread).
+// Round 3 held the whole plane's magnitudes (128 KB for 256 x 128) and loaded it in one exposed phase (18 k of a frame's
+// 112 k clocks), which also left room for 20-row bands only: 640 of the 1024 threads had an item per pass.
+//
 // SYNC: the consumer of the overlapped schedule -- a persistent grid on its own CU set; a workgroup draws a frame ticket,
 // waits for the producer to publish the frame's V planes, and screens it while the producer is still transforming later
-// frames on the other CUs (one tile per frame: planes whose magnitudes fit the LDS).  A wait that times out (the two
-// launches did not run side by side) raises the abort word: the frame in hand and every ticket still to be drawn get
-// counts[f] = -1, i.e. they are handed back to the caller's float64 path like any other frame the screening cannot decide.
+// frames on the other CUs.  A wait that times out (the two launches did not run side by side) raises the abort word: the
+// frame in hand and every ticket still to be drawn get counts[f] = -1, i.e. they are handed back to the caller's float64
+// path like any other frame the screening cannot decide.
 template <int TR, int TD, int GR, int GD, bool SYNC>
-__device__ __forceinline__ void detect_screen_frame(const DetectArgs &a, const long f, const int t, char *smem) {
+__device__ __forceinline__ void detect_screen_frame(const DetectArgs &a, const long f, char *smem) {
     constexpr bool CT = TR >= 0;
-    const int S = a.S, C = a.C, tid = threadIdx.x;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    int tid_ = threadIdx.x;
+    // (persistent form: re-derived behind an opaque asm every frame, else hipcc hoists every frame-invariant index and
+    //  address out of the frame loop and spills them around it)
+    if constexpr (SYNC) asm volatile("" : "+v"(tid_));
+    const int S = a.S, C = a.C, tid = tid_;
     const int hr = CT ? TR + GR : a.tr + a.gr, hd = CT ? TD + GD : a.td + a.gd;
     const bool window_fits = S > 2 * hr && C > 2 * hd;
-    DetTile tl;
-    tl.r_lo = window_fits ? hr + t * a.tile_rows : 0;
-    tl.r_hi = window_fits ? min(tl.r_lo + a.tile_rows, S - hr) : 0;
-    tl.x_lo = window_fits ? tl.r_lo - hr : 0;
-    tl.x_hi = window_fits ? tl.r_hi + hr : S;                   // (no valid cell: one tile that only writes the magnitudes)
-    tl.b_lo = a.tiles == 1 ? 0 : tl.r_lo;
-    const int x_rows_max = a.tile_rows + 2 * hr;
-    float *Xs = reinterpret_cast<float *>(smem);
-    size_t off = ((size_t)(window_fits ? x_rows_max : 0) * C * 4 + 15) & ~(size_t)15;
+    const int xs_rows = a.band_rows + 2 * hr;
+    const size_t xs_bytes = ((size_t)xs_rows * C * 4 + 15) & ~(size_t)15;
     const size_t band_bytes = ((size_t)a.band_rows * a.band_pitch * 4 + 15) & ~(size_t)15;
-    float *Vt = reinterpret_cast<float *>(smem + off);      // column sums over the training rows of the window
-    float *Vg = reinterpret_cast<float *>(smem + off + band_bytes);      // ... over its guard rows
-    off += 2 * band_bytes;
-    unsigned *bits = reinterpret_cast<unsigned *>(smem + off);     // a.words words: tile mask now, frame mask in the last tile
+    float *Xs0 = reinterpret_cast<float *>(smem);
+    float *Vt = reinterpret_cast<float *>(smem + 2 * xs_bytes);         // column sums over the training rows of the window
+    float *Vg = reinterpret_cast<float *>(smem + 2 * xs_bytes + band_bytes);      // ... over its guard rows
+    size_t off = 2 * xs_bytes + 2 * band_bytes;
+    unsigned *bits = reinterpret_cast<unsigned *>(smem + off);          // a.words words: the frame's detection mask
     off += ((size_t)a.words * 4 + 15) & ~(size_t)15;
-    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, 46 ticket, 47 abort, [48, 80) antennas
+    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, [48, 80) antennas
     float2 *tw = reinterpret_cast<float2 *>(smem + off + 96 * 4);
     if constexpr (SYNC) det_mark_acc(a, 0); else det_mark(a, 0);
     if (tid < 2) ws[44 + tid] = 0;
-    const int t_cells = (tl.r_hi - tl.r_lo) * C, t_words = (t_cells + 31) / 32;
-    for (int w = tid; w < (a.tiles == 1 ? a.words : t_words + 1) && w < a.words; w += DET_NT) bits[w] = 0u;
+    for (int w = tid; w < a.words; w += DET_NT) bits[w] = 0u;
 
     // error band scale; 1.0001 covers the float32 summation of the L1 norm itself
     const float l1v = SYNC ? __hip_atomic_load(a.l1 + f * a.V, MMW_RLX_AGENT) : a.l1[f * a.V];
     const double Bf = (double)a.k_fft * (double)l1v * 1.0001;
     // NaN / inf samples in antenna 0, or a scale at which float32 squares over- / underflow (an all-zero plane is fine)
     const bool degenerate = !(l1v == 0.f || (l1v >= 1e-10f && l1v <= 1e18f));
-    // |RD| of antenna 0 in float32: rows [x_lo, x_hi) into the LDS, and out to mag32 the rows this tile owns
-    {
-        const int own_lo = t == 0 ? 0 : tl.r_lo, own_hi = t == a.tiles - 1 ? S : tl.r_hi;
-        const long n_plane = (long)S * C;
-        const float2 *p = a.rd + f * a.V * n_plane + (long)tl.x_lo * C;
-        float *mg = a.mag32 ? a.mag32 + f * n_plane + (long)tl.x_lo * C : nullptr;
-        const int n = (tl.x_hi - tl.x_lo) * C, keep_lo = (own_lo - tl.x_lo) * C, keep_hi = (own_hi - tl.x_lo) * C;
-        if ((C & 1) == 0) {
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            const f4 *p4 = reinterpret_cast<const f4 *>(p);
-            [[maybe_unused]] const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p), 0, n * 8, 0x00020000);
-            constexpr int U = 16;                           // loads in flight per thread (a whole 256 x 128 plane in one trip)
-            for (int i0 = tid; i0 < n / 2; i0 += DET_NT * U) {
-                f4 v[U];
+    const long n_plane = (long)S * C;
+    const float2 *p = a.rd + f * a.V * n_plane;             // antenna 0
+    float *mg = a.mag32 ? a.mag32 + f * n_plane : nullptr;
+    [[maybe_unused]] const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p), 0, (int)(n_plane * 8), 0x00020000);
+    // The cells of plane rows [row_lo, row_hi) -- one contiguous run of the plane -- as 16-byte loads of two consecutive cells,
+    // DET_LOADS per thread, UNCONDITIONAL and clamped (a guarded load is followed by its own s_waitcnt, and so is a load under a
+    // run-time branch: the first version chose between 16- and 8-byte loads by the parity of C and every load waited for the one
+    // before).  A run that starts at an odd cell is 8-byte aligned only: fine for global / buffer loads (dword alignment).
+    auto issue = [&](int row_lo, int row_hi, f4 (&v)[DET_LOADS]) {
+        const long base = (long)row_lo * C;
+        const int n2 = ((row_hi - row_lo) * C + 1) / 2;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = min(i0 + u * DET_NT, n / 2 - 1);
-                    if constexpr (SYNC) v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(prs, (unsigned)i * 16u, 0, 16));
-                    else v[u] = p4[i];
-                }
+        for (int u = 0; u < DET_LOADS; ++u) {
+            const int i = min(tid + u * DET_NT, n2 - 1);
+            if constexpr (SYNC) v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(prs, (unsigned)((base + 2 * i) * 8), 0, 16));
+            else v[u] = *reinterpret_cast<const f4 *>(p + base + 2 * i);
+        }
+    };
+    // |.| of the loaded cells into band buffer Xs (row 0 = plane row row_lo), and out to mag32 for the rows [own_lo, own_hi)
+    auto land = [&](int row_lo, int row_hi, int own_lo, int own_hi, const f4 (&v)[DET_LOADS], float *Xs) {
+        const long base = (long)row_lo * C;
+        const int n = (row_hi - row_lo) * C;
+        const int keep_lo = (own_lo - row_lo) * C, keep_hi = (own_hi - row_lo) * C;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * DET_NT;
-                    if (i < n / 2) {
-                        const float m0 = __fsqrt_rn(fmaf(v[u].x, v[u].x, v[u].y * v[u].y));
-                        const float m1 = __fsqrt_rn(fmaf(v[u].z, v[u].z, v[u].w * v[u].w));
-                        if (window_fits) *reinterpret_cast<float2 *>(Xs + 2 * i) = make_float2(m0, m1);
-                        if (mg && 2 * i >= keep_lo && 2 * i < keep_hi) *reinterpret_cast<float2 *>(mg + 2 * i) = make_float2(m0, m1);
-                    }
+        for (int u = 0; u < DET_LOADS; ++u) {
+            const int i = tid + u * DET_NT;
+            if (2 * i < n) {
+                const float m0 = __fsqrt_rn(fmaf(v[u].x, v[u].x, v[u].y * v[u].y));
+                const float m1 = __fsqrt_rn(fmaf(v[u].z, v[u].z, v[u].w * v[u].w));
+                const bool two = 2 * i + 1 < n;
+                if (Xs) {
+                    if (two) *reinterpret_cast<float2 *>(Xs + 2 * i) = make_float2(m0, m1);
+                    else Xs[2 * i] = m0;
                 }
-            }
-        } else {
-            [[maybe_unused]] const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(p), 0, n * 8, 0x00020000);
-            for (int i = tid; i < n; i += DET_NT) {
-                float2 v;
-                if constexpr (SYNC) v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(prs, (unsigned)i * 8u, 0, 16));
-                else v = p[i];
-                const float m = __fsqrt_rn(fmaf(v.x, v.x, v.y * v.y));
-                if (window_fits) Xs[i] = m;
-                if (mg && i >= keep_lo && i < keep_hi) mg[i] = m;
+                if (mg) {
+                    if (2 * i >= keep_lo && 2 * i < keep_hi) mg[base + 2 * i] = m0;
+                    if (two && 2 * i + 1 >= keep_lo && 2 * i + 1 < keep_hi) mg[base + 2 * i + 1] = m1;
+                }
             }
         }
-    }
-    __syncthreads();
-    if constexpr (SYNC) det_mark_acc(a, 1); else det_mark(a, 1);
-
-    if (!degenerate && window_fits) {
-        if constexpr (CT) cfar_bands_ct<TR, TD, GR, GD>(a, f, tl, Xs, Vt, Vg, bits, ws, Bf);
-        else cfar_bands_rt(a, f, tl, Xs, Vt, Vg, bits, ws, Bf);
+    };
+    if (!window_fits) {
+        // no cell under test (the reference returns no detections: ca_cfar.py:99-102); the magnitudes are still wanted
+        if (mg) {
+            const int rows_per = max(1, 2 * DET_LOADS * DET_NT / C);
+            for (int r0 = 0; r0 < S; r0 += rows_per) {
+                f4 v[DET_LOADS];
+                const int r1 = min(S, r0 + rows_per);
+                issue(r0, r1, v);
+                land(r0, r1, r0, r1, v, nullptr);
+            }
+        }
+    } else {
+        const int r_lo = hr, r_hi = S - hr;                 // rows with cells under test
+        f4 v[DET_LOADS];
+        issue(r_lo - hr, min(r_lo + a.band_rows, r_hi) + hr, v);
+        int b = 0;
+        for (int r0 = r_lo; r0 < r_hi; r0 += a.band_rows, ++b) {
+            const int nb = min(a.band_rows, r_hi - r0);
+            float *Xs = Xs0 + (b & 1) * (xs_bytes / 4);
+            if constexpr (SYNC) det_lap(a, 8);
+            land(r0 - hr, r0 + nb + hr, r0 == r_lo ? 0 : r0, r0 + nb == r_hi ? S : r0 + nb, v, Xs);
+            if constexpr (SYNC) det_lap(a, 9);
+            const int r1 = r0 + a.band_rows;
+            if (r1 < r_hi) issue(r1 - hr, min(r1 + a.band_rows, r_hi) + hr, v);        // the next band travels during this one
+            __syncthreads();            // band b's magnitudes are in; everybody is past band b - 1 (Vt / Vg, the other Xs)
+            if constexpr (SYNC) det_lap(a, 10);
+            if (!degenerate) {
+                if constexpr (CT) cfar_band_ct<TR, TD, GR, GD>(a, f, r0, nb, nb + 2 * hr, Xs, Vt, Vg, bits, ws, Bf, tid);
+                else cfar_band_rt(a, f, r0, nb, Xs, Vt, Vg, bits, ws, Bf, tid);
+            }
+        }
     }
     __syncthreads();
     if constexpr (SYNC) det_mark_acc(a, 2); else det_mark(a, 2);
-    if (a.tiles == 1) {
-        // one tile = the whole frame: its mask is complete in the LDS, nothing to tell other workgroups.  Only a frame with
-        // undecided cells leaves its mask in global memory, for k_cfar_cell_exact to complete (whoever finishes it reads the
-        // mask in a later launch).
-        const int st = (degenerate ? DST_DEGENERATE : 0) | (ws[45] ? DST_OVERFLOW : 0) | (ws[44] ? DST_UNDECIDED : 0);
-        if (st & (DST_DEGENERATE | DST_OVERFLOW)) {             // the float64 path decides this frame
-            if (tid == 0) {
-                a.counts[f] = -1;
-                atomicAdd(a.ctl + DCTL_FALLBACK, 1);
-            }
-            return;
-        }
-        if (st & DST_UNDECIDED) {                               // compaction after k_cfar_cell_exact
-            for (int w = tid; w < a.words; w += DET_NT) a.bits[f * a.words + w] = bits[w];
-            if (tid == 0) a.flag_frames[atomicAdd(a.ctl + DCTL_FLAG_FRAMES, 1)] = (int)f;
-            return;
-        }
-        detect_ant_table(a, ws + 48);
-        for (int i = tid; i < a.A; i += DET_NT) tw[i] = a.twA[i];
-        __syncthreads();
-        detect_finish<SYNC>(a, f, bits, ws, tw);
-        if constexpr (SYNC) det_mark_acc(a, 4); else det_mark(a, 4);
-        return;
-    }
-    // the tile's bits into the frame's mask (zeroed before the launch); tiles need not start on a word boundary
-    {
-        const long b0 = (long)tl.r_lo * C;
-        const int sh = (int)(b0 & 31);
-        unsigned *dst = a.bits + f * a.words + (b0 >> 5);
-        for (int w = tid; w < t_words; w += DET_NT) {
-            const unsigned v = bits[w];
-            if (v) {
-                atomicOr(dst + w, v << sh);
-                if (sh && (v >> (32 - sh))) atomicOr(dst + w + 1, v >> (32 - sh));
-            }
-        }
-    }
-    if (tid == 0) {
-        const int st = (degenerate ? DST_DEGENERATE : 0) | (ws[45] ? DST_OVERFLOW : 0) | (ws[44] ? DST_UNDECIDED : 0);
-        if (st) atomicOr(a.status + f * DET_LINE, st);
-    }
-    // The last tile of the frame to get here finishes the frame.  Everything tiles tell each other travels in device-scope
-    // atomics (mask words, status, ticket) and is read back with coherent loads.  The atomics above return nothing, and
-    // s_barrier does NOT wait for them (gfx950 has back-off barriers: no implicit s_waitcnt in front of it): every wave
-    // drains its own vector-memory counter before the barrier, so all of the tile's atomics have been performed at the L2
-    // before thread 0 draws the ticket.  No __threadfence(): on this multi-XCD part a device-scope release writes the
-    // XCD's whole L2 back -- with one per tile the kernel took 4.3 ms instead of 0.3.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) ws[46] = atomicAdd(a.done + f * DET_LINE, 1);
-    __syncthreads();
-    if (ws[46] != a.tiles - 1) return;
-    const int st = __atomic_load_n(a.status + f * DET_LINE, __ATOMIC_RELAXED);
-    if (st & (DST_DEGENERATE | DST_OVERFLOW)) {                 // the float64 path decides this frame
+    // Only a frame with undecided cells leaves its mask in global memory, for k_cfar_cell_exact to complete.
+    const int st = (degenerate ? DST_DEGENERATE : 0) | (ws[45] ? DST_OVERFLOW : 0) | (ws[44] ? DST_UNDECIDED : 0);
+    if (st & (DST_DEGENERATE | DST_OVERFLOW)) {             // the float64 path decides this frame
         if (tid == 0) {
             a.counts[f] = -1;
             atomicAdd(a.ctl + DCTL_FALLBACK, 1);
         }
         return;
     }
-    if (st & DST_UNDECIDED) {                                   // compaction after k_cfar_cell_exact
+    if (st & DST_UNDECIDED) {                               // compaction after k_cfar_cell_exact
+        for (int w = tid; w < a.words; w += DET_NT) a.bits[f * a.words + w] = bits[w];
         if (tid == 0) a.flag_frames[atomicAdd(a.ctl + DCTL_FLAG_FRAMES, 1)] = (int)f;
         return;
     }
     detect_ant_table(a, ws + 48);
     for (int i = tid; i < a.A; i += DET_NT) tw[i] = a.twA[i];
-    for (int w = tid; w < a.words; w += DET_NT) bits[w] = __atomic_load_n(a.bits + f * a.words + w, __ATOMIC_RELAXED);
     __syncthreads();
-    detect_finish(a, f, bits, ws, tw);
-    det_mark(a, 4);
+    detect_finish<SYNC>(a, f, bits, ws, tw, tid);
+    if constexpr (SYNC) det_mark_acc(a, 4); else det_mark(a, 4);
 }
 
 template <int TR, int TD, int GR, int GD>
 __global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const long f = blockIdx.x / a.tiles;
-    detect_screen_frame<TR, TD, GR, GD, false>(a, f, blockIdx.x - (int)f * a.tiles, smem);
+    detect_screen_frame<TR, TD, GR, GD, false>(a, blockIdx.x, smem);
 }
 
 template <int TR, int TD, int GR, int GD>
@@ -749,7 +799,7 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen_sync(DetectArgs a) {
         const int f = __builtin_amdgcn_readfirstlane(sy[0]);
         const bool dead = __builtin_amdgcn_readfirstlane(sy[1]) != 0;
         if (f >= a.n_frames) return;
-        if (!dead) detect_screen_frame<TR, TD, GR, GD, true>(a, f, 0, smem);
+        if (!dead) detect_screen_frame<TR, TD, GR, GD, true>(a, f, smem);
         __syncthreads();
     }
 }
@@ -768,7 +818,7 @@ __global__ __launch_bounds__(DET_NT) void k_detect_finish(DetectArgs a) {
         const long f = a.flag_frames[e];
         for (int w = threadIdx.x; w < a.words; w += DET_NT) bits[w] = a.bits[f * a.words + w];
         __syncthreads();
-        detect_finish(a, f, bits, ws, tw);
+        detect_finish(a, f, bits, ws, tw, threadIdx.x);
         __syncthreads();
     }
 }

@@ -1751,7 +1751,7 @@ static int ensure_det_queues(mmw_ctx *ctx, int rd_cus) {
 namespace {
 struct DetectPlan {
     bool ok, ct_window;
-    int band_rows, band_pitch, words, tiles, tile_rows;
+    int band_rows, band_pitch, words;
     size_t lds_screen, lds_cell, lds_finish;
 };
 DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, int n_az, int n_el, int A = 64) {
@@ -1767,43 +1767,17 @@ DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, i
     // compile-time windows (the launch below knows the same two): four rows / columns per thread, padded band rows
     p.ct_window = (tr == 4 && td == 4 && gr == 2 && gd == 2) || (tr == 5 && td == 5 && gr == 3 && gd == 2);
     p.band_pitch = p.ct_window ? det_band_pitch(C, hd) : C;
-    const int valid = S - 2 * hr;
-    if (valid <= 0 || C <= 2 * hd) {            // window larger than the plane: no cell under test, magnitudes only
-        p.tiles = 1;
-        p.tile_rows = 0;
-        p.band_rows = p.ct_window ? 4 : 1;
-        p.lds_screen = detect_screen_lds(0, C, p.band_rows, p.band_pitch, p.words, A);
-        p.ok = p.lds_screen <= 160 * 1024;
-        return p;
-    }
-    // Row tiles: as few as fit the LDS (one for every shipped shape; MMW_DETECT_TILES / MMW_DETECT_BAND: experiments).
-    const int band_want = std::max(1, tune_int("MMW_DETECT_BAND", 20)), force_tiles = tune_int("MMW_DETECT_TILES", 0);
-    const size_t lds_goal = 160 * 1024;
-    size_t best_lds = ~(size_t)0;
-    for (int tiles = 1; tiles <= 64 && tiles <= valid; ++tiles) {
-        int rows = (valid + tiles - 1) / tiles;
-        if (p.ct_window) rows = (rows + 3) / 4 * 4;
-        int band = std::min(band_want, rows);
-        if (p.ct_window) band = std::max(4, band / 4 * 4);
-        const size_t lds = detect_screen_lds(rows + 2 * hr, C, band, p.band_pitch, p.words, A);
-        const bool take = force_tiles > 0 ? tiles == force_tiles : (lds <= lds_goal || (tiles == 64 || tiles == valid));
-        if (lds < best_lds && (force_tiles <= 0 || tiles <= force_tiles)) {
-            best_lds = lds;
-            p.tile_rows = rows;
-            p.band_rows = band;
-            p.lds_screen = lds;
-        }
-        if (take && lds <= 160 * 1024) {
-            p.tile_rows = rows;
-            p.band_rows = band;
-            p.lds_screen = lds;
-            break;
-        }
-    }
-    if (p.lds_screen == 0 || p.lds_screen > 160 * 1024) return p;
-    p.tiles = (valid + p.tile_rows - 1) / p.tile_rows;
-    p.lds_screen += (size_t)std::max(0, tune_int("MMW_DETECT_LDS_PAD", 0));     // experiment: fewer workgroups per CU
-    p.ok = true;
+    const int unit = p.ct_window ? 4 : 1;
+    // Band of rows under test: its cells and the 2 hr halo rows travel as at most DET_LOADS loads per thread (two cells per
+    // load); 32 rows x 128 columns give each of the 1024 threads one item in either CFAR pass.
+    const long cap_cells = (long)DET_LOADS * DET_NT * 2;
+    int band = std::min<long>(std::max(1, tune_int("MMW_DETECT_BAND", 32)), cap_cells / C - 2 * hr);
+    band = std::min(band, std::max(unit, S - 2 * hr));
+    band = band / unit * unit;
+    if (band < unit) return p;                              // rows too long for the band loads
+    p.band_rows = band;
+    p.lds_screen = detect_screen_lds(band + 2 * hr, C, band, p.band_pitch, p.words, A);
+    p.ok = p.lds_screen <= 160 * 1024 - 64;
     return p;
 }
 int fill_det_ant(const int *h_ant, int n_ant, int V, int A, DetAnt *out, AntList *full) {
@@ -1860,7 +1834,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     const int cell_cap = std::max(4096, 16 * n_frames);
     const int list_cap = n_frames * cap;
     const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));
-    const size_t b_ctl = up((DCTL_WORDS + 2 * (size_t)n_frames * DET_LINE) * sizeof(int)), b_ff = up((size_t)n_frames * sizeof(int)),
+    const size_t b_ctl = up(DCTL_WORDS * sizeof(int)), b_ff = up((size_t)n_frames * sizeof(int)),
                  b_cells = up((size_t)cell_cap * 2 * sizeof(int)), b_bits = up((size_t)n_frames * plan.words * sizeof(unsigned));
     const int list_cap2 = (int)std::min<long>(2L * list_cap, 0x7fffffffL);      // both lists flag into one
     const int n_split2 = std::min(list_cap2, n_split);
@@ -1873,7 +1847,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     const int want_overlap = opt_int(ctx, "MMW_DETECT_OVERLAP", -1);
     int scr_cus = opt_int(ctx, "MMW_DETECT_SCR_CUS", 32);
     if (scr_cus < 1 || scr_cus >= ctx->num_cu) scr_cus = 32;
-    const bool overlap = fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && plan.tiles == 1 && want_overlap != 0 &&
+    const bool overlap = fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && want_overlap != 0 &&
                          (want_overlap == 1 || n_frames >= 2 * ctx->num_cu) &&
                          ensure_det_queues(ctx, ctx->num_cu - scr_cus) == MMW_OK;
     const size_t b_sync = overlap ? up((CTL_CNT + (size_t)n_frames) * sizeof(unsigned)) : 0;
@@ -1889,11 +1863,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     char *next = base + b_ctl + b_ff + b_cells + b_bits + b_sync;
     int *list = (n_az || n_el) ? (int *)next : nullptr;
     cplx<double> *part = (n_az || n_el) ? (cplx<double> *)(next + b_list2) : nullptr;
-    a.done = a.ctl + DCTL_WORDS;
-    a.status = a.done + (size_t)n_frames * DET_LINE;
-    MMW_HIP(hipMemsetAsync(a.ctl, 0, (DCTL_WORDS + 2 * (size_t)n_frames * DET_LINE) * sizeof(int), ctx->stream));      // counters, done, status
-    if (plan.tiles > 1)
-        MMW_HIP(hipMemsetAsync(a.bits, 0, (size_t)n_frames * plan.words * sizeof(unsigned), ctx->stream));       // tiles OR their bits in
+    MMW_HIP(hipMemsetAsync(a.ctl, 0, DCTL_WORDS * sizeof(int), ctx->stream));      // counters
     if (overlap) MMW_HIP(hipMemsetAsync(sync_words, 0, b_sync, ctx->stream));
     // range-Doppler of every antenna (float32) with the planes' L1 norms
     if (!overlap) MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
@@ -1914,8 +1884,6 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.words = plan.words;
     a.band_rows = plan.band_rows;
     a.band_pitch = plan.band_pitch;
-    a.tiles = plan.tiles;
-    a.tile_rows = plan.tile_rows;
     a.kind = cfar_kind;
     a.tr = train_r;
     a.td = train_d;
@@ -1962,8 +1930,8 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         };
         long long *d_clk = nullptr;
         if (opt_int(ctx, "MMW_PHASE_CLOCKS", 0)) {              // diagnostics: phase clocks of one consumer workgroup, summed over its frames
-            MMW_HIP(hipMalloc((void **)&d_clk, 8 * sizeof(long long)));
-            MMW_HIP(hipMemsetAsync(d_clk, 0, 8 * sizeof(long long), main_stream));
+            MMW_HIP(hipMalloc((void **)&d_clk, 16 * sizeof(long long)));
+            MMW_HIP(hipMemsetAsync(d_clk, 0, 16 * sizeof(long long), main_stream));
             MMW_HIP(hipStreamSynchronize(main_stream));
             a.clk = d_clk;
         }
@@ -1992,7 +1960,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         MMW_HIP(hipStreamWaitEvent(main_stream, ctx->det_rd_done, 0));
         MMW_HIP(hipStreamWaitEvent(main_stream, ctx->det_scr_done, 0));
         if (d_clk) {
-            long long h[8] = {0};
+            long long h[16] = {0};
             MMW_HIP(hipStreamSynchronize(main_stream));
             MMW_HIP(hipMemcpy(h, d_clk, sizeof(h), hipMemcpyDeviceToHost));
             MMW_HIP(hipFree(d_clk));
@@ -2000,6 +1968,9 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
             std::fprintf(stderr, "detect_screen_sync %dx%d, workgroup 0 of the consumer: %lld frames; clocks per frame: wait %lld load %lld cfar %lld "
                          "compact %lld argmax %lld\n", S, C, h[7], h[5] / std::max(1LL, h[7]), h[0] / std::max(1LL, h[7]), h[1] / std::max(1LL, h[7]),
                          h[2] / std::max(1LL, h[7]), h[3] / std::max(1LL, h[7]));
+            const long long nf = std::max(1LL, h[7]);
+            std::fprintf(stderr, "  band loop per frame: top %lld land(+load wait) %lld issue+barrier %lld pass1 %lld pass2 %lld pass3 %lld; candidates %lld\n",
+                         h[8] / nf, h[9] / nf, h[10] / nf, h[11] / nf, h[12] / nf, h[13] / nf, h[14] / nf);
         }
         MMW_TRY(rc);
     } else {
@@ -2013,7 +1984,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
                 MMW_HIP(hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
                 DetectArgs b = a;
                 b.clk = d;
-                hipLaunchKernelGGL(kern, dim3((unsigned)n_frames * plan.tiles), dim3(DET_NT), plan.lds_screen, ctx->stream, b);
+                hipLaunchKernelGGL(kern, dim3((unsigned)n_frames), dim3(DET_NT), plan.lds_screen, ctx->stream, b);
                 MMW_HIP(hipStreamSynchronize(ctx->stream));
                 MMW_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
                 MMW_HIP(hipFree(d));
@@ -2021,7 +1992,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
                              h[2] - h[1], h[3] - h[2], h[4] - h[3]);
                 return MMW_OK;
             }
-            hipLaunchKernelGGL(kern, dim3((unsigned)n_frames * plan.tiles), dim3(DET_NT), plan.lds_screen, ctx->stream, a);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_frames), dim3(DET_NT), plan.lds_screen, ctx->stream, a);
             return MMW_OK;
         };
         // the windows of the reference's own configs as compile-time constants: (4,4)/(2,2) (tests/verify_processors.py:165,
@@ -2208,8 +2179,8 @@ int mmw_diag_detect_plan(int S, int C, int cfar_kind, int train_r, int train_d, 
                 "bad argument");
     const DetectPlan p = detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el, A);
     plan[0] = p.ok;
-    plan[1] = p.tiles;
-    plan[2] = p.tile_rows;
+    plan[1] = p.ok ? 1 : 0;                                 // workgroups per frame (row tiles went with the band-streamed kernel)
+    plan[2] = p.ok ? (int)(((long)DET_LOADS * DET_NT * 2) / C) : 0;      // rows one band's loads can carry (band + halo)
     plan[3] = p.band_rows;
     plan[4] = p.band_pitch;
     plan[5] = (int)p.lds_screen;
