@@ -108,6 +108,8 @@ struct mmw_ctx {
     hipStream_t q_drd = nullptr, q_dscr = nullptr;
     int q_drd_cus = 0;
     hipEvent_t det_begin = nullptr, det_rd_done = nullptr, det_scr_done = nullptr;
+    hipStream_t q_side = nullptr;               // refinement of the flagged argmax evaluations, beside the exact CFAR cells
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     bool det_unavailable = false;
     hipStream_t q_copy = nullptr;               // copy queue of the host-streaming API (mmw_memcpy_async), created lazily
     std::vector<void *> host_owned;             // mmw_host_alloc'ed pinned blocks still alive

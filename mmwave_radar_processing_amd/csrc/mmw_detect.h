@@ -45,6 +45,7 @@ constexpr int DET_NT = 1024;             // threads of the per-frame (per-tile) 
 constexpr int DET_MAX_ANT = 8;           // antennas per list inside the fused kernels (cells, twiddles and error scales of a
                                          // list live in registers; lists of 9+ antennas take mmw_angle_argmax_exact)
 constexpr int DET_LIST2 = 16;            // first lane of the second list's cells
+constexpr int DET_SPEC = 32;             // undecided cells a frame may carry speculatively (more: the frame is handed back)
 enum { DST_UNDECIDED = 1, DST_OVERFLOW = 2, DST_DEGENERATE = 4 };
 enum { DCTL_FLAG_FRAMES = 0, DCTL_CELLS = 1, DCTL_FALLBACK = 2, DCTL_ARGMAX = 16, DCTL_EL = 32, DCTL_WORDS = 64 };   // ARGMAX: flagged
                                                     // evaluations of both lists (the refinement list's length), EL: those of the second
@@ -60,9 +61,9 @@ struct DetectArgs {
     float *mag32;              // optional [F][S][C]: |RD| of antenna 0
     int32_t *dets, *counts;    // [F][cap][2], [F]
     int32_t *az_idx, *el_idx;  // [F][cap] each (nullptr with an empty list)
-    unsigned *bits;            // [F][words] detection bit masks of the frames with undecided cells
     int *ctl;                  // DCTL_* counters
     int *flag_frames;          // [F] frames with undecided cells
+    int *spec;                 // [F][2 * DET_SPEC + 1]: n, then per undecided cell its index r * C + c and (from k_cfar_cell_exact) the decision
     int *cells;                // [cell_cap][2] undecided cells: (frame, r * C + c)
     int cell_cap;
     int V, S, C, cap, words, band_rows, band_pitch;   // band buffers: band_rows x band_pitch floats each
@@ -319,8 +320,13 @@ __device__ __forceinline__ void detect_argmax_lanes(const DetectArgs &a, const f
 // Ordered compaction of the frame's bit mask (bit r * C + c, LDS) into dets / counts, then the angle argmax of every
 // detection.  ws: 96 ints of LDS ([48, 80) = antenna table), tw: W_A^m in LDS.  Ends with every thread past its last
 // use of bits / ws.
+// n_spec undecided cells (ws[80 ..]) ride along SPECULATIVELY: their angle indices are computed as if they were detections, in
+// the slots cap - 1 - u at the end of the frame's list, so that nothing but k_detect_insert (a list insertion) depends on
+// k_cfar_cell_exact's decision -- in round 3 the flagged frames' compaction and argmax, and the refinement of THEIR flagged
+// evaluations, waited for it: three latency chains one after the other behind the screening kernel.
+// false: the certain detections and the speculative slots do not fit cap together (the caller hands the frame back).
 template <bool SYNC = false>
-__device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const unsigned *bits, int *ws, const float2 *tw, int tid) {
+__device__ __forceinline__ bool detect_finish(const DetectArgs &a, long f, const unsigned *bits, int *ws, const float2 *tw, int tid, int n_spec) {
     const int C = a.C;
     int base = 0;
     for (int w0 = 0; w0 < a.words; w0 += DET_NT) {
@@ -340,12 +346,24 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
         }
         base += total;
     }
+    if (n_spec > 0 && base + n_spec > a.cap) return false;
     if (tid == 0) a.counts[f] = base;           // exact even beyond cap (MMW_ERR_TRUNCATED is the caller's check)
+    if (tid < n_spec) {
+        const int cell = ws[80 + tid], r = cell / C;
+        const long slot = f * a.cap + (a.cap - 1 - tid);
+        a.dets[slot * 2] = r;
+        a.dets[slot * 2 + 1] = cell - r * C;
+        a.spec[f * (2 * DET_SPEC + 1) + 1 + tid] = cell;
+        a.spec[f * (2 * DET_SPEC + 1) + 1 + DET_SPEC + tid] = 0;       // the decision (k_cfar_cell_exact)
+    }
+    if (tid == 0 && n_spec > 0) a.spec[f * (2 * DET_SPEC + 1)] = n_spec;
     if constexpr (SYNC) det_mark_acc(a, 3); else det_mark(a, 3);
     const int n_az = a.az.n, n_el = a.el.n;
-    if (n_az == 0 && n_el == 0) return;
+    if (n_az == 0 && n_el == 0) return true;
     __syncthreads();                            // the workgroup's own dets are visible to all of its waves
-    const int n_det = base < a.cap ? base : a.cap;
+    const int n_cert = base < a.cap ? base : a.cap, n_det = n_cert + n_spec;
+    // evaluation j of the frame -> its slot: the certain detections in order, then the speculative ones from the end
+    auto slot_of = [&](int j) { return j < n_cert ? j : a.cap - 1 - (j - n_cert); };
     const int lane = tid & 63, wave = tid >> 6;
     const int *tab = ws + 48;
     // lanes [0, n_az): azimuth list, lanes [DET_LIST2, DET_LIST2 + n_el): elevation list
@@ -363,7 +381,7 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
     auto fetch = [&](int det) {
         float2 v = make_float2(0.f, 0.f);
         if (det < n_det && mine) {
-            const long slot = f * a.cap + det;
+            const long slot = f * a.cap + slot_of(det);
             const long cell = (long)a.dets[slot * 2] * C + a.dets[slot * 2 + 1];
             if constexpr (SYNC)
                 v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(frame_rs, (unsigned)((ant * a.S * C + cell) * 8), 0, 16));
@@ -393,19 +411,28 @@ __device__ __forceinline__ void detect_finish(const DetectArgs &a, long f, const
 #pragma unroll
         for (int i = 0; i + 1 < PD; ++i) q[i] = q[i + 1];
         q[PD - 1] = fetch(det + PD * NW);
-        const long slot = f * a.cap + det;
+        const long slot = f * a.cap + slot_of(det);
         if (n_az) detect_argmax_lanes(a, tw, xl, l1v, 0, n_az, a.shift_az, a.az_idx, a.rf_az, slot, lane, 0, wk, one_bin);
         if (n_el) detect_argmax_lanes(a, tw, xl, l1v, DET_LIST2, n_el, a.shift_el, a.el_idx, a.rf_el, slot, lane, REFINE_SECOND, wk, one_bin);
     }
+    return true;
 }
 
 // One band of a frame: cells under test in plane rows [r0, r0 + nb), their magnitudes and the halo rows [r0 - hr, r0 + nb + hr)
 // in the LDS (Xs row 0 = plane row r0 - hr); the detection bit of cell (r, c) is bit r * C + c of the frame mask.
+// An undecided cell: slot u of the frame (LDS list ws[80 + u], ws[47] = count) and an entry of the global work list of
+// k_cfar_cell_exact; too many for either: ws[45], the frame is handed back.
 __device__ __forceinline__ void det_undecided(const DetectArgs &a, long f, int cell, int *ws) {
+    const int u = atomicAdd(&ws[47], 1);
+    if (u >= DET_SPEC) {
+        ws[45] = 1;
+        return;
+    }
+    ws[80 + u] = cell;
     const int pos = atomicAdd(a.ctl + DCTL_CELLS, 1);
     if (pos < a.cell_cap) {
         a.cells[2 * pos] = (int)f;
-        a.cells[2 * pos + 1] = cell;
+        a.cells[2 * pos + 1] = cell | (u << 24);
         ws[44] = 1;
     } else
         ws[45] = 1;
@@ -615,7 +642,7 @@ __device__ __forceinline__ void cfar_band_ct(const DetectArgs &a, long f, int r0
 
 // LDS of k_detect_screen: two band buffers of float32 magnitudes (band rows + halo), two float32 column-sum buffers, the frame's
 // bit mask, 96 ints, W_A^m table
-inline size_t detect_tail_lds(int words, int A) { return (((size_t)words * 4 + 15) & ~(size_t)15) + 96 * 4 + (size_t)A * 8; }
+inline size_t detect_tail_lds(int words, int A) { return (((size_t)words * 4 + 15) & ~(size_t)15) + 128 * 4 + (size_t)A * 8; }
 inline size_t detect_screen_lds(int xs_rows, int C, int band_rows, int band_pitch, int words, int A) {
     return 2 * (((size_t)xs_rows * C * 4 + 15) & ~(size_t)15) + 2 * (((size_t)band_rows * band_pitch * 4 + 15) & ~(size_t)15) +
            detect_tail_lds(words, A);
@@ -656,10 +683,10 @@ __device__ __forceinline__ void detect_screen_frame(const DetectArgs &a, const l
     size_t off = 2 * xs_bytes + 2 * band_bytes;
     unsigned *bits = reinterpret_cast<unsigned *>(smem + off);          // a.words words: the frame's detection mask
     off += ((size_t)a.words * 4 + 15) & ~(size_t)15;
-    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, [48, 80) antennas
-    float2 *tw = reinterpret_cast<float2 *>(smem + off + 96 * 4);
+    int *ws = reinterpret_cast<int *>(smem + off);          // [0, 40) scan, 44 undecided, 45 overflow, 46 candidates, 47 undecided cells, [48, 80) antennas, [80, 112) those cells
+    float2 *tw = reinterpret_cast<float2 *>(smem + off + 128 * 4);
     if constexpr (SYNC) det_mark_acc(a, 0); else det_mark(a, 0);
-    if (tid < 2) ws[44 + tid] = 0;
+    if (tid < 4) ws[44 + tid] = 0;
     for (int w = tid; w < a.words; w += DET_NT) bits[w] = 0u;
 
     // error band scale; 1.0001 covers the float32 summation of the L1 norm itself
@@ -742,24 +769,22 @@ __device__ __forceinline__ void detect_screen_frame(const DetectArgs &a, const l
     }
     __syncthreads();
     if constexpr (SYNC) det_mark_acc(a, 2); else det_mark(a, 2);
-    // Only a frame with undecided cells leaves its mask in global memory, for k_cfar_cell_exact to complete.
     const int st = (degenerate ? DST_DEGENERATE : 0) | (ws[45] ? DST_OVERFLOW : 0) | (ws[44] ? DST_UNDECIDED : 0);
-    if (st & (DST_DEGENERATE | DST_OVERFLOW)) {             // the float64 path decides this frame
+    const int n_spec = min(ws[47], DET_SPEC);
+    bool ok = !(st & (DST_DEGENERATE | DST_OVERFLOW));
+    if (ok) {
+        detect_ant_table(a, ws + 48);
+        for (int i = tid; i < a.A; i += DET_NT) tw[i] = a.twA[i];
+        __syncthreads();
+        ok = detect_finish<SYNC>(a, f, bits, ws, tw, tid, n_spec);
+    }
+    if (!ok) {                                              // the float64 path decides this frame
         if (tid == 0) {
             a.counts[f] = -1;
             atomicAdd(a.ctl + DCTL_FALLBACK, 1);
         }
-        return;
-    }
-    if (st & DST_UNDECIDED) {                               // compaction after k_cfar_cell_exact
-        for (int w = tid; w < a.words; w += DET_NT) a.bits[f * a.words + w] = bits[w];
-        if (tid == 0) a.flag_frames[atomicAdd(a.ctl + DCTL_FLAG_FRAMES, 1)] = (int)f;
-        return;
-    }
-    detect_ant_table(a, ws + 48);
-    for (int i = tid; i < a.A; i += DET_NT) tw[i] = a.twA[i];
-    __syncthreads();
-    detect_finish<SYNC>(a, f, bits, ws, tw, tid);
+    } else if (n_spec > 0 && tid == 0)                      // k_detect_insert adds the cells k_cfar_cell_exact decides positive
+        a.flag_frames[atomicAdd(a.ctl + DCTL_FLAG_FRAMES, 1)] = (int)f;
     if constexpr (SYNC) det_mark_acc(a, 4); else det_mark(a, 4);
 }
 
@@ -804,21 +829,88 @@ __global__ __launch_bounds__(DET_NT) void k_detect_screen_sync(DetectArgs a) {
     }
 }
 
-// Frames whose masks were completed by k_cfar_cell_exact: compaction + argmax.  Persistent over the flagged list.
-__global__ __launch_bounds__(DET_NT) void k_detect_finish(DetectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned *bits = reinterpret_cast<unsigned *>(smem);
-    const size_t off = ((size_t)a.words * 4 + 15) & ~(size_t)15;
-    int *ws = reinterpret_cast<int *>(smem + off);
-    float2 *tw = reinterpret_cast<float2 *>(smem + off + 96 * 4);
-    const int n = a.ctl[DCTL_FLAG_FRAMES];
-    detect_ant_table(a, ws + 48);
-    for (int i = threadIdx.x; i < a.A; i += DET_NT) tw[i] = a.twA[i];
-    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+// Frames with undecided cells, once k_cfar_cell_exact has decided them (and the refinement kernels are done with the speculative
+// slots): every cell decided positive is INSERTED into the frame's list -- detections, azimuth and elevation indices -- at its
+// place in np.where order.  One 256-thread workgroup per flagged frame
+// (insertions shift the tail up).
+constexpr int INS_NT = 256;
+__global__ __launch_bounds__(INS_NT) void k_detect_insert(DetectArgs a) {
+    __shared__ int pk[DET_SPEC], paz[DET_SPEC], pel[DET_SPEC], ppos[DET_SPEC], n_pos;
+    const int n_flagged = a.ctl[DCTL_FLAG_FRAMES], tid = threadIdx.x, C = a.C;
+    for (int e = blockIdx.x; e < n_flagged; e += gridDim.x) {
         const long f = a.flag_frames[e];
-        for (int w = threadIdx.x; w < a.words; w += DET_NT) bits[w] = a.bits[f * a.words + w];
+        const int *sp = a.spec + f * (2 * DET_SPEC + 1);
+        const int n_spec = sp[0], n = a.counts[f];
+        const int n_list = n < a.cap ? n : a.cap;           // (n + n_spec <= cap was checked when the slots were taken)
+        if (tid == 0) {                                     // the positive cells, sorted by cell index (at most DET_SPEC: insertion sort)
+            int m = 0;
+            for (int u = 0; u < n_spec; ++u)
+                if (sp[1 + DET_SPEC + u]) {
+                    const int key = sp[1 + u];
+                    const long slot = f * a.cap + (a.cap - 1 - u);
+                    const int az = a.az_idx ? a.az_idx[slot] : 0, el = a.el_idx ? a.el_idx[slot] : 0;
+                    int q = m++;
+                    while (q > 0 && pk[q - 1] > key) {
+                        pk[q] = pk[q - 1];
+                        paz[q] = paz[q - 1];
+                        pel[q] = pel[q - 1];
+                        --q;
+                    }
+                    pk[q] = key;
+                    paz[q] = az;
+                    pel[q] = el;
+                }
+            n_pos = m;
+        }
         __syncthreads();
-        detect_finish(a, f, bits, ws, tw, threadIdx.x);
+        const int m = n_pos;
+        if (m > 0 && n >= 0) {
+            if (tid < m) {                                  // certain detections in front of positive cell tid (the list is sorted)
+                int lo = 0, hi = n_list;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const long slot = f * a.cap + mid;
+                    if (a.dets[slot * 2] * C + a.dets[slot * 2 + 1] < pk[tid]) lo = mid + 1;
+                    else hi = mid;
+                }
+                ppos[tid] = lo;
+            }
+            __syncthreads();
+            // the certain entries move up by the number of positive cells in front of them: chunks of INS_NT from the END of the
+            // list, every entry of a chunk in a register before any is written (an entry lands inside its own chunk or above)
+            for (int hi = n_list; hi > 0; hi -= INS_NT) {
+                const int i = hi - INS_NT + tid;
+                int r = 0, c = 0, az = 0, el = 0;
+                if (i >= 0) {
+                    const long slot = f * a.cap + i;
+                    r = a.dets[slot * 2];
+                    c = a.dets[slot * 2 + 1];
+                    if (a.az_idx) az = a.az_idx[slot];
+                    if (a.el_idx) el = a.el_idx[slot];
+                }
+                __syncthreads();
+                if (i >= 0) {
+                    int up = 0;
+                    for (int q = 0; q < m; ++q) up += pk[q] < r * C + c ? 1 : 0;
+                    if (up) {
+                        const long slot = f * a.cap + i + up;
+                        a.dets[slot * 2] = r;
+                        a.dets[slot * 2 + 1] = c;
+                        if (a.az_idx) a.az_idx[slot] = az;
+                        if (a.el_idx) a.el_idx[slot] = el;
+                    }
+                }
+                __syncthreads();
+            }
+            if (tid < m) {
+                const long slot = f * a.cap + ppos[tid] + tid;
+                a.dets[slot * 2] = pk[tid] / C;
+                a.dets[slot * 2 + 1] = pk[tid] - (pk[tid] / C) * C;
+                if (a.az_idx) a.az_idx[slot] = paz[tid];
+                if (a.el_idx) a.el_idx[slot] = pel[tid];
+            }
+            if (tid == 0) a.counts[f] = n + m;
+        }
         __syncthreads();
     }
 }
@@ -832,8 +924,8 @@ struct CellExactArgs {
     const float2 *cubes;       // [F][V][S][C] input
     const int *cells, *n_cells;
     int cell_cap;
-    unsigned *bits;
-    int V, S, C, words;
+    int *spec;                 // [F][2 * DET_SPEC + 1] (DetectArgs::spec): the decision of cell u of frame f goes to [1 + DET_SPEC + u]
+    int V, S, C;
     int kind, tr, td, gr, gd, n_train, k_rank;
     double scale;
     const double *ws, *wc;
@@ -884,7 +976,7 @@ __global__ __launch_bounds__(CE_NT) void k_cfar_cell_exact(CellExactArgs a) {
     };
     for (int e = blockIdx.x; e < n; e += gridDim.x) {
         const long f = a.cells[2 * e];
-        const int cell = a.cells[2 * e + 1], r = cell / C, c = cell - r * C;
+        const int packed = a.cells[2 * e + 1], cell = packed & 0xffffff, u = packed >> 24, r = cell / C, c = cell - r * C;
         const float2 *x = a.cubes + f * a.V * S * C;                 // antenna 0
         for (int ch0 = 0; ch0 < C; ch0 += CE_NT / CE_SG) {           // (uniform trip count: shuffles inside)
             const int ch = ch0 + tid / CE_SG;
@@ -983,7 +1075,7 @@ __global__ __launch_bounds__(CE_NT) void k_cfar_cell_exact(CellExactArgs a) {
             }
         }
         __syncthreads();
-        if (tid == 0 && X > a.scale * res[0]) atomicOr(a.bits + f * a.words + (cell >> 5), 1u << (cell & 31));
+        if (tid == 0) a.spec[f * (2 * DET_SPEC + 1) + 1 + DET_SPEC + u] = X > a.scale * res[0] ? 1 : 0;
         __syncthreads();
         mark(4);
     }

@@ -197,7 +197,11 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
         (void)hipStreamDestroy(ctx->q_drd);
         (void)hipStreamDestroy(ctx->q_dscr);
     }
-    for (hipEvent_t e : {ctx->det_begin, ctx->det_rd_done, ctx->det_scr_done})
+    if (ctx->q_side) {
+        (void)hipStreamSynchronize(ctx->q_side);
+        (void)hipStreamDestroy(ctx->q_side);
+    }
+    for (hipEvent_t e : {ctx->det_begin, ctx->det_rd_done, ctx->det_scr_done, ctx->side_fork, ctx->side_join})
         if (e) (void)hipEventDestroy(e);
     if (ctx->q_copy) {
         (void)hipStreamSynchronize(ctx->q_copy);
@@ -1752,7 +1756,7 @@ namespace {
 struct DetectPlan {
     bool ok, ct_window;
     int band_rows, band_pitch, words;
-    size_t lds_screen, lds_cell, lds_finish;
+    size_t lds_screen, lds_cell;
 };
 DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, int n_az, int n_el, int A = 64) {
     DetectPlan p{};
@@ -1762,8 +1766,7 @@ DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, i
     if (tune_int("MMW_NO_DETECT_SCREEN", 0)) return p;
     p.words = (int)((n + 31) / 32);
     p.lds_cell = cell_exact_lds(S, C, 2 * hr + 1, 2 * hd + 1);
-    p.lds_finish = detect_tail_lds(p.words, A);
-    if (p.lds_cell > 64 * 1024 || p.lds_finish > 64 * 1024) return p;
+    if (p.lds_cell > 64 * 1024) return p;
     // compile-time windows (the launch below knows the same two): four rows / columns per thread, padded band rows
     p.ct_window = (tr == 4 && td == 4 && gr == 2 && gd == 2) || (tr == 5 && td == 5 && gr == 3 && gd == 2);
     p.band_pitch = p.ct_window ? det_band_pitch(C, hd) : C;
@@ -1835,20 +1838,22 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     const int list_cap = n_frames * cap;
     const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));
     const size_t b_ctl = up(DCTL_WORDS * sizeof(int)), b_ff = up((size_t)n_frames * sizeof(int)),
-                 b_cells = up((size_t)cell_cap * 2 * sizeof(int)), b_bits = up((size_t)n_frames * plan.words * sizeof(unsigned));
+                 b_cells = up((size_t)cell_cap * 2 * sizeof(int)), b_bits = up((size_t)n_frames * (2 * DET_SPEC + 1) * sizeof(int));      // (speculative slots of the frames with undecided cells)
     const int list_cap2 = (int)std::min<long>(2L * list_cap, 0x7fffffffL);      // both lists flag into one
     const int n_split2 = std::min(list_cap2, n_split);
     const size_t b_list2 = up((size_t)std::max(list_cap2, 1) * sizeof(int));
     const size_t b_part = up((size_t)n_split2 * REFINE_PARTS * std::max(std::max(n_az, n_el), 1) * sizeof(cplx<double>));
-    // Overlapped schedule (256 x 128 planes, one tile per frame, batches that fill the chip): the range-Doppler producer and the
-    // screening consumer run side by side on disjoint CU sets, frames handed over through counters in device memory.
-    // MMW_DETECT_OVERLAP=0 / 1 forces the serial / overlapped schedule; MMW_DETECT_SCR_CUS = CUs of the consumer (a multiple
-    // of 32); MMW_DETECT_TAIL=0: no second consumer launch behind the producer on the producer's CUs.
+    // Overlapped schedule (256 x 128 planes): the range-Doppler producer and the screening consumer run side by side on disjoint
+    // CU sets, frames handed over through counters in device memory.  Built, tested and MEASURED: it does not
+    // beat the serial schedule on this chip -- the range-Doppler kernel keeps its 5.2 TB/s down to ~224 CUs only, and the
+    // screening of 1250 frames needs ~70 CU-milliseconds, i.e. 2.2 ms on the 32 CUs that leaves -- so it is an option, not the
+    // default: MMW_DETECT_OVERLAP=1 selects it; MMW_DETECT_SCR_CUS = CUs of the consumer (a multiple of 32);
+    // MMW_DETECT_TAIL=0: no second consumer launch behind the producer on the producer's CUs.
     const int want_overlap = opt_int(ctx, "MMW_DETECT_OVERLAP", -1);
     int scr_cus = opt_int(ctx, "MMW_DETECT_SCR_CUS", 32);
     if (scr_cus < 1 || scr_cus >= ctx->num_cu) scr_cus = 32;
-    const bool overlap = fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && want_overlap != 0 &&
-                         (want_overlap == 1 || n_frames >= 2 * ctx->num_cu) &&
+    const bool overlap = fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0) &&
+                         want_overlap == 1 &&
                          ensure_det_queues(ctx, ctx->num_cu - scr_cus) == MMW_OK;
     const size_t b_sync = overlap ? up((CTL_CNT + (size_t)n_frames) * sizeof(unsigned)) : 0;
     size_t total = b_ctl + b_ff + b_cells + b_bits + b_sync;
@@ -1858,7 +1863,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.ctl = (int *)base;
     a.flag_frames = (int *)(base + b_ctl);
     a.cells = (int *)(base + b_ctl + b_ff);
-    a.bits = (unsigned *)(base + b_ctl + b_ff + b_cells);
+    a.spec = (int *)(base + b_ctl + b_ff + b_cells);
     unsigned *sync_words = (unsigned *)(base + b_ctl + b_ff + b_cells + b_bits);      // tickets, abort word | planes published per frame
     char *next = base + b_ctl + b_ff + b_cells + b_bits + b_sync;
     int *list = (n_az || n_el) ? (int *)next : nullptr;
@@ -2002,6 +2007,50 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         else MMW_TRY(go(k_detect_screen<-1, -1, -1, -1>));
         MMW_TRY(check_launch("detect_screen"));
     }
+    // Behind the screening: the exact decision of the undecided cells (context stream) and the float64 refinement of the flagged
+    // argmax evaluations (side stream) run SIDE BY SIDE -- neither needs the other: the frames with undecided cells carry them in
+    // speculative slots --, then k_detect_insert puts the cells decided positive into their lists.
+    const bool refine = cap > 0 && (n_az || n_el);
+    hipStream_t main_stream = ctx->stream;
+    if (refine) {
+        if (!ctx->q_side) {
+            MMW_HIP(hipStreamCreateWithFlags(&ctx->q_side, hipStreamNonBlocking));
+            MMW_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+            MMW_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+        }
+        MMW_HIP(hipEventRecord(ctx->side_fork, main_stream));
+        MMW_HIP(hipStreamWaitEvent(ctx->q_side, ctx->side_fork, 0));
+        ctx->stream = ctx->q_side;
+        int rc;
+        {
+            ProfScope ps(ctx, "argmax_refine");
+            RefineArgs ra{};
+            rc = fill_refine_args(ctx, &ra, S, C, A);
+            ra.cubes = (const float2 *)d_cubes;
+            ra.dets = d_dets;
+            ra.n_flag = a.ctl + DCTL_ARGMAX;
+            ra.list = list;
+            ra.list_cap = list_cap2;
+            ra.out_idx = d_az_idx;
+            ra.out_idx2 = d_el_idx;
+            ra.V = V;
+            ra.cap = cap;
+            ra.ants = az_full;
+            ra.ants2 = el_full;
+            ra.shift = shift_az;
+            ra.shift2 = shift_el;
+            ra.partial = part;
+            ra.n_split = n_split2;
+            ra.parts = refine_parts(n_frames);
+            if (rc == MMW_OK) rc = launch_argmax_refine(ctx, ra);
+        }
+        ctx->stream = main_stream;
+        MMW_HIP(hipEventRecord(ctx->side_join, ctx->q_side));      // (joined below in any case)
+        if (rc != MMW_OK) {
+            MMW_HIP(hipStreamWaitEvent(main_stream, ctx->side_join, 0));
+            return rc;
+        }
+    }
     {
         ProfScope ps(ctx, "detect_exact");
         CellExactArgs ce{};
@@ -2009,11 +2058,10 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         ce.cells = a.cells;
         ce.n_cells = a.ctl + DCTL_CELLS;
         ce.cell_cap = cell_cap;
-        ce.bits = a.bits;
+        ce.spec = a.spec;
         ce.V = V;
         ce.S = S;
         ce.C = C;
-        ce.words = plan.words;
         ce.kind = cfar_kind;
         ce.tr = train_r;
         ce.td = train_d;
@@ -2041,31 +2089,11 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
             std::fprintf(stderr, "cfar_cell_exact clocks: tables %lld range sums %lld doppler sums %lld decision %lld\n", h[1] - h[0], h[2] - h[1],
                          h[3] - h[2], h[4] - h[3]);
         }
-        MMW_TRY(check_launch("cfar_cell_exact"));
-        hipLaunchKernelGGL(k_detect_finish, dim3(std::min(n_frames, ctx->num_cu)), dim3(DET_NT), plan.lds_finish, ctx->stream, a);
-        MMW_TRY(check_launch("detect_finish"));
-    }
-    if (cap > 0 && (n_az || n_el)) {
-        ProfScope ps(ctx, "argmax_refine");
-        RefineArgs ra{};
-        MMW_TRY(fill_refine_args(ctx, &ra, S, C, A));
-        ra.cubes = (const float2 *)d_cubes;
-        ra.dets = d_dets;
-        ra.n_flag = a.ctl + DCTL_ARGMAX;
-        ra.list = list;
-        ra.list_cap = list_cap2;
-        ra.out_idx = d_az_idx;
-        ra.out_idx2 = d_el_idx;
-        ra.V = V;
-        ra.cap = cap;
-        ra.ants = az_full;
-        ra.ants2 = el_full;
-        ra.shift = shift_az;
-        ra.shift2 = shift_el;
-        ra.partial = part;
-        ra.n_split = n_split2;
-        ra.parts = refine_parts(n_frames);
-        MMW_TRY(launch_argmax_refine(ctx, ra));
+        const int rc = check_launch("cfar_cell_exact");
+        if (refine) MMW_HIP(hipStreamWaitEvent(main_stream, ctx->side_join, 0));
+        MMW_TRY(rc);
+        hipLaunchKernelGGL(k_detect_insert, dim3(std::min(n_frames, 4 * ctx->num_cu)), dim3(INS_NT), 0, ctx->stream, a);
+        MMW_TRY(check_launch("detect_insert"));
     }
     if (h_stats) {
         int h[DCTL_WORDS];

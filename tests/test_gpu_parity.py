@@ -1723,9 +1723,8 @@ def test_detect_points_edge_cases_and_pipeline_fallback(monkeypatch):
     monkeypatch.setenv("MMW_DETECT_BAND_MULT", "100000000")
     pipe.load(finite)
     pcs = pipe.point_clouds()
-    # (the zero frame has a zero band: it is decided; the others race for the undecided-cell list -- those that get all of
-    #  their cells in are decided cell by cell in float64, the rest are handed back)
-    assert pipe.screen_stats[2] >= 1 and pipe.screen_stats[1] > 4096
+    # (the zero frame has a zero band: it is decided; a frame with more undecided cells than it can carry is handed back)
+    assert pipe.screen_stats[2] >= 1 and pipe.screen_stats[1] >= 32
     for f in range(6):
         pc_ref, dets_ref, az_i, el_i = O.point_cloud(finite[f], sc, az, el, num_train=(4, 4), num_guard=(2, 2), pfa=1e-3)
         np.testing.assert_array_equal(pipe.dets[f], dets_ref)
