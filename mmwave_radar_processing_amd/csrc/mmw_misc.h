@@ -337,6 +337,8 @@ struct ArgmaxRefine {
     int *list;              // f * cap + det of the flagged detections
     int list_cap;
     float k_fft, k_ang;     // error-bound constants (see below)
+    int *flagpos;           // optional [F][cap]: 1 + list position of a flagged detection (the dense refinement finds a frame's
+    int dense_cap;          // flagged detections through it: mmw_cells64.h); positions from dense_cap on are not recorded
 };
 
 // One wave per detection: gather rd[f][ant[i]][r][v], lane k evaluates angle bins k, k+64, ... of the
@@ -516,6 +518,7 @@ __global__ __launch_bounds__(256) void k_angle_argmax(const float2 *rd, const in
             if (flag) {
                 const int pos = atomicAdd(rf.n_flag, 1);
                 if (pos < rf.list_cap) rf.list[pos] = f * cap + det;
+                if (rf.flagpos && pos < rf.dense_cap) rf.flagpos[(long)f * cap + det] = pos + 1;
             }
         }
     }
@@ -594,7 +597,13 @@ struct RefineArgs {
     cplx<double> *partial;      // [n_split][parts][max(ants.n, ants2.n)]
     int n_split;
     int parts;                  // slices a plane sum is cut into (<= REFINE_PARTS): few when many detections are expected
+    int dense_min, dense_cap;   // dense_min > 0: with *n_flag >= dense_min the first dense_cap entries belong to k_cells64
+                                // (mmw_cells64.h) and these kernels take only what lies beyond them
 };
+// the entries [lo, n) of the flagged list the direct kernels own
+__device__ __forceinline__ int refine_first(const RefineArgs &a, int n) {
+    return a.dense_min > 0 && n >= a.dense_min ? (a.dense_cap < n ? a.dense_cap : n) : 0;
+}
 
 // Per flagged detection the factor of cell (s, c) splits into a range part and a Doppler part,
 //   w_s(s) W_S^(r s)  *  w_c(c) W_C^(kd c),
@@ -716,15 +725,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     __shared__ cplx<double> red[4][REFINE_NA];
     int n = *a.n_flag;
     if (n > a.list_cap) n = a.list_cap;
+    const int first = refine_first(a, n);
     if (n > a.n_split) n = a.n_split;
-    if ((int)blockIdx.y >= n) return;
+    if (first + (int)blockIdx.y >= n) return;
     const int part = blockIdx.x, tid = threadIdx.x;
     const RefineTabs t = refine_tabs(a, smem, tid);
     const long plane_cells = (long)a.S * a.C;
     const long per = ((plane_cells + a.parts - 1) / a.parts + 255) / 256 * 256;
     const long lo = (long)part * per, hi = lo + per < plane_cells ? lo + per : plane_cells;
     const int stride = refine_stride(a);
-    for (int e = blockIdx.y; e < n; e += gridDim.y) {
+    for (int e = first + blockIdx.y; e < n; e += gridDim.y) {
         const RefineEntry q = refine_entry(a, e);
         refine_phases(a, t, q.r, q.kd, tid, 256);
         const int *al = t.ant + (q.which ? MAX_ANT : 0);
@@ -740,10 +750,11 @@ __global__ __launch_bounds__(256) void k_argmax_refine_finish(RefineArgs a) {
     __shared__ cplx<double> X[4][MAX_ANT];
     int n = *a.n_flag;
     if (n > a.list_cap) n = a.list_cap;
+    const int first = refine_first(a, n);
     if (n > a.n_split) n = a.n_split;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int stride = refine_stride(a);
-    for (int e0 = blockIdx.x * 4; e0 < n; e0 += gridDim.x * 4) {
+    for (int e0 = first + blockIdx.x * 4; e0 < n; e0 += gridDim.x * 4) {
         const int e = e0 + wave;
         RefineEntry q{};
         if (e < n) {
@@ -770,9 +781,10 @@ __global__ __launch_bounds__(256) void k_argmax_refine_whole(RefineArgs a) {
     int n = *a.n_flag;
     if (n > a.list_cap) n = a.list_cap;
     const int tid = threadIdx.x;
-    if (a.n_split + (int)blockIdx.x >= n) return;
+    const int begin = a.n_split > refine_first(a, n) ? a.n_split : refine_first(a, n);
+    if (begin + (int)blockIdx.x >= n) return;
     const RefineTabs t = refine_tabs(a, smem, tid);
-    for (int e = a.n_split + blockIdx.x; e < n; e += gridDim.x) {
+    for (int e = begin + blockIdx.x; e < n; e += gridDim.x) {
         const RefineEntry q = refine_entry(a, e);
         refine_phases(a, t, q.r, q.kd, tid, 256);
         const int *al = t.ant + (q.which ? MAX_ANT : 0);

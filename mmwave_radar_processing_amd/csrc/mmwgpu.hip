@@ -6,6 +6,7 @@
 #include "mmw_czt.h"
 #include "mmw_beamform.h"
 #include "mmw_detect.h"
+#include "mmw_cells64.h"
 
 #include <algorithm>
 #include <climits>
@@ -1663,8 +1664,8 @@ static int fill_refine_args(mmw_ctx *ctx, RefineArgs *ra, int S, int C, int A) {
 //    evaluations to float64 -- 120 per frame, each a direct DFT sum over whole planes: 29-36 us/frame against 7.2 with an
 //    eighth of the bound (~10x above anything observed; 1.6 % refined).  Default: 1/8 + the pairwise pass (lists of up to 8
 //    antennas); MMW_ARGMAX_BOUND_DIV=1 selects the worst case, i.e. a proof, at that price.
-static float argmax_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 8)); }
-static float detect_bound_div() { return (float)std::max(1, env_int("MMW_ARGMAX_BOUND_DIV", 1)); }
+static float argmax_bound_div(const mmw_ctx *ctx) { return (float)std::max(1, opt_int(ctx, "MMW_ARGMAX_BOUND_DIV", 1)); }
+
 
 int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1, const void *d_rd, const int32_t *d_dets,
                            const int32_t *d_counts, int32_t *d_idx, int n_frames, int V, int S, int C, int cap,
@@ -1682,13 +1683,27 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     const int list_cap = n_frames * cap;
     const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));   // flagged detections whose
                                                                                           // plane sums are split over workgroups
-    const size_t list_bytes = (256 + (size_t)list_cap * sizeof(int) + 255) & ~(size_t)255;
-    const size_t part_bytes = (size_t)n_split * REFINE_PARTS * n_ant * sizeof(cplx<double>);
-    MMW_TRY(ensure_scratch(ctx, list_bytes + part_bytes));
+    // Dense refinement (mmw_cells64.h): when many evaluations are flagged -- noise-level detections, e.g. the GUI's OS-CFAR --
+    // the float64 cells of a whole frame come from one Doppler FFT per sample row + 256-term range sums instead of one
+    // 32768-term sum per cell and antenna.  On when the call flags >= dense_min evaluations (8 per frame; MMW_ARGMAX_DENSE_MIN)
+    // and the plane has a kernel (128 chirps); covers the first dense_cap entries of the list, the direct kernels the rest.
+    const int max_cells = C == 128 ? cells64_max_cells(S, C) : 0;
+    const int dense_min = max_cells > 0 ? std::max(1, opt_int(ctx, "MMW_ARGMAX_DENSE_MIN", 8 * n_frames)) : 0;
+    const int dense_cap = dense_min > 0 ? (int)std::min<long>(list_cap, 256L * n_frames) : 0;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t list_bytes = up(256 + (size_t)list_cap * sizeof(int));
+    const size_t part_bytes = up((size_t)n_split * REFINE_PARTS * n_ant * sizeof(cplx<double>));
+    const size_t pos_bytes = dense_min > 0 ? up((size_t)list_cap * sizeof(int)) : 0;
+    const size_t cell_bytes = up((size_t)dense_cap * n_ant * sizeof(cplx<double>));
+    MMW_TRY(ensure_scratch(ctx, list_bytes + part_bytes + pos_bytes + cell_bytes));
     int *d_nflag = (int *)ctx->scratch, *d_list = (int *)((char *)ctx->scratch + 256);
+    int *d_flagpos = dense_min > 0 ? (int *)((char *)ctx->scratch + list_bytes + part_bytes) : nullptr;
+    cplx<double> *d_cells = (cplx<double> *)((char *)ctx->scratch + list_bytes + part_bytes + pos_bytes);
     MMW_HIP(hipMemsetAsync(d_nflag, 0, 256, ctx->stream));
-    const float eps = 5.9604645e-8f, div = argmax_bound_div();
-    ArgmaxRefine rf{d_l1, d_nflag, d_list, list_cap, (float)rd_error_ulps(S, C) * eps / div, 4.f * (float)(n_ant + 4) * eps / div};
+    if (d_flagpos) MMW_HIP(hipMemsetAsync(d_flagpos, 0, (size_t)list_cap * sizeof(int), ctx->stream));
+    const float eps = 5.9604645e-8f, div = argmax_bound_div(ctx);
+    ArgmaxRefine rf{d_l1, d_nflag, d_list, list_cap, (float)rd_error_ulps(S, C) * eps / div, 4.f * (float)(n_ant + 4) * eps / div,
+                    d_flagpos, dense_cap};
     ProfScope ps(ctx, "argmax");
     dim3 grid(std::min((cap + 3) / 4, 32), n_frames);      // 128 detections per frame in one pass, more by looping
     launch_angle_argmax(ctx, grid, (const float2 *)d_rd, d_dets, d_counts, d_idx, V, S, C, cap, ants, A, shift,
@@ -1709,6 +1724,35 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     ra.partial = (cplx<double> *)((char *)ctx->scratch + list_bytes);
     ra.n_split = n_split;
     ra.parts = refine_parts(n_frames);
+    ra.dense_min = dense_min;
+    ra.dense_cap = dense_cap;
+    if (dense_min > 0) {
+        Cells64Args ca{};
+        ca.cubes = (const float2 *)d_cubes;
+        ca.dets = d_dets;
+        ca.counts = d_counts;
+        ca.flagpos = d_flagpos;
+        ca.n_flag = d_nflag;
+        ca.dense_min = dense_min;
+        ca.out = d_cells;
+        ca.V = V;
+        ca.S = S;
+        ca.cap = cap;
+        ca.n_ant = n_ant;
+        ca.max_cells = max_cells;
+        ca.ants = ants;
+        ca.ws = ra.ws;
+        ca.wc = ra.wc;
+        ca.twS = ra.twS;
+        ca.twC = ra.twC;
+        const size_t lds = cells64_lds(S, C, max_cells);
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cells64<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_cells64<128>, dim3((unsigned)n_ant, (unsigned)n_frames), dim3(C64_NT), lds, ctx->stream, ca);
+        MMW_TRY(check_launch("cells64"));
+        Argmax64ListArgs la{d_cells, d_nflag, d_list, dense_min, dense_cap, n_ant, A, shift, d_idx, ra.twA};
+        hipLaunchKernelGGL(k_argmax64_list, dim3((unsigned)std::min(std::max(dense_cap / 4, 1), 4 * ctx->num_cu)), dim3(256), 0, ctx->stream, la);
+        MMW_TRY(check_launch("argmax64_list"));
+    }
     MMW_TRY(launch_argmax_refine(ctx, ra));
     if (h_n_refined) {
         MMW_HIP(hipMemcpyAsync(h_n_refined, d_nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1872,7 +1916,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     if (overlap) MMW_HIP(hipMemsetAsync(sync_words, 0, b_sync, ctx->stream));
     // range-Doppler of every antenna (float32) with the planes' L1 norms
     if (!overlap) MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
-    const float eps = 5.9604645e-8f, div = detect_bound_div();
+    const float eps = 5.9604645e-8f, div = argmax_bound_div(ctx);
     const int ulps = rd_error_ulps(S, C);
     a.rd = (const float2 *)d_rd;
     a.l1 = d_l1;

@@ -157,7 +157,8 @@ def test_standalone_exact_argmax_on_os_detections():
     """The stand-alone exact argmax (mmw_angle_argmax_exact through FramePipeline.point_clouds: the path of every detector
     but CA-CFAR 2-D) on OS-CFAR detections with the GUI's parameters -- ~470 mostly noise-level cells per 256 x 128 frame, flat
     angle spectra: the hard case for the certainty test -- against the float64 oracle's argmax on the same detections.
-    MMW_ARGMAX_BOUND_DIV=1 in the environment runs the worst-case bound instead of the default eighth."""
+    The default is the worst-case bound (a proof); flagged evaluations of a batch like this one -- 13 % of them -- are refined
+    by the dense float64 kernels of mmw_cells64.h.  (MMW_ARGMAX_BOUND_DIV=8 in the environment: round 3's empirical eighth.)"""
     n_frames = max(8, int(os.environ.get("MMW_SWEEP_FRAMES", "96")) // 4)
     procs = int(os.environ.get("MMW_SWEEP_PROCS", "4"))
     cm = ConfigManager()
@@ -173,6 +174,6 @@ def test_standalone_exact_argmax_on_os_detections():
     bad_az = sum(int(np.count_nonzero(pipe.az_idx[f] != ref[f][0])) for f in range(n_frames))
     bad_el = sum(int(np.count_nonzero(pipe.el_idx[f] != ref[f][1])) for f in range(n_frames))
     n = sum(len(d) for d in pipe.dets)
-    print(f"stand-alone exact argmax (bound divisor {os.environ.get('MMW_ARGMAX_BOUND_DIV', '8')} + pairwise pass) on OS-CFAR detections: "
+    print(f"stand-alone exact argmax (bound divisor {os.environ.get('MMW_ARGMAX_BOUND_DIV', '1')} + pairwise pass) on OS-CFAR detections: "
           f"{n_frames} frames, {n} detections, {bad_az} azimuth / {bad_el} elevation index differences, {pipe.n_refined} evaluations refined")
     assert n > 100 * n_frames and bad_az == 0 and bad_el == 0
