@@ -155,6 +155,8 @@ class stdout_to_stderr:
 
 
 DET_CFAR = dict(kind=0, train=(4, 4), guard=(2, 2), pfa=1e-5)      # CaCFAR2D((4,4),(2,2),1e-5), SURVEY.md 8d
+# the detector the reference's shipped configs run: OsCFAR2D((5,5),(3,2), rho 0.7, alpha 2) (gui_configs/processor_params.yaml:40-47)
+OS_CFAR = dict(kind=1, train=(5, 5), guard=(3, 2), rho=0.7, alpha=2.0)
 AZ_ANT, EL_ANT = list(range(8)), [8, 9, 10, 11]
 DET_CAP = 2048
 DET_BYTES_PER_FRAME = 2 * CUBE_BYTES + S * C * 4    # RD cube in + out, antenna-0 magnitude (+ 8 B / detection)
@@ -169,8 +171,11 @@ class DetectWorkload:
     azimuth / elevation argmax for every frame of the resident batch (FramePipeline.point_clouds without the host
     table look-ups)."""
 
-    def __init__(self, ctx, F, path="fused"):
+    def __init__(self, ctx, F, path="fused", cfar=None):
         from mmwave_radar_processing_amd import _lib
+        self.cfar = cfar = cfar or DET_CFAR
+        if cfar["kind"] != 0:
+            path = "float64"            # OS-CFAR: float64 CFAR plane + exact argmax (worst-case bound, dense float64 refinement)
         self.ctx, self.F, self._lib, self.path = ctx, F, _lib, path
         n = S * C
         self.d_rd = ctx.alloc(F * CUBE_BYTES)
@@ -180,24 +185,28 @@ class DetectWorkload:
             self.d_mag32 = ctx.alloc(F * n * 4)
         else:
             self.d_mag, self.d_mask = ctx.alloc(F * n * 8), ctx.alloc(F * n)
-        (tr, td), (gr, gd) = DET_CFAR["train"], DET_CFAR["guard"]
+        (tr, td), (gr, gd) = cfar["train"], cfar["guard"]
         n_train = (2 * (tr + gr) + 1) * (2 * (td + gd) + 1) - (2 * gr + 1) * (2 * gd + 1)
-        self.scale = ca_alpha(n_train, DET_CFAR["pfa"])
+        if cfar["kind"] == 0:
+            self.scale, self.k_rank = ca_alpha(n_train, cfar["pfa"]), 0
+        else:
+            self.scale, self.k_rank = cfar["alpha"], max(1, min(int(cfar["rho"] * n_train), n_train))     # detectors/os_cfar.py:131-132
         self.az, self.n_az = _lib.int_array(AZ_ANT)
         self.el, self.n_el = _lib.int_array(EL_ANT)
 
     def step(self, d_in, stats=None):
         L, h, lib, F = self.ctx.lib, self.ctx.handle, self._lib, self.F
-        (tr, td), (gr, gd) = DET_CFAR["train"], DET_CFAR["guard"]
+        (tr, td), (gr, gd) = self.cfar["train"], self.cfar["guard"]
+        kind = self.cfar["kind"]
         if self.path == "fused":
             # one call: RD + screened CFAR (undecided cells settled in float64) + ordered detections + az / el argmax
             lib.check(L.mmw_detect_points(h, d_in.ptr, self.d_rd.ptr, self.d_l1.ptr, self.d_mag32.ptr, self.d_dets.ptr,
-                                          self.d_cnt.ptr, self.d_az.ptr, self.d_el.ptr, F, V, S, C, DET_CFAR["kind"], tr, td, gr, gd,
+                                          self.d_cnt.ptr, self.d_az.ptr, self.d_el.ptr, F, V, S, C, kind, tr, td, gr, gd,
                                           self.scale, 0, DET_CAP, self.az, self.n_az, 1, self.el, self.n_el, 0, A, stats))
             return
         lib.check(L.mmw_detect_batch(h, d_in.ptr, self.d_rd.ptr, self.d_mag.ptr, self.d_mask.ptr, self.d_dets.ptr,
-                                     self.d_cnt.ptr, self.d_l1.ptr, F, V, S, C, DET_CFAR["kind"], tr, td, gr, gd, self.scale,
-                                     0, DET_CAP))
+                                     self.d_cnt.ptr, self.d_l1.ptr, F, V, S, C, kind, tr, td, gr, gd, self.scale,
+                                     self.k_rank, DET_CAP))
         for ant, n_ant, d_idx, shift in ((self.az, self.n_az, self.d_az, 1), (self.el, self.n_el, self.d_el, 0)):
             lib.check(L.mmw_angle_argmax_exact(h, d_in.ptr, self.d_l1.ptr, self.d_rd.ptr, self.d_dets.ptr, self.d_cnt.ptr,
                                                d_idx.ptr, F, V, S, C, DET_CAP, ant, n_ant, A, shift, None))
@@ -211,7 +220,10 @@ class DetectWorkload:
         out = {}
         for f in frames:
             cube = d_in.download((V, S, C), np.complex64, f * CUBE_BYTES)
-            _, dets_ref, az_ref, el_ref = O.point_cloud(cube, sc, AZ_ANT, EL_ANT)
+            if self.cfar["kind"] == 0:
+                _, dets_ref, az_ref, el_ref = O.point_cloud(cube, sc, AZ_ANT, EL_ANT)
+            else:
+                dets_ref, az_ref, el_ref = os_point_indices(O, cube, self.cfar)
             n = int(counts[f])
             dets = self.d_dets.download((n, 2), np.int32, f * DET_CAP * 8).astype(np.int64)
             ok = n == dets_ref.shape[0] and np.array_equal(dets, dets_ref)
@@ -225,22 +237,35 @@ class DetectWorkload:
         return out, int(counts.sum())
 
 
-def cpu_baseline_detect(seconds: float = 12.0):
+def os_point_indices(O, cube, cfar):
+    """Oracle: OS-CFAR 2-D detections (RangeDopplerDetector2D with os_cfar_2d) and the argmax bins of both antenna lists."""
+    dets = O.rd_detect_2d_os(cube, cfar["train"], cfar["guard"], cfar["rho"], cfar["alpha"])
+    if dets.shape[0] == 0:
+        return dets, np.empty(0, int), np.empty(0, int)
+    raw = O.range_doppler(cube)
+    r, v = dets[:, 0].astype(int), dets[:, 1].astype(int)
+    return dets, O.angle_argmax(raw, r, v, AZ_ANT, A, True)[0], O.angle_argmax(raw, r, v, EL_ANT, A, False)[0]
+
+
+def cpu_baseline_detect(seconds: float = 12.0, cfar=None):
     from mmwave_radar_processing_amd import synth
     from oracle import oracle_np as O
     sc = O.cfg_scalars(synth.SYNTH_CFG_256x128x12)
     cubes = [synth.synth_cube(1000 + i) for i in range(4)]
-    O.point_cloud(cubes[0], sc, AZ_ANT, EL_ANT)
+    os_kind = bool(cfar and cfar["kind"] != 0)
+    one = (lambda c: os_point_indices(O, c, cfar)) if os_kind else (lambda c: O.point_cloud(c, sc, AZ_ANT, EL_ANT))
+    one(cubes[0])
     n, t0 = 0, time.perf_counter()
     while True:
-        O.point_cloud(cubes[n % len(cubes)], sc, AZ_ANT, EL_ANT)
+        one(cubes[n % len(cubes)])
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds and n >= 8:
+        if dt >= seconds and n >= (3 if os_kind else 8):
             break
+    what = "OS-CFAR 2-D (sliding-window sort)" if os_kind else "CA-CFAR"
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames of the same synthetic 12x256x128 workload through oracle_np.point_cloud (float64 NumPy "
-                      f"RD + CA-CFAR + angle argmax, single thread) in {dt:.1f} s"}
+            "sample": f"{n} frames of the same synthetic 12x256x128 workload through the oracle (float64 NumPy RD + {what} + angle "
+                      f"argmax, single thread) in {dt:.1f} s"}
 
 
 def host_stream_record(ctx, chunk_frames: int = 128, n_chunks: int = 8):
@@ -379,29 +404,41 @@ def main():
         return dt, ev
 
     elapsed, ev_ms = timed(step, args.profile_every if args.profile_every > 0 else (1 if n_launch == 1 else 7))
-    prof = {k: ctx.profile_get(k) for k in ("rd", "angle", "detect", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
+    prof = {k: ctx.profile_get(k) for k in ("rd", "angle", "detect", "detect_tail", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
                                             "plane_l1", "argmax")} if not args.no_profile else {}
     # BASELINE configs[2] beside the headline: the detection pipeline on the same resident frames, same K / W
     det_extra = None
     if not detect and not args.no_detect_record:
         work = DetectWorkload(ctx, F, args.detect_path)
         det_elapsed, det_ev = timed(lambda: work.step(d_in), 1)
-        det_prof = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
+        det_prof = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_tail", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
                                                     "plane_l1", "argmax")} if not args.no_profile else {}
         det_extra = (det_elapsed, det_ev, det_prof)
+        work_os = DetectWorkload(ctx, F, cfar=OS_CFAR)
+        os_elapsed, os_ev = timed(lambda: work_os.step(d_in), 1)
+        os_prof = {k: ctx.profile_get(k) for k in ("rd", "rd64", "cfar", "compact", "plane_l1", "argmax")} if not args.no_profile else {}
+        os_extra = (os_elapsed, os_ev, os_prof)
 
-    def detect_fields(dt, ev, fam):
+    def detect_fields(dt, ev, fam, wl=None):
         """frames/s, per-stage ms and the roofline of the range-Doppler stage of the detection pipeline."""
         v = world * F * args.steps / dt
+        os_kind = wl is not None and wl.cfar["kind"] != 0
         rec = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps, "hip_event_ms_per_step_rank0": ev / args.steps,
                "algorithmic_bytes_per_frame": DET_BYTES_PER_FRAME,
                "hbm_frac_of_8TBs": v / world * DET_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),
-               "path": args.detect_path,
-               "workload": "range-Doppler of all antennas (float32) + CA-CFAR((4,4),(2,2),1e-5) on antenna 0 (float32 screening "
-                           "with the worst-case error band, undecided cells in float64) + ordered detections + 8-antenna azimuth / "
-                           "4-antenna elevation argmax, float64-exact (BASELINE configs[2])"}
+               "path": wl.path if wl is not None else args.detect_path,
+               "workload": ("range-Doppler of all antennas (float32) + OS-CFAR((5,5),(3,2), rho 0.7, alpha 2: the reference's GUI / "
+                            "analysis default) on the float64 |RD| of antenna 0 + ordered detections + 8-antenna azimuth / 4-antenna "
+                            "elevation argmax with the worst-case error bound, flagged evaluations refined from float64 cells "
+                            "(dense form: mmw_cells64.h)") if os_kind else
+                           ("range-Doppler of all antennas (float32) + CA-CFAR((4,4),(2,2),1e-5) on antenna 0 (float32 screening "
+                            "with the worst-case error band, undecided cells in float64) + ordered detections + 8-antenna azimuth / "
+                            "4-antenna elevation argmax, float64-exact (BASELINE configs[2])")}
         if fam:
             rec["kernels_ms_per_step"] = {k: ms / max(n, 1) * (2 if k == "argmax" else 1) for k, (ms, n) in fam.items() if n}
+            # consistency: stages run back to back on one stream (the exact-cell and refinement kernels side by side), so the
+            # sum of the per-stage event spans brackets the step time from above
+            rec["kernels_ms_sum_over_ms_per_step"] = sum(rec["kernels_ms_per_step"].values()) / (1e3 * dt / args.steps)
             rd_ms, rd_n = fam.get("rd", (0.0, 0))
             if rd_n:
                 avg_s = rd_ms * 1e-3 / rd_n
@@ -440,7 +477,7 @@ def main():
                        "frames_per_gpu": F, "cube": [V, S, C], "angle_bins": A,
                        "sharding": f"frame-sharded x{world}, no collective",
                        "schedule": (f"{args.detect_path}: stages back to back on one stream, whole batch per launch") if detect else plan,
-                       "device": info["name"] or "AMD Instinct MI355X (hipDeviceProp name empty)", "arch": info["arch"]},
+                       "device": info["name"], "arch": info["arch"], "compute_units": info.get("num_cu")},
             "hip_event_ms_per_step_rank0": ev_ms / args.steps,
             "chain_hbm_frac_of_8TBs": value / world * algo / (HBM_PEAK_GBS * 1e9),
         }
@@ -450,7 +487,8 @@ def main():
                 if k in rec:
                     out[k] = rec[k]
         elif det_extra is not None:
-            out["detect"] = detect_fields(*det_extra)
+            out["detect"] = detect_fields(*det_extra, wl=work)
+            out["detect_os"] = detect_fields(*os_extra, wl=work_os)
         if not args.no_profile and not detect:
             ang_ms, ang_n = prof["angle"]
             rd_ms, rd_n = prof["rd"]
@@ -502,12 +540,18 @@ def main():
                 out["detect"]["detections_per_frame"] = total_dets / F
                 parity_ok = parity_ok and all(v["detection_indices_identical"] and not v["argmax_index_differences"]
                                               for v in dpar.values())
+                opar, os_dets = work_os.parity(d_in, sorted({0, F // 2, F - 1}))
+                out["detect_os"]["parity"] = opar
+                out["detect_os"]["detections_per_frame"] = os_dets / F
+                parity_ok = parity_ok and all(v["detection_indices_identical"] and not v["argmax_index_differences"]
+                                              for v in opar.values())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_detect() if detect else cpu_baseline()
             if not detect:
                 out["cpu_baseline_all_cores"] = cpu_baseline_pool()
                 if det_extra is not None:
                     out["detect"]["cpu_baseline"] = cpu_baseline_detect(6.0)
+                    out["detect_os"]["cpu_baseline"] = cpu_baseline_detect(6.0, OS_CFAR)
                     out["detect"]["host_stream_pcie_inclusive"] = host_stream_record(ctx)
         print(json.dumps(out))
         if not parity_ok:

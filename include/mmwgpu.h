@@ -321,7 +321,9 @@ int mmw_diag_membw(mmw_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, i
  * two waves per SIMD.  kind 0 = v_mfma_f32_32x32x2_f32 (the Bartlett GEMM's instruction), 1 = v_mfma_f64_16x16x4_f64
  * (the Capon covariance).  The figure the beamformer kernels' TFLOP/s are divided by in tools/kbench.py.
  * kinds 2 / 3: the kind-0 stream with 8 / 16 independent v_fma_f32 after every MFMA (rate still counts the MFMAs only);
- * kinds 4 / 5: the same with ONE wave per SIMD -- how much vector work hides under float32 MFMAs (it does not). */
+ * kinds 4 / 5: the same with ONE wave per SIMD -- how much vector work hides under float32 MFMAs (it does not);
+ * kinds 6 / 7: the contrast case, v_mfma_f32_32x32x16_bf16 alone / with 8 v_fma_f32 after every MFMA (tools/pmc_coexec.sh
+ * collects SQ_VALU_MFMA_COEXEC_CYCLES for all of them). */
 int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops);
 /* Which range-Doppler kernel mmw_range_doppler picks for an S x C plane, without touching a device (host logic
  * only): plan[0] = 0 fused 256x128 | 1 LDS-resident power of two | 2 mixed radix | 3 generic two-kernel path |

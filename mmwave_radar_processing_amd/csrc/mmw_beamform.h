@@ -314,7 +314,7 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
     // small batches: split K over workgroups until about half the chip is busy (each part at least two K steps)
     const long wgs = (long)((T + CG_TN - 1) / CG_TN) * ((S + CG_TM - 1) / CG_TM) * n_frames;
     int ksplit = 1;
-    if (wgs * 2 <= ctx->num_cu && E >= 4 * CG_TK && !tune_int("MMW_CGEMM_NO_KSPLIT", 0))
+    if (wgs * 2 <= ctx->num_cu && E >= 4 * CG_TK && !0)
         ksplit = (int)std::min<long>(std::min<long>(16, E / (2 * CG_TK)), ctx->num_cu / (2 * wgs));
     if (ksplit < 2) ksplit = 1;
     const int kc = ksplit > 1 ? ((E + ksplit - 1) / ksplit + CG_TK - 1) / CG_TK * CG_TK : E;
@@ -330,13 +330,13 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
     // small contractions (at most four 32 x 32 tiles per CU): steering evaluated inside the tile kernel
     const int tiles_s = (S + 31) / 32, NT = (T + 31) / 32;
     const long MT = (long)n_frames * tiles_s;     // (< 2^31: n_frames <= 65535)
-    const int path = tune_int("MMW_BARTLETT_PATH", 0);      // 1: tile kernel, 2: tiled GEMM (experiments / tests)
+    const int path = opt_int(ctx, "MMW_BARTLETT_PATH", 0);      // 1: tile kernel, 2: tiled GEMM (experiments / tests)
     if (path == 1 || (path == 0 && MT * NT <= 4L * ctx->num_cu)) {
         ProfScope pg(ctx, "cgemm");
         const int nw = 8;
         const unsigned grid = (unsigned)(8 * NT * ((MT + 7) / 8));
         const size_t lds = (size_t)nw * BT_STRIP + (size_t)nw * 2 * 16 * 64 * 4;
-        const bool poly = tune_int("MMW_BARTLETT_POLY", 0) != 0;       // polynomial sine / cosine instead of v_sin / v_cos
+        const bool poly = opt_int(ctx, "MMW_BARTLETT_POLY", 0) != 0;       // polynomial sine / cosine instead of v_sin / v_cos
         auto kern = k_bartlett_tile<8, 16, false, 1>;
         if ((E & 31) == 0) kern = poly ? k_bartlett_tile<8, 16, true, 0> : k_bartlett_tile<8, 16, true, 1>;
         else if (poly) kern = k_bartlett_tile<8, 16, false, 0>;
@@ -406,6 +406,49 @@ __global__ __launch_bounds__(256) void k_diag_mfma(float *sink, int iters, int k
         }
         const float v = a0[0] + a1[1] + a2[2] + a3[3];
         if (v == 12345.678f) sink[0] = v;
+    } else if (kind >= 6) {
+        // kind 6 / 7: the contrast case for the co-execution question -- v_mfma_f32_32x32x16_bf16 (a matrix instruction the
+        // guide says has its own pipe) alone / with 8 independent float32 FMAs after every MFMA
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        v16f a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+        bf16x8 x, y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] = (__bf16)seed;
+            y[j] = (__bf16)0.5f;
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = seed + (float)j;
+        const float m = 0.999f, c = 0.001f;
+        auto valu = [&]() {
+            if (kind == 7) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(m), "v"(c));
+            }
+        };
+        for (int i = 0; i < iters; ++i) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            valu();
+            __builtin_amdgcn_sched_barrier(0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            valu();
+            __builtin_amdgcn_sched_barrier(0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            valu();
+            __builtin_amdgcn_sched_barrier(0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            valu();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float t = a0[0] + a1[1] + a2[2] + a3[3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += v[j];
+        if (t == 12345.678f) sink[0] = t;
     } else if (kind >= 2) {
         // kind 2 / 3: the same MFMA stream with 8 / 16 independent float32 FMAs after every MFMA -- do a wave's (or the
         // SIMD's other wave's) vector instructions run under an MFMA in flight?  (rate reported counts the MFMAs only)
@@ -689,7 +732,7 @@ inline int capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d
     const int n_bins = n_frames * R;
     // sixteen waves per CU (four per SIMD), each wave walking its share of the bins
     const long want = ((long)n_bins + 3) / 4;
-    const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 4 * std::max(1, tune_int("MMW_CAPON_WG_ROUNDS", 1)));
+    const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 4 * std::max(1, 1));
     const int lds = CAPON2_UTAB * 16 + 4 * CAPON2_WAVE_LDS;
     if ((long)n_frames * R >= (1L << 31)) return set_error(MMW_ERR_INVALID, "capon: more than 2^31 range bins in one call");
     auto kern = (K & 31) == 0 ? (V <= 4 ? k_capon_sweep<1, true> : V <= 8 ? k_capon_sweep<2, true> : V <= 12 ? k_capon_sweep<3, true>

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4
 
 // even bin counts whose rows are not 64-B aligned take the row-window kernels
 inline bool angle_rows_needed(long bins, bool mag) {
-    return bins % 2 == 0 && bins % angle_rows_unit(mag) != 0 && tune_int("MMW_ANGLE_ROWS", 1) != 0;
+    return bins % 2 == 0 && bins % angle_rows_unit(mag) != 0 && 1 != 0;
 }
 inline int angle_rows_waves(long bins, bool mag) {      // waves per frame: the last window must reach the row end for every m
     const int U = angle_rows_unit(mag);
@@ -350,8 +350,8 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)F);
-    const bool nt = tune_int("MMW_ANGLE_NT", 1) != 0;
-    const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f && tune_int("MMW_ANGLE_ZE", 1) != 0;
+    const bool nt = 1 != 0;
+    const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f && opt_int(ctx, "MMW_ANGLE_ZE", 1) != 0;
     if (bins % 2) {         // angle_fast_path admits odd bin counts only for complex output
         const int n_waves = (int)((bins + 15 + 111) / 112);
         dim3 g((unsigned)((n_waves + 3) / 4), (unsigned)F);
@@ -1248,9 +1248,9 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
     const int blocks = (int)skip_planes(planes, rv);   // one plane per workgroup
     // Standalone launches use the persistent variant with 8 rows prefetched (+12 %); inside the overlapped
     // chain the one-plane-per-workgroup kernel is faster (measured), so the chain sets active_cus and gets it.
-    const int pf = tune_int("MMW_RD_PERSIST", -1) >= 0 ? tune_int("MMW_RD_PERSIST", -1) : (ctx->active_cus > 0 ? 0 : 8);
+    const int pf = ctx->active_cus > 0 ? 0 : 8;
     if (pf == 8 && rv.vskip <= 2) {
-        int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu) * tune_int("MMW_RD_PERSIST_WGS_PER_CU", 1);
+        int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu) * 1;
         if (grid > planes) grid = planes;
         auto launch = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
@@ -1268,22 +1268,7 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
         } else launch(k_rd_fused_256x128_persist<true, 6>);     // 6 rows prefetched: 8 no longer fit the register budget (spills)
         return check_launch("rd_fused_persist");
     }
-#ifdef MMW_ABLATE   // timing-only variants (no loads / no stores), build with EXTRA=-DMMW_ABLATE
-    const int abl = tune_int("MMW_RD_ABLATE", 0);
-    if (abl) {
-        auto launch = [&](auto kern) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream, (const f32x4 *)d_in,
-                               (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                               (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
-        };
-        if (abl == 1) launch(k_rd_fused_256x128<true, 1>);
-        else if (abl == 2) launch(k_rd_fused_256x128<true, 2>);
-        else launch(k_rd_fused_256x128<true, 3>);
-        return check_launch("rd_fused_ablate");
-    }
-#endif
-    if (tune_int("MMW_RD_NT", 1))
+    if (1)
         hipLaunchKernelGGL(k_rd_fused_256x128<true>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
                            (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
                            (const cplx<float> *)t256, (const cplx<float> *)t128, rv);

@@ -515,7 +515,7 @@ template <typename T, bool MAG>
 int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C,
                     RawView rv = RawView{1, 0}) {
     if constexpr (sizeof(T) == 4 && !MAG)
-        if (rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0))
+        if (rd_mixed_ct_supported(S, C) && !0)
             return launch_rd_mixed_ct(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv);
     RdMixedPlan pl;
     if (!rd_mixed_plan(S, C, sizeof(cplx<T>), &pl))
@@ -561,7 +561,7 @@ int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *
     // (measured on 63x100: 256 threads 0.68, 512 threads 0.53 us/frame; on 120x126: 256 -> 1024 threads 4.1 -> 1.7).
     const int wgs = (int)(MIXED_LDS_MAX / pl.lds_bytes);
     if constexpr (sizeof(T) == 4) {
-        const bool wide = pl.big || wgs < tune_int("MMW_MIXED_WIDE_BELOW", 3);
+        const bool wide = pl.big || wgs < 3;
         switch (pl.cls * 2 + pl.big) {
             case 0:
                 if (wide) return go(k_rd_mixed<T, 0, false, MAG, 1024>, 1024);

@@ -557,7 +557,7 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
         MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_rd_mixed_ct<S, C, NT, 0>), NT, lds_bytes));
         persist_dflt = nb <= 1 ? 1 : 0;
     }
-    const bool persist = rv.ntx <= 1 && (tune_int("MMW_MIXED_CT_PERSIST", -1) >= 0 ? tune_int("MMW_MIXED_CT_PERSIST", -1) : persist_dflt) != 0;
+    const bool persist = rv.ntx <= 1 && persist_dflt != 0;
     auto kern = persist ? k_rd_mixed_ct<S, C, NT, 1> : k_rd_mixed_ct<S, C, NT, 0>;
     if (lds_bytes > 64 * 1024)
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -34,7 +34,7 @@ int abs_c64(mmw_ctx *ctx, const void *d_in, float *d_out, size_t n) {
 }
 
 // Range FFT (windows on both axes folded into the load) then in-place Doppler FFT + fftshift.
-// Frames go through in chunks of ~MMW_RD_GENERIC_CHUNK_MB of output so that the Doppler pass finds the range
+// Frames go through in chunks of ~96 MB of output so that the Doppler pass finds the range
 // pass's result still in the 256 MB Infinity Cache instead of re-reading it from HBM.
 static int range_doppler_generic_chunk(mmw_ctx *ctx, const void *d_cubes, void *d_out, int F, int V, int S, int C) {
     FftArgs a{};
@@ -65,7 +65,7 @@ static int range_doppler_generic_chunk(mmw_ctx *ctx, const void *d_cubes, void *
 
 int range_doppler_generic(mmw_ctx *ctx, const void *d_cubes, void *d_out, int F, int V, int S, int C) {
     const size_t cube_bytes = (size_t)V * S * C * sizeof(float2);
-    long chunk = (long)(((size_t)tune_int("MMW_RD_GENERIC_CHUNK_MB", 96) << 20) / cube_bytes);
+    long chunk = (long)(((size_t)96 << 20) / cube_bytes);
     if (chunk < 1) chunk = 1;
     for (long f0 = 0; f0 < F; f0 += chunk) {
         const int nf = (int)((F - f0 < chunk) ? F - f0 : chunk);
@@ -126,7 +126,18 @@ int mmw_device_info(int device, char *name, int name_len, char *arch, int arch_l
                     size_t *total_mem) {
     hipDeviceProp_t prop;
     MMW_HIP(hipGetDeviceProperties(&prop, device));
-    if (name && name_len > 0) snprintf(name, name_len, "%s", prop.name);
+    if (name && name_len > 0) {
+        // hipDeviceProp_t::name comes back empty on this image's MI355X boxes: ask the runtime's other query, and failing that
+        // name the product from what identifies it (gfx950 with 256 compute units is the MI355X / MI350X package)
+        char buf[256] = {0};
+        snprintf(buf, sizeof(buf), "%s", prop.name);
+        if (!buf[0] && hipDeviceGetName(buf, (int)sizeof(buf), device) != hipSuccess) buf[0] = 0;
+        (void)hipGetLastError();
+        if (!buf[0] && !std::strncmp(prop.gcnArchName, "gfx950", 6))
+            snprintf(buf, sizeof(buf), "AMD Instinct MI355X (identified by arch %s, %d CUs, %.0f GiB: the runtime reports no name)",
+                     prop.gcnArchName, prop.multiProcessorCount, (double)prop.totalGlobalMem / (1 << 30));
+        snprintf(name, name_len, "%s", buf);
+    }
     if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
     if (num_cu) *num_cu = prop.multiProcessorCount;
     if (total_mem) *total_mem = prop.totalGlobalMem;
@@ -145,14 +156,7 @@ int mmw_ctx_create(mmw_ctx **out, int device) {
     hipDeviceProp_t prop;
     MMW_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
-    const int ctx_cus = env_int("MMW_CTX_CUS", 0);   // experiment: restrict the context stream to the first n CUs
-    if (ctx_cus > 0 && ctx_cus < c->num_cu) {
-        std::vector<uint32_t> m((c->num_cu + 31) / 32, 0u);
-        for (int i = 0; i < ctx_cus; ++i) m[i / 32] |= 1u << (i % 32);
-        MMW_HIP(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)m.size(), m.data()));
-    } else {
-        MMW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    }
+    MMW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     MMW_HIP(hipEventCreate(&c->t0));
     MMW_HIP(hipEventCreate(&c->t1));
     *out = c.release();
@@ -448,10 +452,10 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
         bool l1_done = false;
         // int16 raw cubes: folded into the loads of the 256 x 128 kernel and of the compile-time mixed-radix kernels (the
         // plane shapes of every shipped cfg); anything else converts + de-interleaves first (one extra pass)
-        const bool i16_folded = rv.i16 && rv.ntx > 1 && !env_int("MMW_NO_I16_FOLD", 0) &&
+        const bool i16_folded = rv.i16 && rv.ntx > 1 && !0 &&
                                 ((fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0)) ||
-                                 (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0) && !tune_int("MMW_NO_MIXED_CT", 0) &&
-                                  !(rd_lds_supported(S, C) && env_int("MMW_PREFER_LDS_RD", 0))));
+                                 (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0) && !0 &&
+                                  !(rd_lds_supported(S, C) && 0)));
         if (rv.i16 && !i16_folded) {
             MMW_REQUIRE(rv.ntx >= 1 && rv.nrx >= 1, "int16 cubes are raw cubes");
             const long total = (long)n_frames * V * S * C;
@@ -465,9 +469,9 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
         }
         if (fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
             MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C, rv, rv.ntx > 1 ? nullptr : d_l1, &l1_done));
-        else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && !(rd_mixed_ct_supported(S, C) && !env_int("MMW_PREFER_LDS_RD", 0)))      // the compile-time kernel is faster where both exist (64 x 64: 6.0 vs 4.4 TB/s)
+        else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && !(rd_mixed_ct_supported(S, C) && !0))      // the compile-time kernel is faster where both exist (64 x 64: 6.0 vs 4.4 TB/s)
             MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
-        else if (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0) && !tune_int("MMW_NO_MIXED_CT", 0)) {
+        else if (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0) && !0) {
             // compile-time kernel; on virtual-array cubes it also leaves the planes' L1 norms when asked
             float *l1 = rv.ntx > 1 ? nullptr : d_l1;
             MMW_TRY(launch_rd_mixed_ct(ctx, d_cubes, (long)S * C, d_out, n_frames * V, S, C, rv, nullptr, 0, nullptr, false, l1));
@@ -521,7 +525,7 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     // two passes with a complex128 intermediate: chunks of frames small enough for the intermediate to stay in the
     // Infinity Cache between them (128 MB; it also bounds the scratch: all 1250 frames of the bench at once were 640 MB)
     const size_t plane_bytes = (size_t)S * C * sizeof(cplx<double>);
-    long chunk = (long)(((size_t)tune_int("MMW_RD64_CHUNK_MB", 128) << 20) / plane_bytes);
+    long chunk = (long)(((size_t)128 << 20) / plane_bytes);
     if (chunk < 1) chunk = 1;
     if (chunk > n_frames) chunk = n_frames;
     MMW_TRY(ensure_scratch(ctx, (size_t)chunk * plane_bytes));
@@ -831,11 +835,11 @@ static int ensure_pipe_queues(mmw_ctx *ctx, int rd_cus) {
 // Does the angle stage of this call run k_angle64's ZE variant (planes 0 and V-1 never loaded)?
 static bool angle_fast_path(int V, long bins, int A, bool mag) {      // per launch of at most 65535 frames
     // odd bin counts: complex output only (k_angle64_rows_odd)
-    return A == 64 && (bins % 2 == 0 || (!mag && tune_int("MMW_ANGLE_ROWS", 1))) && !env_int("MMW_NO_FUSED_ANGLE", 0) && (V == 4 || V == 8 || V == 12 || V == 16);
+    return A == 64 && (bins % 2 == 0 || (!mag && 1)) && !env_int("MMW_NO_FUSED_ANGLE", 0) && (V == 4 || V == 8 || V == 12 || V == 16);
 }
-static bool angle_skips_end_planes(int V, long bins, int A, int flags) {
+static bool angle_skips_end_planes(const mmw_ctx *ctx, int V, long bins, int A, int flags) {
     return angle_fast_path(V, bins, A, (flags & MMW_ANGLE_MAGNITUDE) != 0) && V > 2 && !(flags & MMW_ANGLE_NO_WINDOW) &&
-           np_window(TAB_HANN, 0, V) == 0.0 && np_window(TAB_HANN, V - 1, V) == 0.0 && tune_int("MMW_ANGLE_ZE", 1) != 0;
+           np_window(TAB_HANN, 0, V) == 0.0 && np_window(TAB_HANN, V - 1, V) == 0.0 && opt_int(ctx, "MMW_ANGLE_ZE", 1) != 0;
 }
 
 // Schedule of one chain call (DESIGN.md "chain schedule"), also reported by mmw_diag_chain_plan.
@@ -858,7 +862,7 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // (np.hanning end points) and k_angle64's ZE variant never loads them, so when the RD cube is only an internal
     // intermediate (d_rd == NULL) their range-Doppler transform is skipped: 1/6 of the RD work at V = 12.
     // (Non-finite samples in an end antenna: the reference's 0 * inf gives NaN everywhere, this path stays finite.)
-    p.vskip = (!keep_rd && angle_skips_end_planes(V, (long)S * C, A, flags) && tune_int("MMW_CHAIN_SKIP_ENDS", 1)) ? V : 0;
+    p.vskip = (!keep_rd && angle_skips_end_planes(ctx, V, (long)S * C, A, flags) && opt_int(ctx, "MMW_CHAIN_SKIP_ENDS", 1)) ? V : 0;
     const int v_live = p.vskip > 2 ? V - 2 : V;
     // CU split: half the chip each.  The angle stage is bound by HBM writes and needs ~128 CUs to saturate them (a CU
     // sustains ~44 GB/s of stores); the range-Doppler stage keeps up from 112 CUs on (sweep in DESIGN.md)
@@ -872,9 +876,9 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     const bool big_prime = S % 127 == 0 || C % 127 == 0;
     const bool heavy_rd = !fused_rd_ok(S, C) && (plane_lds > 80 * 1024 || big_prime);
     const int rd_cus_dflt = !heavy_rd ? ctx->num_cu / 2 : (big_prime && plane_lds > 100 * 1024) ? ctx->num_cu * 3 / 4 : ctx->num_cu * 5 / 8;
-    p.rd_cus = env_int("MMW_RD_CUS", rd_cus_dflt);
+    p.rd_cus = opt_int(ctx, "MMW_RD_CUS", rd_cus_dflt);
     if (p.rd_cus < 0 || p.rd_cus >= ctx->num_cu) p.rd_cus = rd_cus_dflt;         // 0: unmasked queues
-    p.ring = std::max(2, std::min(env_int("MMW_CHAIN_RING", 3), (int)PIPE_RING_MAX));
+    p.ring = std::max(2, std::min(opt_int(ctx, "MMW_CHAIN_RING", 3), (int)PIPE_RING_MAX));
     // chunk: whole RD waves (rd_cus planes each) and `ring` chunks of live RD planes within ~250 MB of cache
     const size_t live_bytes = (size_t)v_live * S * C * sizeof(cplx<float>);
     int chunk_auto = (int)((250u << 20) / ((size_t)p.ring * live_bytes));
@@ -888,10 +892,10 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
                              angle_fast_path(V, (long)S * C, A, (flags & MMW_ANGLE_MAGNITUDE) != 0);   // both stages have a single-pass kernel
     // (the split kernel of the 32768-cell planes is latency bound at 2 waves per SIMD: on half the chip it is slower than
     //  the serial schedule -- 5.6 vs 5.3 us/frame at 12 x 512 x 64 -- so those planes stay serial)
-    const int want_pipe = env_int("MMW_CHAIN_PIPELINE", -1);
+    const int want_pipe = opt_int(ctx, "MMW_CHAIN_PIPELINE", -1);
     p.pipelined = !keep_rd && !ctx->pipe_unavailable &&
                   (want_pipe == 1 || (want_pipe == -1 && fused_shape && n_frames >= 2 * chunk_auto));
-    p.chunk = env_int("MMW_CHAIN_CHUNK", p.pipelined ? chunk_auto : 1024);
+    p.chunk = opt_int(ctx, "MMW_CHAIN_CHUNK", p.pipelined ? chunk_auto : 1024);
     p.chunk = std::max(1, std::min(p.chunk, std::min(n_frames, 65535)));          // 65535: grid.y of the angle kernel
     // Device-synchronised form (256 x 128 planes): needs the two disjoint CU sets, because persistent angle workgroups
     // that filled every CU would keep the range-Doppler workgroups they wait for from ever becoming resident.
@@ -900,11 +904,11 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // raw cubes: RAWIN variant of the 256 x 128 kernel, MODE 3 of the compile-time mixed-radix ones
     // (int16 raw cubes: the 256 x 128 producer only)
     const bool sync_shape = fused_rd_ok(S, C) || (!i16 && (raw ? rd_mixed_ct_raw_sync_supported(S, C) : rd_mixed_ct_supported(S, C)) &&
-                                                  !tune_int("MMW_NO_MIXED_CT", 0) && tune_int("MMW_MIXED_CT_SYNC", 1));
+                                                  !0 && 1);
     p.sync = allow_sync && p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
     // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
-    p.ring_frames = env_int("MMW_CHAIN_RING_FRAMES", (int)((120u << 20) / live_bytes));
+    p.ring_frames = (int)((120u << 20) / live_bytes);
     p.ring_frames = std::max(2, std::min(p.ring_frames, (int)CTL_RING_MAX));
     while ((size_t)p.ring_frames * V * S * C * sizeof(cplx<float>) >= ((size_t)1 << 31)) --p.ring_frames;   // 32-bit buffer offsets
     if (p.sync) p.chunk = n_frames;
@@ -934,7 +938,7 @@ static bool sync_slot_acquire(mmw_ctx *ctx) {
     }
     owner = ctx;
     g_sync_launching[ctx->device] = true;
-    if (const int ms = env_int("MMW_SYNC_SLOT_TEST_SLEEP_MS", 0)) {      // test hook: widen the window between acquire and launch
+    if (const int ms = opt_int(ctx, "MMW_SYNC_SLOT_TEST_SLEEP_MS", 0)) {      // test hook: widen the window between acquire and launch
         g_sync_mu.unlock();
         std::this_thread::sleep_for(std::chrono::milliseconds(ms));
         g_sync_mu.lock();
@@ -993,7 +997,7 @@ int chain_settle(mmw_ctx *ctx) {
     // counters are inconsistent (aborted workgroups leave without drawing their past-the-end ticket): fresh layout
     MMW_HIP(hipMemset(ctx->chain_ctl, 0, CTL_WORDS * sizeof(unsigned)));
     ctx->chain_layout[0] = 0;
-    if (env_int("MMW_CHAIN_NO_RERUN", 0))
+    if (opt_int(ctx, "MMW_CHAIN_NO_RERUN", 0))
         return set_error(MMW_ERR_HIP, "chain hand-off timed out on the device (output incomplete): the range-Doppler and angle "
                          "launches of the device-synchronised chain must run concurrently -- a tool that serialises kernel "
                          "dispatches (e.g. rocprofv3 --pmc) needs MMW_CHAIN_MODE=events");
@@ -1053,7 +1057,7 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     cs.v_live = v_live;
     cs.tiles = tiles;
     cs.n_frames = n_frames;
-    cs.timeout = (unsigned long long)std::max(1, env_int("MMW_CHAIN_TIMEOUT_MS", 2000)) * 100000ull;      // 100 MHz ticks
+    cs.timeout = (unsigned long long)std::max(1, opt_int(ctx, "MMW_CHAIN_TIMEOUT_MS", 2000)) * 100000ull;      // 100 MHz ticks
     // order of the RD work items inside a frame: plain cubes by antenna; raw cubes rx-major, so that the ntx planes that
     // de-interleave the same raw rows are handed out back to back (their second and third read come from cache)
     {
@@ -1068,15 +1072,15 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     cs.ntx = rv.ntx > 1 ? rv.ntx : 1;
     cs.nrx = rv.nrx;
     cs.i16 = rv.i16;
-    cs.naps_rd = std::max(0, env_int("MMW_SYNC_NAPS_RD", 32));
-    cs.naps_ang = std::max(0, env_int("MMW_SYNC_NAPS_ANG", 4));
+    cs.naps_rd = std::max(0, 32);
+    cs.naps_ang = std::max(0, 4);
     const int n_rd_items = n_frames * v_live, n_ang_items = n_frames * tiles;
     const bool fused = fused_rd_ok(S, C);
     int rd_grid = std::min(plan.rd_cus, n_rd_items);
     if (!fused)     // compile-time mixed-radix producer: several workgroups per CU where they fit
         MMW_TRY(launch_rd_mixed_ct(ctx, nullptr, 0, nullptr, n_rd_items, S, C, RawView{rv.ntx > 1 ? rv.ntx : 1, rv.nrx}, nullptr, plan.rd_cus,
                                    &rd_grid, true));
-    const int ang_grid = std::min((ctx->num_cu - plan.rd_cus) * std::max(1, tune_int("MMW_ANGLE_WGS_PER_CU", 3)), n_ang_items);
+    const int ang_grid = std::min((ctx->num_cu - plan.rd_cus) * std::max(1, 3), n_ang_items);
     hipStream_t main_stream = ctx->stream;
     MMW_HIP(hipEventRecord(ctx->pipe_begin, main_stream));
     MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_begin, 0));
@@ -1093,7 +1097,7 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     ctx->chain_rd_base += (unsigned)(n_rd_items + rd_grid);       // every workgroup draws one ticket past the end
     ctx->chain_ang_base += (unsigned)(n_ang_items + ang_grid);
     int rc;
-    if (env_int("MMW_CHAIN_DIAG_SKIP_RD", 0)) {
+    if (opt_int(ctx, "MMW_CHAIN_DIAG_SKIP_RD", 0)) {
         rc = MMW_OK;        // diagnostics: no producer -- the consumer's bounded spin must give up (tests of the abort path)
     } else {
         ctx->stream = ctx->q_rd;
@@ -1176,7 +1180,7 @@ static int chain3d_impl(mmw_ctx *ctx, const void *d_cubes, RawView rv, void *d_r
     MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_begin, 0));
     MMW_HIP(hipStreamWaitEvent(ctx->q_ang, ctx->pipe_begin, 0));
     MMW_HIP(hipStreamWaitEvent(ctx->q_ang2, ctx->pipe_begin, 0));
-    const int n_angq = env_int("MMW_ANGLE_QUEUES", 2) >= 2 ? 2 : 1;
+    const int n_angq = opt_int(ctx, "MMW_ANGLE_QUEUES", 2) >= 2 ? 2 : 1;
     // The ring slots of this call overlay those of the previous (possibly still running) chain call only if the
     // layout is the same; otherwise RD must not start before every earlier angle launch has read its slot.
     const size_t slot_bytes = (size_t)chunk * cube_bytes;
@@ -1399,7 +1403,7 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
     const int hr = train_r + guard_r, hd = train_d + guard_d;
     const long ntrain = (long)(2 * hr + 1) * (2 * hd + 1) - (long)(2 * guard_r + 1) * (2 * guard_d + 1);
     if (kind == MMW_CFAR_OS) MMW_REQUIRE(k_rank >= 1 && k_rank <= ntrain, "k_rank must be between 1 and %ld, got %d", ntrain, k_rank);
-    if (kind == MMW_CFAR_OS && !d_thr && !d_noise && d_mask && scale > 0.0 && !env_int("MMW_OS_SELECT", 0)) {
+    if (kind == MMW_CFAR_OS && !d_thr && !d_noise && d_mask && scale > 0.0 && !0) {
         // mask only: one count per cell under test instead of an order-statistic selection (k_cfar2d_os_mask)
         const int TW = OSM_TC + 2 * hd, TH = OSM_TR + 2 * hr, TWp = ((TW + 15) / 32) * 32 + 16;
         const size_t lds_m = (size_t)TH * TWp * sizeof(double);
@@ -1413,7 +1417,7 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
         }
     }
     MMW_REQUIRE(2 * hd + 1 <= 512, "Doppler window too wide for the exact summation order");
-    if (kind == MMW_CFAR_CA && !env_int("MMW_CA_SMALL_TILE", 0)) {
+    if (kind == MMW_CFAR_CA && !0) {
         // 32 x 32 tile (k_cfar2d_ca) while tile + halo + row-sum tables fit the default LDS limit
         const size_t th = CA_TR + 2 * hr, tw = CA_TC + 2 * hd;
         const size_t lds_ca = (th * tw + 2 * th * CA_TC) * sizeof(double);
@@ -1433,7 +1437,7 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
     size_t aux_os = npad * 8 + npad * 2 + ((n_tile + 1) & ~(size_t)1) * 2 + 16;         // keys, positions, ranks
     const size_t integ = (size_t)(OS_COARSE - 1) * (CFAR_TR + 2 * hr + 1) * (CFAR_TC + 2 * hd + 1) * 2;
     const bool os_fast = kind == MMW_CFAR_OS && npad <= 1024 && n_tile * sizeof(double) + aux_os + integ <= 64 * 1024 &&
-                         !env_int("MMW_OS_SLOW", 0);
+                         !0;
     if (os_fast) aux_os += integ;
     const size_t lds = n_tile * sizeof(double) + (kind == MMW_CFAR_OS ? aux_os : aux_ca);
     MMW_REQUIRE(kind != MMW_CFAR_OS || npad <= 32768, "OS-CFAR window too large");
@@ -1590,7 +1594,7 @@ static int rd_error_ulps(int S, int C) {
     const int structured = 8 + factors(S) + factors(C);
     const bool no_fused = env_int("MMW_NO_FUSED_RD", 0), no_mixed = env_int("MMW_NO_MIXED_RD", 0);
     if (!no_fused && (fused_rd_ok(S, C) || rd_lds_supported(S, C))) return structured;
-    if (!no_mixed && rd_mixed_ct_supported(S, C) && !tune_int("MMW_NO_MIXED_CT", 0)) return structured;
+    if (!no_mixed && rd_mixed_ct_supported(S, C) && !0) return structured;
     RdMixedPlan mp;
     if (!no_mixed && rd_mixed_plan(S, C, sizeof(cplx<float>), &mp))
         return structured + mp.s1 + mp.s2 + mp.c1 + mp.c2 + 2 * (mp.rad_s[0] + mp.rad_s[1] + mp.rad_c[0] + mp.rad_c[1]);
@@ -1614,7 +1618,7 @@ static int launch_argmax_refine(mmw_ctx *ctx, const RefineArgs &ra) {
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_argmax_refine_whole), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (ra.n_split > 0) {
-        const int units = std::min(ra.n_split, std::max(1, tune_int("MMW_REFINE_GRID", 512)));
+        const int units = std::min(ra.n_split, std::max(1, 512));
         hipLaunchKernelGGL(k_argmax_refine_part, dim3(ra.parts, units), dim3(256), lds, ctx->stream, ra);
         MMW_TRY(check_launch("argmax_refine_part"));
         hipLaunchKernelGGL(k_argmax_refine_finish, dim3(std::min((ra.n_split + 3) / 4, ctx->num_cu)), dim3(256), 0, ctx->stream, ra);
@@ -1630,8 +1634,6 @@ static int launch_argmax_refine(mmw_ctx *ctx, const RefineArgs &ra) {
 // Slices per plane sum: a few flagged evaluations per hundred frames are expected, and ~1000 workgroups of the slice
 // kernel are resident at once: 16 slices (latency of the single task), fewer and longer ones for very large batches.
 static int refine_parts(int n_frames) {
-    const int want = tune_int("MMW_REFINE_PARTS_RT", 0);
-    if (want > 0) return std::min(want, (int)REFINE_PARTS);
     int p = REFINE_PARTS;
     while (p > 2 && (long)p * n_frames > 60000) p /= 2;
     return p;
@@ -1681,7 +1683,7 @@ int mmw_angle_argmax_exact(mmw_ctx *ctx, const void *d_cubes, const float *d_l1,
     const void *twA = nullptr;
     MMW_TRY(get_table<float>(ctx, TAB_TWIDDLE, A, &twA));
     const int list_cap = n_frames * cap;
-    const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));   // flagged detections whose
+    const int n_split = std::min(list_cap, std::max(0, opt_int(ctx, "MMW_REFINE_SPLIT", 32768)));   // flagged detections whose
                                                                                           // plane sums are split over workgroups
     // Dense refinement (mmw_cells64.h): when many evaluations are flagged -- noise-level detections, e.g. the GUI's OS-CFAR --
     // the float64 cells of a whole frame come from one Doppler FFT per sample row + 256-term range sums instead of one
@@ -1807,7 +1809,7 @@ DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, i
     const long n = (long)S * C;
     const int hr = tr + gr, hd = td + gd;
     if (kind != MMW_CFAR_CA || n_az > DET_MAX_ANT || n_el > DET_MAX_ANT || n > (1L << 20) || A < 1 || A > 1024) return p;
-    if (tune_int("MMW_NO_DETECT_SCREEN", 0)) return p;
+    if (0) return p;
     p.words = (int)((n + 31) / 32);
     p.lds_cell = cell_exact_lds(S, C, 2 * hr + 1, 2 * hd + 1);
     if (p.lds_cell > 64 * 1024) return p;
@@ -1880,7 +1882,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const int cell_cap = std::max(4096, 16 * n_frames);
     const int list_cap = n_frames * cap;
-    const int n_split = std::min(list_cap, std::max(0, env_int("MMW_REFINE_SPLIT", 32768)));
+    const int n_split = std::min(list_cap, std::max(0, opt_int(ctx, "MMW_REFINE_SPLIT", 32768)));
     const size_t b_ctl = up(DCTL_WORDS * sizeof(int)), b_ff = up((size_t)n_frames * sizeof(int)),
                  b_cells = up((size_t)cell_cap * 2 * sizeof(int)), b_bits = up((size_t)n_frames * (2 * DET_SPEC + 1) * sizeof(int));      // (speculative slots of the frames with undecided cells)
     const int list_cap2 = (int)std::min<long>(2L * list_cap, 0x7fffffffL);      // both lists flag into one
@@ -1943,7 +1945,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.scale = scale;
     // the screening band always uses the full worst-case bound (MMW_DETECT_BAND_MULT widens it: test hook that sends more
     // cells through the float64 decision, or -- when huge -- whole frames back to the caller)
-    a.k_fft = (float)ulps * eps * (float)std::max(1, env_int("MMW_DETECT_BAND_MULT", 1));
+    a.k_fft = (float)ulps * eps * (float)std::max(1, opt_int(ctx, "MMW_DETECT_BAND_MULT", 1));
     a.A = A;
     a.shift_az = shift_az;
     a.shift_el = shift_el;
@@ -2277,12 +2279,13 @@ int mmw_diag_czt_runs(const double *h_freq, int M, int n_used, int *h_runs, int 
 }
 
 int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops) {
-    MMW_REQUIRE(ctx && tflops && kind >= 0 && kind <= 5, "bad argument");
+    MMW_REQUIRE(ctx && tflops && kind >= 0 && kind <= 7, "bad argument");
     MMW_JOIN(ctx);
     MMW_TRY(ensure_scratch(ctx, 256));
     // kinds 4 / 5: kinds 2 / 3 (vector FMAs between the MFMAs) with ONE wave per SIMD
-    const int iters = 1 << 15, wgs = ctx->num_cu * (kind >= 4 ? 1 : 2);            // 8 waves per CU = 2 per SIMD
-    if (kind >= 4) kind -= 2;
+    // kinds 6 / 7: v_mfma_f32_32x32x16_bf16 alone / with 8 float32 FMAs after every MFMA (two waves per SIMD)
+    const int iters = 1 << 15, wgs = ctx->num_cu * (kind == 4 || kind == 5 ? 1 : 2);            // 8 waves per CU = 2 per SIMD
+    if (kind == 4 || kind == 5) kind -= 2;
     hipLaunchKernelGGL(k_diag_mfma, dim3(wgs), dim3(256), 0, ctx->stream, (float *)ctx->scratch, 256, kind);    // warm-up
     MMW_HIP(hipEventRecord(ctx->t0, ctx->stream));
     hipLaunchKernelGGL(k_diag_mfma, dim3(wgs), dim3(256), 0, ctx->stream, (float *)ctx->scratch, iters, kind);
@@ -2291,7 +2294,7 @@ int mmw_diag_mfma_peak(mmw_ctx *ctx, int kind, double *tflops) {
     MMW_HIP(hipEventSynchronize(ctx->t1));
     float ms = 0.f;
     MMW_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
-    const double flops_per_mfma = kind != 1 ? 2.0 * 32 * 32 * 2 : 2.0 * 16 * 16 * 4;
+    const double flops_per_mfma = kind >= 6 ? 2.0 * 32 * 32 * 16 : kind != 1 ? 2.0 * 32 * 32 * 2 : 2.0 * 16 * 16 * 4;
     *tflops = (double)wgs * 4 * iters * 4 * flops_per_mfma / (ms * 1e-3) / 1e12;
     return MMW_OK;
 }

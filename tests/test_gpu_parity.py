@@ -455,9 +455,8 @@ def test_bartlett_mfma_vs_oracle_shapes(S, E, naz, nel):
 
 def test_bartlett_both_contraction_paths():
     """The steering-matrix contraction has two kernels: the fused tile kernel (small problems: steering evaluated in the
-    kernel) and the LDS-tiled GEMM behind k_steer (large ones).  A problem big enough for the second by default, and --
-    in fresh processes, the knob is read once -- the small shapes forced through each path and through the polynomial
-    sine / cosine variant of the tile kernel."""
+    kernel) and the LDS-tiled GEMM behind k_steer (large ones).  A problem big enough for the second by default, and the small
+    shapes forced through each path and through the polynomial sine / cosine variant of the tile kernel (context options)."""
     from mmwave_radar_processing_amd.processors.steering_beamformers import SyntheticArrayBeamformerCore
     rng = np.random.default_rng(77)
     S, E = 512, 128
@@ -468,25 +467,24 @@ def test_bartlett_both_contraction_paths():
     out = SyntheticArrayBeamformerCore(az, el, lam).contract(X, P)
     for f in range(3):
         assert rel_err(out[f], O.bartlett_response(X[f].astype(complex), P[f], O.steering_dirs(az, el), lam)) <= SPEC_TOL
-    import subprocess, sys
-    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
-            "from oracle import oracle_np as O\n"
-            "from mmwave_radar_processing_amd.processors.steering_beamformers import SyntheticArrayBeamformerCore\n"
-            "lam = 299792458.0 / 77e9; worst = 0.0\n"
-            "for S, E, naz, nel in ((256, 256, 60, 1), (128, 100, 33, 3), (70, 37, 5, 2)):\n"
-            "    rng = np.random.default_rng(S + E)\n"
-            "    X = (rng.standard_normal((2, S, E)) + 1j * rng.standard_normal((2, S, E))).astype(np.complex64)\n"
-            "    P = rng.uniform(-0.05, 0.05, (2, 3, E))\n"
-            "    az, el = np.linspace(-1.2, 1.2, naz), np.linspace(-0.4, 0.4, nel)\n"
-            "    out = SyntheticArrayBeamformerCore(az, el, lam).contract(X, P)\n"
-            "    for f in range(2):\n"
-            "        ref = O.bartlett_response(X[f].astype(complex), P[f], O.steering_dirs(az, el), lam)\n"
-            "        worst = max(worst, float(np.abs(out[f] - ref).max() / np.abs(ref).max()))\n"
-            "print(worst)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for knobs in ({"MMW_BARTLETT_PATH": "2"}, {"MMW_BARTLETT_PATH": "1"}, {"MMW_BARTLETT_PATH": "1", "MMW_BARTLETT_POLY": "1"}):
-        run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **knobs), timeout=300)
-        assert run.returncode == 0, run.stderr
-        worst = float(run.stdout.strip().splitlines()[-1])
+    ctx = _lib.default_context()
+    for knobs in ({"MMW_BARTLETT_PATH": 2}, {"MMW_BARTLETT_PATH": 1}, {"MMW_BARTLETT_PATH": 1, "MMW_BARTLETT_POLY": 1}):
+        for k, v in knobs.items():
+            ctx.set_option(k, v)
+        try:
+            worst = 0.0
+            for S2, E2, naz, nel in ((256, 256, 60, 1), (128, 100, 33, 3), (70, 37, 5, 2)):
+                rng2 = np.random.default_rng(S2 + E2)
+                X2 = (rng2.standard_normal((2, S2, E2)) + 1j * rng2.standard_normal((2, S2, E2))).astype(np.complex64)
+                P2 = rng2.uniform(-0.05, 0.05, (2, 3, E2))
+                az2, el2 = np.linspace(-1.2, 1.2, naz), np.linspace(-0.4, 0.4, nel)
+                out2 = SyntheticArrayBeamformerCore(az2, el2, lam, ctx=ctx).contract(X2, P2)
+                for f in range(2):
+                    ref = O.bartlett_response(X2[f].astype(complex), P2[f], O.steering_dirs(az2, el2), lam)
+                    worst = max(worst, float(np.abs(out2[f] - ref).max() / np.abs(ref).max()))
+        finally:
+            for k in knobs:
+                ctx.set_option(k, None)
         print(f"bartlett {knobs}: worst deviation {worst:.2e} of the peak")
         assert worst <= SPEC_TOL
 
@@ -2002,21 +2000,15 @@ def test_non_finite_sample_in_an_end_antenna_is_the_one_documented_divergence(mo
     d_in.upload(cube)
     _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, 1, V, S, C, A, 0))
     assert rel_err(d_out.download((A, S, C), np.complex64), ref) <= SPEC_TOL        # ... and equals the clean cube's result
-    monkeypatch.setenv("MMW_CHAIN_SKIP_ENDS", "0")
-    monkeypatch.setenv("MMW_ANGLE_ZE", "0")
-    if True:
-        # (the knobs are read once per process; in a fresh process they restore the reference's behaviour)
-        import subprocess, sys
-        code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
-                "from mmwave_radar_processing_amd import _lib, synth\n"
-                "ctx = _lib.default_context(); V, S, C, A = 12, 256, 128, 64\n"
-                "d_in, d_out = ctx.alloc(V*S*C*8), ctx.alloc(A*S*C*8)\n"
-                "cube = synth.synth_cube(3).copy(); cube[0, 17, 9] = np.inf; d_in.upload(cube)\n"
-                "_lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, 1, V, S, C, A, 0))\n"
-                "print(int(np.isfinite(d_out.download((A, S, C), np.complex64)).sum()))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ), timeout=300)
-        assert out.returncode == 0, out.stderr
-        assert int(out.stdout.strip().splitlines()[-1]) == 0
+    # the two switches of this context restore the reference's behaviour: every plane transformed and loaded, 0 * inf = NaN
+    ctx.set_option("MMW_CHAIN_SKIP_ENDS", 0)
+    ctx.set_option("MMW_ANGLE_ZE", 0)
+    try:
+        _lib.check(ctx.lib.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, 1, V, S, C, A, 0))
+        assert int(np.isfinite(d_out.download((A, S, C), np.complex64)).sum()) == 0
+    finally:
+        ctx.set_option("MMW_CHAIN_SKIP_ENDS", None)
+        ctx.set_option("MMW_ANGLE_ZE", None)
     for b in (d_in, d_out, d_rd):
         b.free()
 
