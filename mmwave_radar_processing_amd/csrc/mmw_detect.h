@@ -198,10 +198,9 @@ __device__ __forceinline__ float key_mag(unsigned k) {
 // wk (one_bin: A == 64, the lane's only bin is k = lane): W_A^(i lane), i < DET_MAX_ANT, held in registers by the caller for
 // the whole frame -- the table walk (an LDS read and three index instructions per antenna) was a third of an evaluation.
 template <int NMAX>
-__device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const float2 *tw, float2 xl, float l1v, int base, int n,
+__device__ __forceinline__ void detect_argmax_list(int A, int *ctl_el, const float2 *tw, float2 xl, float l1v, int base, int n,
                                                    int shift, int32_t *out_idx, const ArgmaxRefine &rf, long slot, int lane, int tag,
                                                    const float2 (&wk)[DET_MAX_ANT], bool one_bin) {
-    const int A = a.A;
     float xr[NMAX], xi[NMAX], e[NMAX], be = 0.f, sum_abs = 0.f;
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
@@ -305,7 +304,8 @@ __device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const fl
         if (flag) {                                 // both lists share one refinement list
             const int pos = atomicAdd(rf.n_flag, 1);
             if (pos < rf.list_cap) rf.list[pos] = (int)slot | tag;
-            if (tag) atomicAdd(a.ctl + DCTL_EL, 1);
+            if (rf.flagpos && pos < rf.dense_cap) rf.flagpos[slot] = pos + 1;
+            if (tag) atomicAdd(ctl_el, 1);
         }
     }
 }
@@ -313,8 +313,68 @@ __device__ __forceinline__ void detect_argmax_list(const DetectArgs &a, const fl
 __device__ __forceinline__ void detect_argmax_lanes(const DetectArgs &a, const float2 *tw, float2 xl, float l1v, int base, int n,
                                                     int shift, int32_t *out_idx, const ArgmaxRefine &rf, long slot, int lane,
                                                     int tag, const float2 (&wk)[DET_MAX_ANT], bool one_bin) {
-    if (n <= 4) detect_argmax_list<4>(a, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag, wk, one_bin);
-    else detect_argmax_list<DET_MAX_ANT>(a, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag, wk, one_bin);
+    if (n <= 4) detect_argmax_list<4>(a.A, a.ctl + DCTL_EL, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag, wk, one_bin);
+    else detect_argmax_list<DET_MAX_ANT>(a.A, a.ctl + DCTL_EL, tw, xl, l1v, base, n, shift, out_idx, rf, slot, lane, tag, wk, one_bin);
+}
+
+// The stand-alone float32 argmax of mmw_angle_argmax_exact for lists of up to DET_MAX_ANT antennas, on the routine above (one
+// wave per detection, its cells in lanes, DPP reductions, W_A^m in the LDS, per-lane twiddles in registers, PD detections of
+// look-ahead).  k_angle_argmax (mmw_misc.h: cells n-fold in every lane's registers, global twiddle reads, shuffle butterflies)
+// took 1.16 us per 256 x 128 frame of ~470 OS-CFAR detections for the azimuth list alone.
+template <int NMAX>
+__global__ __launch_bounds__(256) void k_angle_argmax_lanes(const float2 *rd, const int32_t *dets, const int32_t *counts, int32_t *out_idx,
+                                                             int V, int S, int C, int cap, AntList ants, int A, int shift, const float2 *twA,
+                                                             ArgmaxRefine rf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *tw = reinterpret_cast<float2 *>(smem);          // [A]
+    __shared__ int tab[DET_MAX_ANT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < A; i += 256) tw[i] = twA[i];
+    if (tid == 0) {
+        static_for<DET_MAX_ANT>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            tab[i] = ants.idx[i];
+        });
+    }
+    __syncthreads();
+    const long f = blockIdx.y;
+    int n_det = counts[f];
+    if (n_det > cap) n_det = cap;
+    const int n = ants.n;
+    const bool mine = lane < n;
+    const long ant = mine ? tab[lane] : 0;
+    const float l1v = (mine && rf.l1) ? rf.l1[f * V + ant] : 0.f;
+    const float2 *plane = rd + (f * V + ant) * (long)S * C;
+    const bool one_bin = A == 64;
+    float2 wk[DET_MAX_ANT];
+    {
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < DET_MAX_ANT; ++i) {
+            wk[i] = one_bin ? tw[t] : make_float2(0.f, 0.f);
+            t = (t + lane) & 63;
+        }
+    }
+    const int stride = gridDim.x * 4;
+    auto fetch = [&](int det) {
+        float2 v = make_float2(0.f, 0.f);
+        if (det < n_det && mine) {
+            const long slot = f * cap + det;
+            v = plane[(long)dets[slot * 2] * C + dets[slot * 2 + 1]];
+        }
+        return v;
+    };
+    constexpr int PD = 4;
+    float2 q[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) q[i] = fetch(blockIdx.x * 4 + wave + i * stride);
+    for (int det = blockIdx.x * 4 + wave; det < n_det; det += stride) {
+        const float2 xl = q[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PD; ++i) q[i] = q[i + 1];
+        q[PD - 1] = fetch(det + PD * stride);
+        detect_argmax_list<NMAX>(A, nullptr, tw, xl, l1v, 0, n, shift, out_idx, rf, f * cap + det, lane, 0, wk, one_bin);
+    }
 }
 
 // Ordered compaction of the frame's bit mask (bit r * C + c, LDS) into dets / counts, then the angle argmax of every

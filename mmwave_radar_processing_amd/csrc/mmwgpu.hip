@@ -1528,6 +1528,16 @@ static void launch_angle_argmax(mmw_ctx *ctx, dim3 grid, const float2 *rd, const
                                 const float2 *twA, const ArgmaxRefine &rf) {
 #define MMW_ARGMAX(NA) \
     hipLaunchKernelGGL(k_angle_argmax<NA>, grid, dim3(256), 0, ctx->stream, rd, dets, counts, idx, V, S, C, cap, ants, A, shift, twA, rf)
+    // lists of up to 8 antennas with the error bound: the lane-resident routine of the fused detection stage
+    if (rf.l1 && ants.n <= DET_MAX_ANT && A <= 1024) {
+        if (ants.n <= 4)
+            hipLaunchKernelGGL(k_angle_argmax_lanes<4>, grid, dim3(256), (size_t)A * 8, ctx->stream, rd, dets, counts, idx, V, S, C, cap, ants, A,
+                               shift, twA, rf);
+        else
+            hipLaunchKernelGGL(k_angle_argmax_lanes<DET_MAX_ANT>, grid, dim3(256), (size_t)A * 8, ctx->stream, rd, dets, counts, idx, V, S, C,
+                               cap, ants, A, shift, twA, rf);
+        return;
+    }
     if (ants.n <= 4) MMW_ARGMAX(4);
     else if (ants.n <= 8) MMW_ARGMAX(8);
     else if (ants.n <= 16) MMW_ARGMAX(16);

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--splits", default="32,64,96")
     ap.add_argument("--naps", default="4")
+    ap.add_argument("--mag32", action="store_true", help="also ask for the float32 |RD| plane of antenna 0 (as bench.py does)")
     ap.add_argument("--clocks", action="store_true", help="phase clocks of consumer workgroup 0 (stderr) instead of timings")
     args = ap.parse_args()
     F, reps = args.frames, args.reps
@@ -37,9 +38,10 @@ def main():
     el4, n_el = _lib.int_array(range(8, 12))
     alpha = 144 * (1e-5 ** (-1.0 / 144) - 1.0)
     stats = (_lib.C.c_int * 5)()
+    d_m32 = ctx.alloc(F * S * C * 4) if args.mag32 else None
 
     def run(st=None):
-        _lib.check(L.mmw_detect_points(ctx.handle, d_in.ptr, d_rd.ptr, d_l1.ptr, None, d_dets.ptr, d_cnt.ptr, d_az.ptr, d_el.ptr, F,
+        _lib.check(L.mmw_detect_points(ctx.handle, d_in.ptr, d_rd.ptr, d_l1.ptr, d_m32.ptr if d_m32 else None, d_dets.ptr, d_cnt.ptr, d_az.ptr, d_el.ptr, F,
                                        V, S, C, 0, 4, 4, 2, 2, alpha, 0, cap, az8, n_az, 1, el4, n_el, 0, A, st))
 
     def measure(tag):
