@@ -314,7 +314,7 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
     // small batches: split K over workgroups until about half the chip is busy (each part at least two K steps)
     const long wgs = (long)((T + CG_TN - 1) / CG_TN) * ((S + CG_TM - 1) / CG_TM) * n_frames;
     int ksplit = 1;
-    if (wgs * 2 <= ctx->num_cu && E >= 4 * CG_TK && !0)
+    if (wgs * 2 <= ctx->num_cu && E >= 4 * CG_TK)
         ksplit = (int)std::min<long>(std::min<long>(16, E / (2 * CG_TK)), ctx->num_cu / (2 * wgs));
     if (ksplit < 2) ksplit = 1;
     const int kc = ksplit > 1 ? ((E + ksplit - 1) / ksplit + CG_TK - 1) / CG_TK * CG_TK : E;
@@ -732,7 +732,7 @@ inline int capon(mmw_ctx *ctx, const void *d_X, const double *h_thetas, float *d
     const int n_bins = n_frames * R;
     // sixteen waves per CU (four per SIMD), each wave walking its share of the bins
     const long want = ((long)n_bins + 3) / 4;
-    const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 4 * std::max(1, 1));
+    const int grid = (int)std::min<long>(want, (long)ctx->num_cu * 4);
     const int lds = CAPON2_UTAB * 16 + 4 * CAPON2_WAVE_LDS;
     if ((long)n_frames * R >= (1L << 31)) return set_error(MMW_ERR_INVALID, "capon: more than 2^31 range bins in one call");
     auto kern = (K & 31) == 0 ? (V <= 4 ? k_capon_sweep<1, true> : V <= 8 ? k_capon_sweep<2, true> : V <= 12 ? k_capon_sweep<3, true>

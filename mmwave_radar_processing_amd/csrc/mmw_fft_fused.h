@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, (VIN == 12 && ZE && !MAG && !ROWS) || VIN <= 4
 
 // even bin counts whose rows are not 64-B aligned take the row-window kernels
 inline bool angle_rows_needed(long bins, bool mag) {
-    return bins % 2 == 0 && bins % angle_rows_unit(mag) != 0 && 1 != 0;
+    return bins % 2 == 0 && bins % angle_rows_unit(mag) != 0;
 }
 inline int angle_rows_waves(long bins, bool mag) {      // waves per frame: the last window must reach the row end for every m
     const int U = angle_rows_unit(mag);
@@ -350,7 +350,7 @@ int launch_angle64(mmw_ctx *ctx, const void *rd, void *out, int F, long bins, bo
     for (int i = 0; i < 16; ++i) w.h[i] = i < VIN ? h[i] : 0.f;
     const long pairs = bins / 2;
     dim3 grid((unsigned)((pairs + 255) / 256), (unsigned)F);
-    const bool nt = 1 != 0;
+    const bool nt = true;
     const bool ze = VIN > 2 && h[0] == 0.f && h[VIN - 1] == 0.f && opt_int(ctx, "MMW_ANGLE_ZE", 1) != 0;
     if (bins % 2) {         // angle_fast_path admits odd bin counts only for complex output
         const int n_waves = (int)((bins + 15 + 111) / 112);
@@ -1250,7 +1250,7 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
     // chain the one-plane-per-workgroup kernel is faster (measured), so the chain sets active_cus and gets it.
     const int pf = ctx->active_cus > 0 ? 0 : 8;
     if (pf == 8 && rv.vskip <= 2) {
-        int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu) * 1;
+        int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu);
         if (grid > planes) grid = planes;
         auto launch = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);

@@ -515,7 +515,7 @@ template <typename T, bool MAG>
 int launch_rd_mixed(mmw_ctx *ctx, const void *d_in, long in_plane_stride, void *d_out, int planes, int S, int C,
                     RawView rv = RawView{1, 0}) {
     if constexpr (sizeof(T) == 4 && !MAG)
-        if (rd_mixed_ct_supported(S, C) && !0)
+        if (rd_mixed_ct_supported(S, C))
             return launch_rd_mixed_ct(ctx, d_in, in_plane_stride, d_out, planes, S, C, rv);
     RdMixedPlan pl;
     if (!rd_mixed_plan(S, C, sizeof(cplx<T>), &pl))

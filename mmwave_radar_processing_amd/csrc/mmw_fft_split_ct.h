@@ -294,7 +294,7 @@ int launch_rd_split4_ct_sc(mmw_ctx *ctx, const void *d_in, void *d_out, int plan
 bool rd_split_ct_supported(int S, int C) {
 #define X(s, c) if (S == s && C == c) return true;
     MMW_SPLIT_CT_SHAPES(X)
-    if (!0) { MMW_SPLIT4_CT_SHAPES(X) }
+    MMW_SPLIT4_CT_SHAPES(X)
 #undef X
     return false;
 }

@@ -452,10 +452,9 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
         bool l1_done = false;
         // int16 raw cubes: folded into the loads of the 256 x 128 kernel and of the compile-time mixed-radix kernels (the
         // plane shapes of every shipped cfg); anything else converts + de-interleaves first (one extra pass)
-        const bool i16_folded = rv.i16 && rv.ntx > 1 && !0 &&
+        const bool i16_folded = rv.i16 && rv.ntx > 1 &&
                                 ((fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0)) ||
-                                 (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0) && !0 &&
-                                  !(rd_lds_supported(S, C) && 0)));
+                                 (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0)));
         if (rv.i16 && !i16_folded) {
             MMW_REQUIRE(rv.ntx >= 1 && rv.nrx >= 1, "int16 cubes are raw cubes");
             const long total = (long)n_frames * V * S * C;
@@ -469,9 +468,9 @@ static int range_doppler_impl(mmw_ctx *ctx, const void *d_cubes, void *d_out, vo
         }
         if (fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0))
             MMW_TRY(launch_rd_fused(ctx, d_cubes, d_out, n_frames * V, S, C, rv, rv.ntx > 1 ? nullptr : d_l1, &l1_done));
-        else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && !(rd_mixed_ct_supported(S, C) && !0))      // the compile-time kernel is faster where both exist (64 x 64: 6.0 vs 4.4 TB/s)
+        else if (rd_lds_supported(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && !rd_mixed_ct_supported(S, C))      // the compile-time kernel is faster where both exist (64 x 64: 6.0 vs 4.4 TB/s)
             MMW_TRY(launch_rd_lds(ctx, d_cubes, d_out, n_frames * V, S, C, rv));
-        else if (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0) && !0) {
+        else if (rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0)) {
             // compile-time kernel; on virtual-array cubes it also leaves the planes' L1 norms when asked
             float *l1 = rv.ntx > 1 ? nullptr : d_l1;
             MMW_TRY(launch_rd_mixed_ct(ctx, d_cubes, (long)S * C, d_out, n_frames * V, S, C, rv, nullptr, 0, nullptr, false, l1));
@@ -835,7 +834,7 @@ static int ensure_pipe_queues(mmw_ctx *ctx, int rd_cus) {
 // Does the angle stage of this call run k_angle64's ZE variant (planes 0 and V-1 never loaded)?
 static bool angle_fast_path(int V, long bins, int A, bool mag) {      // per launch of at most 65535 frames
     // odd bin counts: complex output only (k_angle64_rows_odd)
-    return A == 64 && (bins % 2 == 0 || (!mag && 1)) && !env_int("MMW_NO_FUSED_ANGLE", 0) && (V == 4 || V == 8 || V == 12 || V == 16);
+    return A == 64 && (bins % 2 == 0 || !mag) && !env_int("MMW_NO_FUSED_ANGLE", 0) && (V == 4 || V == 8 || V == 12 || V == 16);
 }
 static bool angle_skips_end_planes(const mmw_ctx *ctx, int V, long bins, int A, int flags) {
     return angle_fast_path(V, bins, A, (flags & MMW_ANGLE_MAGNITUDE) != 0) && V > 2 && !(flags & MMW_ANGLE_NO_WINDOW) &&
@@ -903,8 +902,7 @@ static ChainPlan chain_plan(const mmw_ctx *ctx, bool keep_rd, bool raw, int n_fr
     // (windowed chains only: the un-windowed angle variants of the persistent kernel exceed its register budget)
     // raw cubes: RAWIN variant of the 256 x 128 kernel, MODE 3 of the compile-time mixed-radix ones
     // (int16 raw cubes: the 256 x 128 producer only)
-    const bool sync_shape = fused_rd_ok(S, C) || (!i16 && (raw ? rd_mixed_ct_raw_sync_supported(S, C) : rd_mixed_ct_supported(S, C)) &&
-                                                  !0 && 1);
+    const bool sync_shape = fused_rd_ok(S, C) || (!i16 && (raw ? rd_mixed_ct_raw_sync_supported(S, C) : rd_mixed_ct_supported(S, C)));
     p.sync = allow_sync && p.pipelined && sync_shape && p.rd_cus > 0 && p.vskip > 2 && !(mode && !std::strcmp(mode, "events"));
     // ring: ~120 MB of live planes (48 frames at 10 x 256 x 128): the ring and the streaming traffic around it share the
     // 256 MB Infinity Cache; 40-64 frames measured equal, 96 was 8 % slower
@@ -1080,7 +1078,7 @@ static int chain3d_sync(mmw_ctx *ctx, const ChainPlan &plan, const void *d_cubes
     if (!fused)     // compile-time mixed-radix producer: several workgroups per CU where they fit
         MMW_TRY(launch_rd_mixed_ct(ctx, nullptr, 0, nullptr, n_rd_items, S, C, RawView{rv.ntx > 1 ? rv.ntx : 1, rv.nrx}, nullptr, plan.rd_cus,
                                    &rd_grid, true));
-    const int ang_grid = std::min((ctx->num_cu - plan.rd_cus) * std::max(1, 3), n_ang_items);
+    const int ang_grid = std::min((ctx->num_cu - plan.rd_cus) * 3, n_ang_items);
     hipStream_t main_stream = ctx->stream;
     MMW_HIP(hipEventRecord(ctx->pipe_begin, main_stream));
     MMW_HIP(hipStreamWaitEvent(ctx->q_rd, ctx->pipe_begin, 0));
@@ -1403,7 +1401,7 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
     const int hr = train_r + guard_r, hd = train_d + guard_d;
     const long ntrain = (long)(2 * hr + 1) * (2 * hd + 1) - (long)(2 * guard_r + 1) * (2 * guard_d + 1);
     if (kind == MMW_CFAR_OS) MMW_REQUIRE(k_rank >= 1 && k_rank <= ntrain, "k_rank must be between 1 and %ld, got %d", ntrain, k_rank);
-    if (kind == MMW_CFAR_OS && !d_thr && !d_noise && d_mask && scale > 0.0 && !0) {
+    if (kind == MMW_CFAR_OS && !d_thr && !d_noise && d_mask && scale > 0.0) {
         // mask only: one count per cell under test instead of an order-statistic selection (k_cfar2d_os_mask)
         const int TW = OSM_TC + 2 * hd, TH = OSM_TR + 2 * hr, TWp = ((TW + 15) / 32) * 32 + 16;
         const size_t lds_m = (size_t)TH * TWp * sizeof(double);
@@ -1417,7 +1415,7 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
         }
     }
     MMW_REQUIRE(2 * hd + 1 <= 512, "Doppler window too wide for the exact summation order");
-    if (kind == MMW_CFAR_CA && !0) {
+    if (kind == MMW_CFAR_CA) {
         // 32 x 32 tile (k_cfar2d_ca) while tile + halo + row-sum tables fit the default LDS limit
         const size_t th = CA_TR + 2 * hr, tw = CA_TC + 2 * hd;
         const size_t lds_ca = (th * tw + 2 * th * CA_TC) * sizeof(double);
@@ -1436,8 +1434,7 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
     const size_t aux_ca = 2 * (size_t)(CFAR_TR + 2 * hr) * CFAR_TC * sizeof(double);     // row-sum tables
     size_t aux_os = npad * 8 + npad * 2 + ((n_tile + 1) & ~(size_t)1) * 2 + 16;         // keys, positions, ranks
     const size_t integ = (size_t)(OS_COARSE - 1) * (CFAR_TR + 2 * hr + 1) * (CFAR_TC + 2 * hd + 1) * 2;
-    const bool os_fast = kind == MMW_CFAR_OS && npad <= 1024 && n_tile * sizeof(double) + aux_os + integ <= 64 * 1024 &&
-                         !0;
+    const bool os_fast = kind == MMW_CFAR_OS && npad <= 1024 && n_tile * sizeof(double) + aux_os + integ <= 64 * 1024;
     if (os_fast) aux_os += integ;
     const size_t lds = n_tile * sizeof(double) + (kind == MMW_CFAR_OS ? aux_os : aux_ca);
     MMW_REQUIRE(kind != MMW_CFAR_OS || npad <= 32768, "OS-CFAR window too large");
@@ -1604,7 +1601,7 @@ static int rd_error_ulps(int S, int C) {
     const int structured = 8 + factors(S) + factors(C);
     const bool no_fused = env_int("MMW_NO_FUSED_RD", 0), no_mixed = env_int("MMW_NO_MIXED_RD", 0);
     if (!no_fused && (fused_rd_ok(S, C) || rd_lds_supported(S, C))) return structured;
-    if (!no_mixed && rd_mixed_ct_supported(S, C) && !0) return structured;
+    if (!no_mixed && rd_mixed_ct_supported(S, C)) return structured;
     RdMixedPlan mp;
     if (!no_mixed && rd_mixed_plan(S, C, sizeof(cplx<float>), &mp))
         return structured + mp.s1 + mp.s2 + mp.c1 + mp.c2 + 2 * (mp.rad_s[0] + mp.rad_s[1] + mp.rad_c[0] + mp.rad_c[1]);

@@ -1652,7 +1652,8 @@ def _same_points(got, ref):
         np.testing.assert_array_equal(el[f, :k], el_r[f, :k])
 
 
-@pytest.mark.parametrize("shape,frames", [((12, 256, 128), 160), ((12, 63, 100), 400), ((8, 64, 32), 300), ((12, 254, 50), 64)])
+@pytest.mark.parametrize("shape,frames", [((12, 256, 128), 160), ((12, 63, 100), 400), ((8, 64, 32), 300), ((12, 254, 50), 64),
+                                          ((12, 512, 128), 24), ((4, 127, 32), 96), ((8, 63, 127), 48)])
 def test_detect_points_screening_equals_the_float64_path(shape, frames, monkeypatch):
     """mmw_detect_points (float32 screening with the worst-case error band + float64 decision of the undecided cells)
     against mmw_detect_batch + mmw_angle_argmax_exact on the same resident cubes: counts, detections (values and order)

@@ -182,7 +182,8 @@ def main():
     res["mfma_peak_measured_TFLOPs"] = {k: round(v, 1) for k, v in peak.items()}
     probe = {}
     for kind, name in ((2, "8_fma_per_mfma_2_waves_per_simd"), (3, "16_fma_per_mfma_2_waves_per_simd"),
-                       (4, "8_fma_per_mfma_1_wave_per_simd"), (5, "16_fma_per_mfma_1_wave_per_simd")):
+                       (4, "8_fma_per_mfma_1_wave_per_simd"), (5, "16_fma_per_mfma_1_wave_per_simd"),
+                       (6, "bf16_mfma_alone_2_waves_per_simd"), (7, "bf16_mfma_8_fma_per_mfma_2_waves_per_simd")):
         v = ct.c_double(0)
         _lib.check(L.mmw_diag_mfma_peak(ctx.handle, kind, ct.byref(v)))
         probe[name] = round(v.value, 1)
@@ -226,7 +227,8 @@ def main():
         if key in res:
             res[key]["us_per_frame"] = round(1e3 * res[key]["ms"] / Fc, 3)
             res[key]["TFLOPs_useful"] = round(flops / (res[key]["ms"] * 1e-3) / 1e12, 2)
-            res[key]["frac_of_f64_mfma_peak"] = round(res[key]["TFLOPs_useful"] / peak["f64"], 3)
+            res[key]["frac_of_f64_mfma_peak"] = round(res[key]["TFLOPs_useful"] / peak["f64"], 3)       # measured instruction rate
+            res[key]["frac_of_f64_datasheet_78_6TF"] = round(res[key]["TFLOPs_useful"] / 78.6, 3)      # the float64 matrix / vector rate
             res[key]["covariance_mfma_flops_issued"] = Fc * Rc * (Kc // 4) * 4 * 2.0 * 16 * 16 * 4
             res[key]["input_GBs"] = round(Fc * Vc * Rc * Kc * 8 / res[key]["ms"] / 1e6, 1)
         d_Xc.free(); d_Pc.free()
