@@ -345,7 +345,42 @@ def gen_detectors_rd():
     print("detectors_rd.npz:", {k: (v.shape if v.ndim else v.item()) for k, v in d.items()})
 
 
+# shipped cfg files with non-power-of-two planes (shape = virtual antennas x samples x loops), the antenna lists used with them
+NP2_CASES = (("1843_RaGNNarok_UAV_10m.cfg", (8, 254, 50), [0, 1, 2, 3], [4, 5, 6, 7]),
+             ("1843_RadVel_5Hz.cfg", (8, 63, 127), [0, 1, 2, 3, 4, 5, 6, 7], [1, 5]),
+             ("RadSAR.cfg", (12, 100, 100), [0, 1, 2, 3, 4, 5, 6, 7], [8, 9, 10, 11]),
+             ("1843_vel_nav.cfg", (4, 127, 32), [0, 1, 2, 3], []))
+NP2_SEEDS = (411, 412)
+
+
+def gen_detectors_np2():
+    """Detector and point-cloud outputs of the reference on four more shipped cfg shapes, none a power of two (round 3 had one
+    such fixture, 12 x 63 x 70): PointCloudGenerator with the CA-CFAR 2-D detector, the GUI's OS-CFAR 2-D and the YAML
+    sequential detector, two seeded cubes per shape."""
+    d = {}
+    for cfg, shape, az, el in NP2_CASES:
+        with open(os.path.join(REF, "configs", cfg)) as f:
+            cm = load_cm(f.read())
+        tag = "x".join(str(x) for x in shape)
+        assert (cm.num_rx_antennas * (cm.num_tx_antennas if cm.virtual_antennas_enabled else 1), cm.get_num_adc_samples(0),
+                cm.frameCfg_loops) == shape, (cfg, shape)
+        for seed in NP2_SEEDS:
+            cube = synth.synth_cube(seed, shape)
+            pcg = PointCloudGenerator(cm, az_antenna_idxs=az, el_antenna_idxs=el, detector_type="range_doppler_detector_2d",
+                                      detector_params={"cfar_type": "ca_cfar_2d",
+                                                       "cfar_params": {"num_train": (4, 4), "num_guard": (2, 2), "pfa": 1e-5}})
+            d[f"{tag}_s{seed}_pc"] = pcg.process(cube)
+            d[f"{tag}_s{seed}_dets"] = np.asarray(pcg.detector.dets)
+            d[f"{tag}_s{seed}_os2d"] = RangeDopplerDetector2D(cm, cfar_type="os_cfar_2d", cfar_params=YAML_OS2D).process(cube)
+            d[f"{tag}_s{seed}_seq"] = RangeDopplerDetectorSequential(cm, **YAML_SEQ).process(cube)
+    np.savez_compressed(os.path.join(HERE, "detectors_np2.npz"), **d)
+    print("detectors_np2.npz:", {k: v.shape for k, v in d.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "detectors_np2":
+        gen_detectors_np2()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "doppler_azimuth":
         gen_doppler_azimuth()
         sys.exit(0)
@@ -359,3 +394,4 @@ if __name__ == "__main__":
     gen_bartlett()
     gen_doppler_azimuth()
     gen_detectors_rd()
+    gen_detectors_np2()

@@ -1671,6 +1671,16 @@ def test_detect_points_screening_equals_the_float64_path(shape, frames, monkeypa
     print(f"{shape}: {frames} frames, {int(ref[0].sum())} detections; screening left {got[4][1]} cells in {got[4][0]} frames "
           f"undecided, {got[4][2]} frames handed back, {got[4][3]} + {got[4][4]} argmax evaluations refined")
     assert got[4][2] == 0 and ref[0].sum() > frames
+    # ... and not only each other: the oracle (float64 NumPy restatement of the reference) on the first frames of every shape
+    for f in range(3):
+        cube = d_in.download((V, S, C), np.complex64, f * V * S * C * 8)
+        raw, _, dets_ref, _, _ = O.rd_detect_2d(cube, (4, 4), (2, 2), 1e-5)
+        k = int(got[0][f])
+        np.testing.assert_array_equal(got[1][f, :k], dets_ref)
+        if k:
+            r, v = dets_ref[:, 0].astype(int), dets_ref[:, 1].astype(int)
+            np.testing.assert_array_equal(got[2][f, :k], O.angle_argmax(raw, r, v, az, 64, True)[0])
+            np.testing.assert_array_equal(got[3][f, :k], O.angle_argmax(raw, r, v, el, 64, False)[0])
     monkeypatch.setenv("MMW_DETECT_BAND_MULT", "50")
     wide = _detect_points_raw(ctx, d_in, frames, shape, cfar, 1024, az, el)
     handed_back = wide[0] < 0
@@ -1943,6 +1953,30 @@ def test_sequential_and_os2d_detectors_match_reference_fixtures():
     pipe.load(np.stack([synth.synth_cube(s) for s in range(4)]))
     for s, d in enumerate(pipe.detect()):
         np.testing.assert_array_equal(d, g[f"s{s}_os2d_yaml"])
+
+
+def test_detectors_on_more_non_power_of_two_shapes_match_reference_fixtures():
+    """PointCloudGenerator (CA-CFAR 2-D: the fused stage on the compile-time mixed-radix RD kernels), RangeDopplerDetector2D with
+    the GUI's OS-CFAR and the YAML sequential detector on four more shipped cfg shapes, against fixtures generated by the
+    imported reference (tests/golden/detectors_np2.npz): detections identical, point clouds to 1e-9 of the range."""
+    from test_oracle_golden import NP2_CASES, NP2_SEEDS, YAML_OS2D, YAML_SEQ, np2_cfg_text
+    g = np.load(os.path.join(GOLDEN, "detectors_np2.npz"))
+    for cfg, shape, az, el in NP2_CASES:
+        cm = make_cm(np2_cfg_text(cfg))
+        tag = "x".join(str(x) for x in shape)
+        pcg = PointCloudGenerator(cm, az_antenna_idxs=az, el_antenna_idxs=el,
+                                  detector_params={"cfar_type": "ca_cfar_2d",
+                                                   "cfar_params": {"num_train": (4, 4), "num_guard": (2, 2), "pfa": 1e-5}})
+        os2d = RangeDopplerDetector2D(cm, cfar_type="os_cfar_2d", cfar_params=dict(YAML_OS2D))
+        seq = RangeDopplerDetectorSequential(cm, rng_cfar_type=YAML_SEQ[0], rng_cfar_params=YAML_SEQ[1], vel_cfar_type=YAML_SEQ[2],
+                                             vel_cfar_params=YAML_SEQ[3])
+        for seed in NP2_SEEDS:
+            cube = synth.synth_cube(seed, shape)
+            pc = pcg.process(cube)
+            np.testing.assert_array_equal(pcg.detector.dets, g[f"{tag}_s{seed}_dets"])
+            np.testing.assert_allclose(pc, g[f"{tag}_s{seed}_pc"], rtol=0, atol=1e-9 * cm.range_max_m)
+            np.testing.assert_array_equal(os2d.process(cube), g[f"{tag}_s{seed}_os2d"])
+            np.testing.assert_array_equal(seq.process(cube), g[f"{tag}_s{seed}_seq"])
 
 
 def test_ground_detector_and_altimeter_match_reference_fixtures():

@@ -250,6 +250,39 @@ def test_sequential_and_os2d_detectors_on_range_doppler_data():
     assert total > 2000
 
 
+# tests/golden/make_golden.py::gen_detectors_np2: shipped cfg files with non-power-of-two planes
+NP2_CASES = (("1843_RaGNNarok_UAV_10m.cfg", (8, 254, 50), [0, 1, 2, 3], [4, 5, 6, 7]),
+             ("1843_RadVel_5Hz.cfg", (8, 63, 127), [0, 1, 2, 3, 4, 5, 6, 7], [1, 5]),
+             ("RadSAR.cfg", (12, 100, 100), [0, 1, 2, 3, 4, 5, 6, 7], [8, 9, 10, 11]),
+             ("1843_vel_nav.cfg", (4, 127, 32), [0, 1, 2, 3], []))
+NP2_SEEDS = (411, 412)
+
+
+def np2_cfg_text(cfg):
+    with open(os.path.join(GOLDEN, "cfg_scalars.json")) as fh:
+        return "\n".join(json.load(fh)[cfg]["lines"])
+
+
+def test_detectors_on_more_non_power_of_two_shapes():
+    """Four more shipped cfg shapes (254 x 50, 63 x 127, 100 x 100, 127 x 32; round 3 pinned 63 x 70 only), two cubes each, run by
+    the imported reference: CA-CFAR detections + point cloud, the GUI's OS-CFAR 2-D and the YAML sequential detector --
+    oracle == reference."""
+    g = np.load(os.path.join(GOLDEN, "detectors_np2.npz"))
+    total = 0
+    for cfg, shape, az, el in NP2_CASES:
+        sc = O.cfg_scalars(np2_cfg_text(cfg))
+        tag = "x".join(str(x) for x in shape)
+        for seed in NP2_SEEDS:
+            cube = synth.synth_cube(seed, shape)
+            pc, dets, _, _ = O.point_cloud(cube, sc, az, el)
+            np.testing.assert_array_equal(dets, g[f"{tag}_s{seed}_dets"])
+            close(pc, g[f"{tag}_s{seed}_pc"], 1e-12)
+            np.testing.assert_array_equal(O.rd_detect_2d_os(cube, **YAML_OS2D), g[f"{tag}_s{seed}_os2d"])
+            np.testing.assert_array_equal(O.rd_detect_sequential(cube, *YAML_SEQ), g[f"{tag}_s{seed}_seq"])
+            total += dets.shape[0]
+    assert total > 300
+
+
 def test_ground_detector_sequence_with_altimeter_state():
     """RangeDopplerGroundDetector over a 5-frame sequence (the altimeter keeps its last altitude), reset(), one more frame:
     detections and the altitude track of the oracle == reference, for the YAML parameters (never locks on: the ground return
