@@ -1,9 +1,7 @@
 // Fused per-frame detection stage of the batch pipeline (BASELINE configs[2]): everything behind the range-Doppler
-// kernel in ONE launch, one 1024-thread workgroup per frame.  A plane whose float32 magnitudes do not fit the LDS is cut
-// into row tiles (one workgroup each); the tile that finishes LAST compacts the frame's detection mask and runs the angle
-// argmax.  (Measured on 256 x 128: 2 / 3 / 4 / 6 tiles of 512 threads -- two or three workgroups per CU instead of one --
-// are all slower than the whole plane in one workgroup, 0.41 - 0.72 ms against 0.32 ms per 1250 frames: the halo rows are
-// loaded twice and the last tile's compaction + argmax has half the waves.)
+// kernel in ONE launch, one 512-thread workgroup per frame, whatever the plane's size: the plane streams through the LDS in
+// bands of rows (detect_screen_frame).  (Round 3 held the whole plane's magnitudes in the LDS and cut larger planes into row
+// tiles with a last-finisher protocol; both are gone.)
 //
 //   RangeDopplerDetector._compute_range_doppler_response   processors/range_doppler_detection/range_doppler_detector.py:62-80
 //   CaCFAR2D / OsCFAR2D .detect                             detectors/ca_cfar.py:85-155, os_cfar.py:97-195, base.py:208-230
@@ -41,7 +39,8 @@
 
 namespace mmw {
 
-constexpr int DET_NT = 1024;             // threads of the per-frame (per-tile) workgroup
+constexpr int DET_NT = 512;              // threads of the per-frame workgroup: TWO workgroups per CU (70 KB of LDS each at 256 x 128, 125
+                                         // VGPRs): one's barriers and load waits are the other's issue slots -- 8 % faster than one of 1024
 constexpr int DET_MAX_ANT = 8;           // antennas per list inside the fused kernels (cells, twiddles and error scales of a
                                          // list live in registers; lists of 9+ antennas take mmw_angle_argmax_exact)
 constexpr int DET_LIST2 = 16;            // first lane of the second list's cells
@@ -707,7 +706,7 @@ inline size_t detect_screen_lds(int xs_rows, int C, int band_rows, int band_pitc
     return 2 * (((size_t)xs_rows * C * 4 + 15) & ~(size_t)15) + 2 * (((size_t)band_rows * band_pitch * 4 + 15) & ~(size_t)15) +
            detect_tail_lds(words, A);
 }
-constexpr int DET_LOADS = 4;        // 16-byte loads a thread has in flight for the next band (two cells each)
+constexpr int DET_LOADS = 5;        // 16-byte loads a thread has in flight for the next band (two cells each)
 
 // TR, TD, GR, GD >= 0: the window is a compile-time constant (every loop over it unrolls: all of a cell's LDS reads are
 // issued before the first add); -1: taken from the arguments at run time.
@@ -849,13 +848,13 @@ __device__ __forceinline__ void detect_screen_frame(const DetectArgs &a, const l
 }
 
 template <int TR, int TD, int GR, int GD>
-__global__ __launch_bounds__(DET_NT) void k_detect_screen(DetectArgs a) {
+__global__ __launch_bounds__(DET_NT, 2048 / DET_NT) void k_detect_screen(DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     detect_screen_frame<TR, TD, GR, GD, false>(a, blockIdx.x, smem);
 }
 
 template <int TR, int TD, int GR, int GD>
-__global__ __launch_bounds__(DET_NT) void k_detect_screen_sync(DetectArgs a) {
+__global__ __launch_bounds__(DET_NT, 2048 / DET_NT) void k_detect_screen_sync(DetectArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int sy[2];       // ticket, abort
     const int tid = threadIdx.x;

@@ -1827,7 +1827,7 @@ DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, i
     // Band of rows under test: its cells and the 2 hr halo rows travel as at most DET_LOADS loads per thread (two cells per
     // load); 32 rows x 128 columns give each of the 1024 threads one item in either CFAR pass.
     const long cap_cells = (long)DET_LOADS * DET_NT * 2;
-    int band = std::min<long>(std::max(1, tune_int("MMW_DETECT_BAND", 32)), cap_cells / C - 2 * hr);
+    int band = std::min<long>(std::max(1, tune_int("MMW_DETECT_BAND", DET_NT >= 1024 ? 32 : 24)), cap_cells / C - 2 * hr);
     band = std::min(band, std::max(unit, S - 2 * hr));
     band = band / unit * unit;
     if (band < unit) return p;                              // rows too long for the band loads
@@ -2002,14 +2002,14 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         if (rc == MMW_OK) {
             ctx->stream = ctx->q_dscr;
             ProfScope ps(ctx, "detect");
-            rc = screen(std::min(scr_cus, n_frames));
+            rc = screen(std::min(scr_cus * (1024 / DET_NT), n_frames));       // (512-thread workgroups: two per CU)
         }
         if (rc == MMW_OK && opt_int(ctx, "MMW_DETECT_TAIL", 1)) {
             // frames the consumer's CUs have not reached when the producer drains: the same kernel (same ticket counter) on
             // the producer's CUs, behind it in its queue
             ctx->stream = ctx->q_drd;
             ProfScope ps(ctx, "detect_tail");
-            rc = screen(std::min(rd_cus, n_frames));
+            rc = screen(std::min(rd_cus * (1024 / DET_NT), n_frames));
         }
         ctx->stream = main_stream;
         // join in any case: whatever was enqueued runs to its end (bounded waits) before the context's next work
