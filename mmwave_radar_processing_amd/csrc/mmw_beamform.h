@@ -26,6 +26,41 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Exact three-way split of eight float32 values into bfloat16 fragments (element j of each fragment = piece of v[j]):
+// v = p1 + p2 + p3 with p1 = v truncated to 8 significant bits, p2 = (v - p1) truncated, p3 = the rest (<= 8 bits: exact).
+// Truncation (a mask) instead of rounding keeps every remainder exactly representable in float32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8 &f1, bf16x8 &f2, bf16x8 &f3) {
+    u32x4 p1, p2, p3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = v[2 * q], b = v[2 * q + 1];
+        const unsigned a1 = __builtin_bit_cast(unsigned, a) & 0xffff0000u, b1 = __builtin_bit_cast(unsigned, b) & 0xffff0000u;
+        const float ra = a - __builtin_bit_cast(float, a1), rb = b - __builtin_bit_cast(float, b1);
+        const unsigned a2 = __builtin_bit_cast(unsigned, ra) & 0xffff0000u, b2 = __builtin_bit_cast(unsigned, rb) & 0xffff0000u;
+        const float sa = ra - __builtin_bit_cast(float, a2), sb = rb - __builtin_bit_cast(float, b2);
+        const unsigned a3 = __builtin_bit_cast(unsigned, sa), b3 = __builtin_bit_cast(unsigned, sb);
+        p1[q] = (a1 >> 16) | b1;            // element 2 q in the low half, 2 q + 1 in the high half
+        p2[q] = (a2 >> 16) | b2;
+        p3[q] = (a3 >> 16) | (b3 & 0xffff0000u);
+    }
+    f1 = __builtin_bit_cast(bf16x8, p1);
+    f2 = __builtin_bit_cast(bf16x8, p2);
+    f3 = __builtin_bit_cast(bf16x8, p3);
+}
+// acc += A B over 16 values of k, A and B given as three-way splits: the six products down to 2^-24 of |a||b|
+// (a1 b1, a1 b2, a2 b1, a1 b3, a2 b2, a3 b1; what is dropped -- a2 b3, a3 b2, a3 b3 -- is <= 3 * 2^-24 |a||b|)
+__device__ __forceinline__ v16f mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], v16f acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
 // W[f][e][t] (complex64, row-major [E][Tp] per frame); phase reduced mod 1 turn in float64 before the sincos.
 // P [F][3][E] element positions of each frame's (synthetic) array, dirs [3][T] steering directions.
 __global__ __launch_bounds__(256) void k_steer(cplx<float> *W, const double *P, const double *dirs,
@@ -132,6 +167,137 @@ __global__ __launch_bounds__(256) void k_cgemm_mfma(const cplx<float> *__restric
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = n0 + wn + (lane & 31);
             if (row < M && col < N) Cm[(long)row * ldc + col] = cplx<float>{acc_r[mb][r], acc_i[mb][r]};
+        }
+}
+
+// The same product on bf16 x 3 (see split_bf16x3 / mfma_bf16x3): float32 MFMAs never co-execute with vector instructions on
+// gfx950 and run at 1 / 12.8 of the bf16 rate, so the tile's operands are split EXACTLY into three bfloat16 pieces each while
+// they are staged (vector work, under the matrix work of the previous step) and six of the nine partial products are formed
+// by v_mfma_f32_32x32x16_bf16: 48 MFMAs of 32 cycles per wave and K step of 16 instead of 64 of 64 cycles; the error per
+// product is 3 * 2^-24, the size of a float32 rounding (the 1e-5 tolerance of the spectra holds: tests).
+// LDS per buffer: A [3 pieces][re, im][128 rows][16 k] and B [3][re, im][64 columns][16 k] bfloat16, 32 bytes per row; the two
+// 16-byte halves of a row (k 0..7 / 8..15) swap places in rows 8..15 of every 16 (cb_slot): the 16-byte fragment reads of 16
+// consecutive rows then fall into 16 different 16-byte slots.  72 KB double-buffered: two workgroups per CU.
+constexpr int CB_PITCH = 16;                                                // bfloat16 per row
+__device__ __forceinline__ int cb_slot(int row, int half) { return 8 * (half ^ ((row >> 3) & 1)); }
+constexpr int CB_A = 3 * 2 * CG_TM * CB_PITCH, CB_B = 3 * 2 * CG_TN * CB_PITCH;   // bfloat16 per buffer
+constexpr size_t CB_LDS_BYTES = 2 * (size_t)(CB_A + CB_B) * 2;
+__device__ __forceinline__ void split_bf16x3_4(const float (&v)[4], unsigned (&p1)[2], unsigned (&p2)[2], unsigned (&p3)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float a = v[2 * q], b = v[2 * q + 1];
+        const unsigned a1 = __builtin_bit_cast(unsigned, a) & 0xffff0000u, b1 = __builtin_bit_cast(unsigned, b) & 0xffff0000u;
+        const float ra = a - __builtin_bit_cast(float, a1), rb = b - __builtin_bit_cast(float, b1);
+        const unsigned a2 = __builtin_bit_cast(unsigned, ra) & 0xffff0000u, b2 = __builtin_bit_cast(unsigned, rb) & 0xffff0000u;
+        const float sa = ra - __builtin_bit_cast(float, a2), sb = rb - __builtin_bit_cast(float, b2);
+        p1[q] = (a1 >> 16) | b1;
+        p2[q] = (a2 >> 16) | b2;
+        p3[q] = (__builtin_bit_cast(unsigned, sa) >> 16) | (__builtin_bit_cast(unsigned, sb) & 0xffff0000u);
+    }
+}
+__global__ __launch_bounds__(256, 2) void k_cgemm_bf16x3(const cplx<float> *__restrict__ A, const cplx<float> *__restrict__ B,
+                                                       cplx<float> *__restrict__ Cm, int M, int N, int K, int lda,
+                                                       int ldb, int ldc, long sa, long sb, long sc, int ksplit, int kc, long spart) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned short *lds = reinterpret_cast<unsigned short *>(smem);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int bz = blockIdx.z / ksplit, kz = blockIdx.z - bz * ksplit;
+    A += (long)bz * sa;
+    B += (long)bz * sb;
+    Cm += (long)bz * sc + (long)kz * spart;
+    const int k_begin = kz * kc;
+    if (ksplit > 1) K = K < k_begin + kc ? K : k_begin + kc;
+    const int m0 = blockIdx.y * CG_TM, n0 = blockIdx.x * CG_TN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
+    // global -> registers: A rows (thread = row, 8 consecutive k), B columns (thread = column, 4 consecutive k)
+    const int a_row = t >> 1, a_k = (t & 1) * 8, b_n = t & 63, b_k = (t >> 6) * 4;
+    cplx<float> ra[8], rb[4];
+    auto fetch = [&](int k0) {
+        const int gm = m0 + a_row;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int gk = k0 + a_k + j;
+            ra[j] = (gm < M && gk < K) ? A[(long)gm * lda + gk] : cplx<float>{0.f, 0.f};
+        }
+        const int gn = n0 + b_n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gk = k0 + b_k + j;
+            rb[j] = (gk < K && gn < N) ? B[(long)gk * ldb + gn] : cplx<float>{0.f, 0.f};
+        }
+    };
+    // piece p, component c (0 re, 1 im): A at ((p * 2 + c) * CG_TM + row) * CB_PITCH + k, B behind all of A
+    auto stash = [&](int buf) {
+        unsigned short *Ab = lds + buf * (CB_A + CB_B), *Bb = Ab + CB_A;
+        float xr[8], xi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xr[j] = ra[j].x;
+            xi[j] = ra[j].y;
+        }
+        bf16x8 f[3];
+        split_bf16x3(xr, f[0], f[1], f[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8 *>(Ab + ((p * 2 + 0) * CG_TM + a_row) * CB_PITCH + cb_slot(a_row, a_k >> 3)) = f[p];
+        split_bf16x3(xi, f[0], f[1], f[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8 *>(Ab + ((p * 2 + 1) * CG_TM + a_row) * CB_PITCH + cb_slot(a_row, a_k >> 3)) = f[p];
+        float yr[4], yi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            yr[j] = rb[j].x;
+            yi[j] = rb[j].y;
+        }
+        unsigned q1[2], q2[2], q3[2];
+        split_bf16x3_4(yr, q1, q2, q3);
+        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2v *>(Bb + ((0 * 2 + 0) * CG_TN + b_n) * CB_PITCH + cb_slot(b_n, b_k >> 3) + (b_k & 7)) = u32x2v{q1[0], q1[1]};
+        *reinterpret_cast<u32x2v *>(Bb + ((1 * 2 + 0) * CG_TN + b_n) * CB_PITCH + cb_slot(b_n, b_k >> 3) + (b_k & 7)) = u32x2v{q2[0], q2[1]};
+        *reinterpret_cast<u32x2v *>(Bb + ((2 * 2 + 0) * CG_TN + b_n) * CB_PITCH + cb_slot(b_n, b_k >> 3) + (b_k & 7)) = u32x2v{q3[0], q3[1]};
+        split_bf16x3_4(yi, q1, q2, q3);
+        *reinterpret_cast<u32x2v *>(Bb + ((0 * 2 + 1) * CG_TN + b_n) * CB_PITCH + cb_slot(b_n, b_k >> 3) + (b_k & 7)) = u32x2v{q1[0], q1[1]};
+        *reinterpret_cast<u32x2v *>(Bb + ((1 * 2 + 1) * CG_TN + b_n) * CB_PITCH + cb_slot(b_n, b_k >> 3) + (b_k & 7)) = u32x2v{q2[0], q2[1]};
+        *reinterpret_cast<u32x2v *>(Bb + ((2 * 2 + 1) * CG_TN + b_n) * CB_PITCH + cb_slot(b_n, b_k >> 3) + (b_k & 7)) = u32x2v{q3[0], q3[1]};
+    };
+    v16f acc_r[2] = {{0}, {0}}, acc_r2[2] = {{0}, {0}}, acc_i[2] = {{0}, {0}};
+    fetch(k_begin);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    const int ij = lane & 31;
+    for (int k0 = k_begin; k0 < K; k0 += CG_TK, buf ^= 1) {
+        const bool more = k0 + CG_TK < K;
+        if (more) fetch(k0 + CG_TK);                    // in flight while this step's MFMAs run
+        const unsigned short *Ab = lds + buf * (CB_A + CB_B), *Bb = Ab + CB_A;
+        // operand maps of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8 h + j], B[k = 8 h + j][col r]
+        bf16x8 br3[3], bi3[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            br3[p] = *reinterpret_cast<const bf16x8 *>(Bb + ((p * 2 + 0) * CG_TN + wn + ij) * CB_PITCH + cb_slot(wn + ij, lane >> 5));
+            bi3[p] = *reinterpret_cast<const bf16x8 *>(Bb + ((p * 2 + 1) * CG_TN + wn + ij) * CB_PITCH + cb_slot(wn + ij, lane >> 5));
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            bf16x8 ar3[3], ai3[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                ar3[p] = *reinterpret_cast<const bf16x8 *>(Ab + ((p * 2 + 0) * CG_TM + wm + 32 * mb + ij) * CB_PITCH + cb_slot(wm + 32 * mb + ij, lane >> 5));
+                ai3[p] = *reinterpret_cast<const bf16x8 *>(Ab + ((p * 2 + 1) * CG_TM + wm + 32 * mb + ij) * CB_PITCH + cb_slot(wm + 32 * mb + ij, lane >> 5));
+            }
+            acc_r[mb] = mfma_bf16x3(ar3, br3, acc_r[mb]);
+            acc_r2[mb] = mfma_bf16x3(ai3, bi3, acc_r2[mb]);
+            acc_i[mb] = mfma_bf16x3(ar3, bi3, acc_i[mb]);
+            acc_i[mb] = mfma_bf16x3(ai3, br3, acc_i[mb]);
+        }
+        if (more) stash(buf ^ 1);                       // the other buffer: nobody reads it during this step
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = n0 + wn + (lane & 31);
+            if (row < M && col < N) Cm[(long)row * ldc + col] = cplx<float>{acc_r[mb][r] - acc_r2[mb][r], acc_i[mb][r]};
         }
 }
 
@@ -264,6 +430,33 @@ __global__ __launch_bounds__(64 * NW) void k_bartlett_tile(const cplx<float> *__
             bi = sn * hm[s];
         };
         mark(2);
+        if constexpr (VAR & 2) {
+            // bf16 x 3: float32 MFMAs and vector instructions never co-execute on this chip (profiles/r04_coexec.json), bf16 MFMAs do,
+            // and v_mfma_f32_32x32x16_bf16 moves 8 x the k of the float32 instruction in half the cycles: the operands are split
+            // exactly into three bfloat16 pieces each (vector work that now runs UNDER the matrix work) and six of the nine
+            // partial products are kept -- the error per product is 3 * 2^-24, the size of a float32 rounding.
+            static_assert(NS == 16, "two blocks of 8 k per half-wave");
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float arv[8], aiv[8], brv[8], biv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int s_ = 8 * b + j;
+                    arv[j] = (s_ & 1) ? ra[s_ >> 1].z : ra[s_ >> 1].x;
+                    aiv[j] = (s_ & 1) ? ra[s_ >> 1].w : ra[s_ >> 1].y;
+                    steer(s_, brv[j], biv[j]);
+                }
+                bf16x8 ar3[3], ai3[3], br3[3], bi3[3];
+                split_bf16x3(arv, ar3[0], ar3[1], ar3[2]);
+                split_bf16x3(aiv, ai3[0], ai3[1], ai3[2]);
+                split_bf16x3(brv, br3[0], br3[1], br3[2]);
+                split_bf16x3(biv, bi3[0], bi3[1], bi3[2]);
+                acc_r = mfma_bf16x3(ar3, br3, acc_r);
+                acc_i = mfma_bf16x3(ar3, bi3, acc_i);
+                acc_r2 = mfma_bf16x3(ai3, bi3, acc_r2);         // (subtracted after the loop)
+                acc_i2 = mfma_bf16x3(ai3, br3, acc_i2);
+            }
+        } else {
         float br, bi;
         steer(0, br, bi);
 #pragma unroll
@@ -283,12 +476,13 @@ __global__ __launch_bounds__(64 * NW) void k_bartlett_tile(const cplx<float> *__
             br = nbr;
             bi = nbi;
         }
+        }
         mark(3);
         wave_lds_sync();                                // the strip is rewritten by the next chunk
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        red[((wave * 2 + 0) * 16 + r) * 64 + lane] = acc_r[r] + acc_r2[r];
+        red[((wave * 2 + 0) * 16 + r) * 64 + lane] = (VAR & 2) ? acc_r[r] - acc_r2[r] : acc_r[r] + acc_r2[r];
         red[((wave * 2 + 1) * 16 + r) * 64 + lane] = acc_i[r] + acc_i2[r];
     }
     __syncthreads();
@@ -337,8 +531,10 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
         const unsigned grid = (unsigned)(8 * NT * ((MT + 7) / 8));
         const size_t lds = (size_t)nw * BT_STRIP + (size_t)nw * 2 * 16 * 64 * 4;
         const bool poly = opt_int(ctx, "MMW_BARTLETT_POLY", 0) != 0;       // polynomial sine / cosine instead of v_sin / v_cos
-        auto kern = k_bartlett_tile<8, 16, false, 1>;
-        if ((E & 31) == 0) kern = poly ? k_bartlett_tile<8, 16, true, 0> : k_bartlett_tile<8, 16, true, 1>;
+        // MMW_BARTLETT_BF16 (default 1): the contraction on bf16 x 3 MFMAs; 0: float32 MFMAs
+        const bool bf3 = opt_int(ctx, "MMW_BARTLETT_BF16", 1) != 0 && !poly;
+        auto kern = bf3 ? k_bartlett_tile<8, 16, false, 3> : k_bartlett_tile<8, 16, false, 1>;
+        if ((E & 31) == 0) kern = poly ? k_bartlett_tile<8, 16, true, 0> : bf3 ? k_bartlett_tile<8, 16, true, 3> : k_bartlett_tile<8, 16, true, 1>;
         else if (poly) kern = k_bartlett_tile<8, 16, false, 0>;
         long long *d_clk = nullptr;
         if (tune_int("MMW_PHASE_CLOCKS", 0)) {
@@ -366,8 +562,14 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
             ProfScope pg(ctx, "cgemm");
             dim3 grid((T + CG_TN - 1) / CG_TN, (S + CG_TM - 1) / CG_TM, (unsigned)(n_frames * ksplit));
             const long n_c = (long)n_frames * S * T;
-            hipLaunchKernelGGL(k_cgemm_mfma, grid, dim3(256), 0, ctx->stream, (const cplx<float> *)d_X, W, ksplit > 1 ? Cparts : Cm, S, T, E,
-                               E, Tp, T, (long)S * E, (long)E * Tp, (long)S * T, ksplit, kc, n_c);
+            if (opt_int(ctx, "MMW_BARTLETT_BF16", 1)) {
+                MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cgemm_bf16x3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)CB_LDS_BYTES));
+                hipLaunchKernelGGL(k_cgemm_bf16x3, grid, dim3(256), CB_LDS_BYTES, ctx->stream, (const cplx<float> *)d_X, W,
+                                   ksplit > 1 ? Cparts : Cm, S, T, E, E, Tp, T, (long)S * E, (long)E * Tp, (long)S * T, ksplit, kc, n_c);
+            } else
+                hipLaunchKernelGGL(k_cgemm_mfma, grid, dim3(256), 0, ctx->stream, (const cplx<float> *)d_X, W, ksplit > 1 ? Cparts : Cm, S, T, E,
+                                   E, Tp, T, (long)S * E, (long)E * Tp, (long)S * T, ksplit, kc, n_c);
             MMW_TRY(check_launch("cgemm_mfma"));
             if (ksplit > 1) {
                 hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((n_c + 255) / 256)), dim3(256), 0, ctx->stream, Cparts, Cm, n_c, ksplit);
