@@ -61,6 +61,14 @@ __device__ __forceinline__ v16f mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 (
     return acc;
 }
 
+// v where keep, +0 elsewhere, as a bit mask: a select lets the compiler sink the LOAD of v into a branch on the condition
+// (and every load under a branch is followed by its own s_waitcnt)
+__device__ __forceinline__ cplx<float> and_mask(cplx<float> v, bool keep) {
+    const unsigned m = 0u - (unsigned)keep;
+    const float re = v.x, im = v.y;         // (copies first: __builtin_bit_cast applied to an ext-vector ELEMENT reads element 0)
+    return cplx<float>{__builtin_bit_cast(float, __builtin_bit_cast(unsigned, re) & m), __builtin_bit_cast(float, __builtin_bit_cast(unsigned, im) & m)};
+}
+
 // W[f][e][t] (complex64, row-major [E][Tp] per frame); phase reduced mod 1 turn in float64 before the sincos.
 // P [F][3][E] element positions of each frame's (synthetic) array, dirs [3][T] steering directions.
 __global__ __launch_bounds__(256) void k_steer(cplx<float> *W, const double *P, const double *dirs,
@@ -108,17 +116,21 @@ __global__ __launch_bounds__(256) void k_cgemm_mfma(const cplx<float> *__restric
     const int a_row = t >> 1, a_k = (t & 1) * 8, b_k = t >> 4, b_n = (t & 15) * 4;
     cplx<float> ra[8], rb[4];
     auto fetch = [&](int k0) {
-        const int gm = m0 + a_row;
+        // unconditional, clamped loads + a select afterwards: a load under a condition is followed by its own s_waitcnt, and the
+        // twelve loads of a step then cost twelve trips to memory one after the other (this was 5 k of a step's 7 k clocks)
+        const int gm = m0 + a_row, gmc = gm < M ? gm : M - 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int gk = k0 + a_k + j;
-            ra[j] = (gm < M && gk < K) ? A[(long)gm * lda + gk] : cplx<float>{0.f, 0.f};
+            const cplx<float> v = A[(long)gmc * lda + (gk < K ? gk : K - 1)];
+            ra[j] = and_mask(v, (gm < M) & (gk < K));
         }
-        const int gk = k0 + b_k;
+        const int gk = k0 + b_k, gkc = gk < K ? gk : K - 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int gn = n0 + b_n + j;
-            rb[j] = (gk < K && gn < N) ? B[(long)gk * ldb + gn] : cplx<float>{0.f, 0.f};
+            const cplx<float> v = B[(long)gkc * ldb + (gn < N ? gn : N - 1)];
+            rb[j] = and_mask(v, (gk < K) & (gn < N));
         }
     };
     auto stash = [&](int buf) {
@@ -213,27 +225,31 @@ __global__ __launch_bounds__(256, 2) void k_cgemm_bf16x3(const cplx<float> *__re
     const int a_row = t >> 1, a_k = (t & 1) * 8, b_n = t & 63, b_k = (t >> 6) * 4;
     cplx<float> ra[8], rb[4];
     auto fetch = [&](int k0) {
-        const int gm = m0 + a_row;
+        // unconditional, clamped loads + a select afterwards: a load under a condition is followed by its own s_waitcnt, and the
+        // twelve loads of a step then cost twelve trips to memory one after the other (this was 5 k of a step's 7 k clocks)
+        const int gm = m0 + a_row, gmc = gm < M ? gm : M - 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int gk = k0 + a_k + j;
-            ra[j] = (gm < M && gk < K) ? A[(long)gm * lda + gk] : cplx<float>{0.f, 0.f};
+            ra[j] = A[(long)gmc * lda + (gk < K ? gk : K - 1)];           // (masked in stash(): the AND would wait for the load here)
         }
-        const int gn = n0 + b_n;
+        const int gn = n0 + b_n, gnc = gn < N ? gn : N - 1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int gk = k0 + b_k + j;
-            rb[j] = (gk < K && gn < N) ? B[(long)gk * ldb + gn] : cplx<float>{0.f, 0.f};
+            rb[j] = B[(long)(gk < K ? gk : K - 1) * ldb + gnc];
         }
     };
     // piece p, component c (0 re, 1 im): A at ((p * 2 + c) * CG_TM + row) * CB_PITCH + k, B behind all of A
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, int k0) {                 // k0: the step the registers were fetched for
         unsigned short *Ab = lds + buf * (CB_A + CB_B), *Bb = Ab + CB_A;
         float xr[8], xi[8];
+        const bool row_ok = m0 + a_row < M, col_ok = n0 + b_n < N;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            xr[j] = ra[j].x;
-            xi[j] = ra[j].y;
+            const cplx<float> v = and_mask(ra[j], row_ok & (k0 + a_k + j < K));
+            xr[j] = v.x;
+            xi[j] = v.y;
         }
         bf16x8 f[3];
         split_bf16x3(xr, f[0], f[1], f[2]);
@@ -245,8 +261,9 @@ __global__ __launch_bounds__(256, 2) void k_cgemm_bf16x3(const cplx<float> *__re
         float yr[4], yi[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            yr[j] = rb[j].x;
-            yi[j] = rb[j].y;
+            const cplx<float> v = and_mask(rb[j], col_ok & (k0 + b_k + j < K));
+            yr[j] = v.x;
+            yi[j] = v.y;
         }
         unsigned q1[2], q2[2], q3[2];
         split_bf16x3_4(yr, q1, q2, q3);
@@ -261,13 +278,15 @@ __global__ __launch_bounds__(256, 2) void k_cgemm_bf16x3(const cplx<float> *__re
     };
     v16f acc_r[2] = {{0}, {0}}, acc_r2[2] = {{0}, {0}}, acc_i[2] = {{0}, {0}};
     fetch(k_begin);
-    stash(0);
+    stash(0, k_begin);
+    if (k_begin + CG_TK < K) fetch(k_begin + CG_TK);
     __syncthreads();
     int buf = 0;
     const int ij = lane & 31;
+    // Software pipeline, two steps deep: the registers hold step k0 + 16 (fetched during the previous iteration, long arrived),
+    // so splitting + staging them has no wait in front of it and can be scheduled INTO the MFMA block of step k0 (bf16 MFMAs
+    // leave 24 of their 32 cycles to vector instructions); the loads of step k0 + 32 go out behind it.
     for (int k0 = k_begin; k0 < K; k0 += CG_TK, buf ^= 1) {
-        const bool more = k0 + CG_TK < K;
-        if (more) fetch(k0 + CG_TK);                    // in flight while this step's MFMAs run
         const unsigned short *Ab = lds + buf * (CB_A + CB_B), *Bb = Ab + CB_A;
         // operand maps of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8 h + j], B[k = 8 h + j][col r]
         bf16x8 br3[3], bi3[3];
@@ -289,7 +308,15 @@ __global__ __launch_bounds__(256, 2) void k_cgemm_bf16x3(const cplx<float> *__re
             acc_i[mb] = mfma_bf16x3(ar3, bi3, acc_i[mb]);
             acc_i[mb] = mfma_bf16x3(ai3, br3, acc_i[mb]);
         }
-        if (more) stash(buf ^ 1);                       // the other buffer: nobody reads it during this step
+        // (unconditional -- after the last step it stages stale registers into the buffer nobody reads -- so that it shares the
+        //  MFMAs' basic block and the scheduler may interleave: one MFMA, four vector instructions, ...)
+        stash(buf ^ 1, k0 + CG_TK);
+#pragma unroll
+        for (int g = 0; g < 48; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        if (k0 + 2 * CG_TK < K) fetch(k0 + 2 * CG_TK);
         __syncthreads();
     }
 #pragma unroll
