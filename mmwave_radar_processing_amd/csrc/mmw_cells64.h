@@ -99,19 +99,30 @@ __global__ __launch_bounds__(C64_NT) void k_cells64(Cells64Args a) {
         cplx<double> acc[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) acc[j] = cplx<double>{0.0, 0.0};
+        // the samples of the NEXT pass travel while this one is transformed and summed (one workgroup per CU: nothing else
+        // would cover the trip); unconditional clamped loads
+        const int rl = 4 * wave + g4;
+        float2 raw[R];
+        auto fetch = [&](int s0) {
+            const int s = s0 + rl, sc = s < S ? s : S - 1;
+            const float2 *rowp = plane + (long)sc * C;
+#pragma unroll
+            for (int n2 = 0; n2 < R; ++n2) raw[n2] = rowp[n1 + 16 * n2];
+        };
+        fetch(0);
         for (int s0 = 0; s0 < S; s0 += C64_ROWS) {
             // ---- Doppler FFT of rows s0 .. s0 + 63: wave w, lane group g4 -> row 4 w + g4; lane n1 holds c = n1 + 16 n2
             {
-                const int rl = 4 * wave + g4, s = s0 + rl, sc = s < S ? s : S - 1;
+                const int s = s0 + rl, sc = s < S ? s : S - 1;
                 const double wrow = s < S ? wsl[sc] : 0.0;                  // hann(S)[s] rides along; rows past the plane: zero
-                const float2 *rowp = plane + (long)sc * C;
                 cplx<double> x[R];
 #pragma unroll
                 for (int n2 = 0; n2 < R; ++n2) {
-                    const float2 t = rowp[n1 + 16 * n2];
+                    const float2 t = raw[n2];
                     const double w = wcl[n1 + 16 * n2] * wrow;
                     x[n2] = cplx<double>{(double)t.x * w, (double)t.y * w};
                 }
+                fetch(s0 + C64_ROWS < S ? s0 + C64_ROWS : s0);
                 RegFFT<R, double>::run(x);
                 cplx<double> *slab = Z + rl * P;                            // the row's own LDS: [k2][n1] now, [k] afterwards
                 static_for<R>([&](auto K) {

@@ -550,6 +550,69 @@ __global__ __launch_bounds__(OSM_TR *OSM_TC) void k_cfar2d_os_mask(Cfar2dArgs p)
     p.mask[(long)blockIdx.z * plane + (long)r * p.D + c] = det ? 1 : 0;
 }
 
+// The same count with FOUR vertically adjacent cells per thread and the window shape at compile time.  k_cfar2d_os_mask is
+// bound by the LDS (220 eight-byte reads per cell: 14 of the CU's 16 doubles per clock); the windows of four cells in a column
+// share all but three of their rows, so a thread reads (2 hr + 4) x (2 hd + 1) values once and compares each with the cells
+// whose training set holds it: 75 reads per cell instead of 220, the kernel is then bound by its 2 x 220 compare / add-carry
+// instructions per cell.  32 x 32 cells per 256-thread workgroup (a half-wave reads 32 consecutive doubles: conflict-free).
+constexpr int OSV_T = 32, OSV_NV = 4;
+template <int TR, int TD, int GR, int GD>
+__global__ __launch_bounds__(256) void k_cfar2d_os_mask_v(Cfar2dArgs p) {
+    constexpr int HR = TR + GR, HD = TD + GD, WR = 2 * HR + 1, WD = 2 * HD + 1;
+    constexpr int TW = OSV_T + 2 * HD, TH = OSV_T + 2 * HR;
+    __shared__ double tile[TH * TW];                            // alpha * X over the tile + halo
+    const long plane = (long)p.R * p.D;
+    const double *X = p.X + (long)blockIdx.z * plane;
+    const int r0 = blockIdx.y * OSV_T, c0 = blockIdx.x * OSV_T;
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int y = i / TW, x = i - y * TW, rr = r0 - HR + y, cc = c0 - HD + x;
+        tile[i] = (rr >= 0 && rr < p.R && cc >= 0 && cc < p.D) ? p.scale * X[(long)rr * p.D + cc] : 0.0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = c0 + tx, rb = r0 + ty * OSV_NV;
+    if (c >= p.D || rb >= p.R) return;
+    double x[OSV_NV];
+    int below[OSV_NV];
+#pragma unroll
+    for (int j = 0; j < OSV_NV; ++j) {
+        const int r = rb + j < p.R ? rb + j : p.R - 1;
+        x[j] = X[(long)r * p.D + c];
+        below[j] = 0;
+    }
+    const double *base = tile + (ty * OSV_NV) * TW + tx;
+    // a run-time loop over the tile rows (fully unrolled, the compiler issues all 300 reads first and spills); which cells a
+    // row belongs to, and whether as a guard row, are wave-uniform branches
+#pragma unroll 1
+    for (int y = 0; y < WR + OSV_NV - 1; ++y) {
+        double v[WD];
+#pragma unroll
+        for (int wd = 0; wd < WD; ++wd) v[wd] = base[y * TW + wd];
+        static_for<OSV_NV>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const int wr = y - j;                               // window row of cell j
+            if (wr >= 0 && wr < WR) {
+                if (wr >= TR && wr <= TR + 2 * GR) {
+                    static_for<WD>([&](auto Wd) {
+                        constexpr int wd = decltype(Wd)::value;
+                        if constexpr (wd < TD || wd > TD + 2 * GD) below[j] += v[wd] < x[j] ? 1 : 0;
+                    });
+                } else {
+#pragma unroll
+                    for (int wd = 0; wd < WD; ++wd) below[j] += v[wd] < x[j] ? 1 : 0;
+                }
+            }
+        });
+    }
+#pragma unroll
+    for (int j = 0; j < OSV_NV; ++j) {
+        const int r = rb + j;
+        if (r >= p.R) break;
+        const bool valid = r >= HR && r < p.R - HR && c >= HD && c < p.D - HD;
+        p.mask[(long)blockIdx.z * plane + (long)r * p.D + c] = (valid && below[j] >= p.k_rank) ? 1 : 0;
+    }
+}
+
 struct Cfar1dArgs {
     const double *x;
     double *thr, *noise;

@@ -376,6 +376,171 @@ __global__ __launch_bounds__(256) void k_angle_argmax_lanes(const float2 *rd, co
     }
 }
 
+// Lane-per-detection form of the same float32 argmax + certainty test, for the 64-bin angle axis of the reference's point cloud
+// (point_cloud_generator.py:143-214: az_el_fft_size 64) and lists of up to 8 antennas.  The wave-per-detection routine above
+// spends ~130 wave instructions per evaluation (24 v_readlane broadcasts, three wave-wide reductions, the bookkeeping) on 32
+// useful FMAs per lane; with ~470 noise-level OS-CFAR detections per frame and list that was a quarter of the OS pipeline.
+// Here a lane owns a detection:
+//   * zero-padded 64-point DFT of N cells as G = 64 / N register FFTs of length N:  S[b + G a] = FFT_N( x_i W_64^(i b) )[a]
+//     (compile-time twiddles, packed float32 math): ~11 instructions per bin and detection, a quarter of the direct sums;
+//   * the order is decided on p = re^2 + im^2 (no square root per bin), first maximum by a scan in output order; the two
+//     square roots of the certainty test  m1 - m2 > 2 (Be + c_ang)  come last.  Rounding: one twiddle product, log2 N
+//     butterfly levels, one (1 +- j) / sqrt 2 rotation, p and its root: under 12 eps sum |x_i|, inside c_ang = 4 (n + 4) eps sum |x_i|;
+//   * lanes whose runner-up is inside the independent-errors bound run the correlated (pairwise) form of the test -- the one of
+//     detect_argmax_list, same arithmetic: direct sums with table twiddles -- over their CANDIDATE bins only (those the generic
+//     test does not clear: p_k >= (m1 - 2B)^2 less a rounding allowance); a wave loops as long as its busiest lane.
+// Flagged evaluations join rf.list / rf.flagpos with one atomic per wave.  Every index it reports unflagged is the float64
+// one by the same proof as before; what it flags is re-evaluated in float64 by the caller.
+template <int N, bool SHIFT>
+__global__ __launch_bounds__(256) void k_angle_argmax_dets(const float2 *__restrict__ rd, const int32_t *__restrict__ dets,
+                                                            const int32_t *__restrict__ counts, int32_t *__restrict__ out_idx, int V, int S,
+                                                            int C, int cap, AntList ants, const float2 *__restrict__ twA, ArgmaxRefine rf) {
+    constexpr int A = 64, G = A / N;
+    static_assert(N == 4 || N == 8, "lists of up to 4 / up to 8 antennas");
+    __shared__ float2 tw[A];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < A) tw[tid] = twA[tid];
+    __syncthreads();
+    const long f = blockIdx.y;
+    int n_det = counts[f];
+    if (n_det > cap) n_det = cap;
+    const int n = ants.n;
+    float e[N], be = 0.f;
+    long poff[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int ant = ants.idx[i < n ? i : 0];
+        e[i] = i < n ? rf.k_fft * rf.l1[f * V + ant] : 0.f;
+        be += e[i];
+        poff[i] = (f * V + ant) * (long)S * C;
+    }
+    for (int det0 = (blockIdx.x * 4 + wave) * 64; det0 < n_det; det0 += gridDim.x * 256) {
+        const int det = det0 + lane;
+        const bool active = det < n_det;
+        const long slot = f * cap + (active ? det : det0);
+        const long cell = (long)dets[slot * 2] * C + dets[slot * 2 + 1];
+        cplx<float> x[N];
+        float sum_abs = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float2 v = rd[poff[i] + cell];                    // unconditional (a valid slot); unused antennas read as zeros
+            x[i] = i < n ? cplx<float>{v.x, v.y} : cplx<float>{0.f, 0.f};
+            sum_abs += fabsf(x[i].x) + fabsf(x[i].y);
+        }
+        // ---- all 64 bins: p[k] = |S_k|^2
+        unsigned key[A];
+        static_for<G>([&](auto B) {
+            constexpr int b = decltype(B)::value;
+            cplx<float> y[N];
+            static_for<N>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                y[i] = mul_w<64, i * b, float>(x[i]);
+            });
+            RegFFT<N, float>::run(y);
+            static_for<N>([&](auto Aa) {
+                constexpr int a = decltype(Aa)::value;
+                const cplx<float> sk = y[bitrev<N>(a)];
+                key[b + G * a] = mag_key(fmaf(sk.x, sk.x, sk.y * sk.y));
+            });
+        });
+        // ---- first maximum in output order (np.argmax), largest other value
+        unsigned k1key = 0u, k2key = 0u;
+        int wi = 0;
+        static_for<A>([&](auto KK) {
+            constexpr int kk = decltype(KK)::value;
+            constexpr int k = SHIFT ? (kk + A / 2) % A : kk;
+            const unsigned v = key[k];
+            if constexpr (kk == 0) {
+                k1key = v;
+            } else {
+                const bool up = v > k1key;
+                k2key = up ? k1key : max(k2key, v);
+                k1key = up ? v : k1key;
+                wi = up ? kk : wi;
+            }
+        });
+        const float m1p = __fsqrt_rn(key_mag(k1key)), m2p = __fsqrt_rn(key_mag(k2key));
+        const float c_ang = rf.k_ang * sum_abs, two_b = 2.f * (be + c_ang);
+        bool bad = !(m1p - m2p > two_b);                            // (also for a NaN winner)
+        if (bad && m1p == m1p) {
+            // candidate bins: everything the generic test does not clear against the winner
+            const float thr = m1p - two_b, t2 = thr > 0.f ? thr * thr * (1.f - 2e-6f) : 0.f;
+            unsigned long long cand = 0ull;
+            static_for<A>([&](auto KK) {
+                constexpr int kk = decltype(KK)::value;
+                constexpr int k = SHIFT ? (kk + A / 2) % A : kk;
+                if (!(key_mag(key[k]) < t2)) cand |= 1ull << k;
+            });
+            const int k1 = SHIFT ? (wi + A - A / 2) % A : wi;
+            cand &= ~(1ull << k1);
+            // the winner by direct sums (the arithmetic of detect_argmax_list), conj(u_1) W^(i k_1)
+            float2 t1[N];
+            float re1 = 0.f, im1 = 0.f;
+            {
+                int t = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const float2 w = tw[t];
+                    t1[i] = w;
+                    re1 += x[i].x * w.x - x[i].y * w.y;
+                    im1 += x[i].x * w.y + x[i].y * w.x;
+                    t = (t + k1) & (A - 1);
+                }
+            }
+            const float m1 = __fsqrt_rn(fmaf(re1, re1, im1 * im1));
+            const float inv1 = 1.f / m1, u1x = re1 * inv1, u1y = im1 * inv1;
+#pragma unroll
+            for (int i = 0; i < N; ++i) t1[i] = make_float2(u1x * t1[i].x + u1y * t1[i].y, u1x * t1[i].y - u1y * t1[i].x);
+            bad = !(m1 > 0.f);                                      // (a zero or non-finite winner stays flagged)
+            while (__ballot(cand != 0ull) != 0ull) {
+                if (cand != 0ull) {
+                    const int k = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1ull;
+                    float2 w[N];
+                    float re = 0.f, im = 0.f;
+                    int t = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        w[i] = tw[t];
+                        t = (t + k) & (A - 1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        re += x[i].x * w[i].x - x[i].y * w[i].y;
+                        im += x[i].x * w[i].y + x[i].y * w[i].x;
+                    }
+                    const float m = __fsqrt_rn(fmaf(re, re, im * im)), margin = m1 - m;
+                    bool ok = margin > two_b;
+                    if (!ok && m > 0.f) {
+                        const float inv = 1.f / m, ux = re * inv, uy = im * inv;
+                        float lin = 0.f;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) {
+                            const float dx = t1[i].x - (ux * w[i].x + uy * w[i].y), dy = t1[i].y - (ux * w[i].y - uy * w[i].x);
+                            lin += e[i] * __fsqrt_rn(fmaf(dx, dx, dy * dy));
+                        }
+                        ok = margin > 1.001f * (lin + be * be / (2.f * fminf(m1, m))) + 2.f * c_ang;
+                    }
+                    bad |= !ok;
+                }
+            }
+        }
+        const bool flag = active && bad;
+        if (active) out_idx[slot] = wi;
+        const unsigned long long fm = __ballot(flag);
+        if (fm != 0ull) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(rf.n_flag, __popcll(fm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (flag) {
+                const int pos = base + __popcll(fm & ((1ull << lane) - 1ull));
+                if (pos < rf.list_cap) rf.list[pos] = (int)slot;
+                if (rf.flagpos && pos < rf.dense_cap) rf.flagpos[slot] = pos + 1;
+            }
+        }
+    }
+}
+
 // Ordered compaction of the frame's bit mask (bit r * C + c, LDS) into dets / counts, then the angle argmax of every
 // detection.  ws: 96 ints of LDS ([48, 80) = antenna table), tw: W_A^m in LDS.  Ends with every thread past its last
 // use of bits / ws.

@@ -1403,6 +1403,20 @@ static int cfar2d_impl(mmw_ctx *ctx, const double *d_X, double *d_thr, double *d
     if (kind == MMW_CFAR_OS) MMW_REQUIRE(k_rank >= 1 && k_rank <= ntrain, "k_rank must be between 1 and %ld, got %d", ntrain, k_rank);
     if (kind == MMW_CFAR_OS && !d_thr && !d_noise && d_mask && scale > 0.0) {
         // mask only: one count per cell under test instead of an order-statistic selection (k_cfar2d_os_mask)
+        // the GUI's window (gui_configs/processor_params.yaml: [5,5] / [3,2]) and the (4,4)/(2,2) of the tests: four cells per thread
+        if (n_frames > 0 && opt_int(ctx, "MMW_OS_MASK_FORM", 1) == 1) {
+            Cfar2dArgs a{d_X, nullptr, nullptr, d_mask, R, D, kind, train_r, train_d, guard_r, guard_d, scale, k_rank, 0};
+            const dim3 grid((D + OSV_T - 1) / OSV_T, (R + OSV_T - 1) / OSV_T, n_frames);
+#define MMW_OSV(tr, td, gr, gd) \
+    if (train_r == tr && train_d == td && guard_r == gr && guard_d == gd) { \
+        ProfScope ps(ctx, "cfar"); \
+        hipLaunchKernelGGL((k_cfar2d_os_mask_v<tr, td, gr, gd>), grid, dim3(256), 0, ctx->stream, a); \
+        return check_launch("cfar2d_os_mask_v"); \
+    }
+            MMW_OSV(5, 5, 3, 2)
+            MMW_OSV(4, 4, 2, 2)
+#undef MMW_OSV
+        }
         const int TW = OSM_TC + 2 * hd, TH = OSM_TR + 2 * hr, TWp = ((TW + 15) / 32) * 32 + 16;
         const size_t lds_m = (size_t)TH * TWp * sizeof(double);
         if (lds_m <= 64 * 1024) {
@@ -1526,6 +1540,19 @@ static void launch_angle_argmax(mmw_ctx *ctx, dim3 grid, const float2 *rd, const
 #define MMW_ARGMAX(NA) \
     hipLaunchKernelGGL(k_angle_argmax<NA>, grid, dim3(256), 0, ctx->stream, rd, dets, counts, idx, V, S, C, cap, ants, A, shift, twA, rf)
     // lists of up to 8 antennas with the error bound: the lane-resident routine of the fused detection stage
+    if (rf.l1 && ants.n <= DET_MAX_ANT && A == 64 && opt_int(ctx, "MMW_ARGMAX_FORM", 1) == 1) {
+        // one lane per detection (64 bins as register FFTs): 256 detections of a frame per workgroup and pass
+        const dim3 g2((unsigned)std::min((cap + 255) / 256, 4), grid.y);
+#define MMW_ARGMAX_DETS(NA, SH) \
+    hipLaunchKernelGGL((k_angle_argmax_dets<NA, SH>), g2, dim3(256), 0, ctx->stream, rd, dets, counts, idx, V, S, C, cap, ants, twA, rf)
+        if (ants.n <= 4) {
+            if (shift) MMW_ARGMAX_DETS(4, true); else MMW_ARGMAX_DETS(4, false);
+        } else {
+            if (shift) MMW_ARGMAX_DETS(8, true); else MMW_ARGMAX_DETS(8, false);
+        }
+#undef MMW_ARGMAX_DETS
+        return;
+    }
     if (rf.l1 && ants.n <= DET_MAX_ANT && A <= 1024) {
         if (ants.n <= 4)
             hipLaunchKernelGGL(k_angle_argmax_lanes<4>, grid, dim3(256), (size_t)A * 8, ctx->stream, rd, dets, counts, idx, V, S, C, cap, ants, A,

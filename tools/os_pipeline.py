@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only-default", action="store_true", help="the default variant only (for a kernel trace)")
     args = ap.parse_args()
     F, cap = args.frames, 2048
     ctx = _lib.Context(0)
@@ -49,7 +50,7 @@ def main():
     ref = None
     for tag, opts in (("worst_case_bound_dense", {}),
                       ("worst_case_bound_direct_sums", {"MMW_ARGMAX_DENSE_MIN": 1 << 30}),
-                      ("eighth_of_the_bound_direct_sums", {"MMW_ARGMAX_DENSE_MIN": 1 << 30, "MMW_ARGMAX_BOUND_DIV": 8})):
+                      ("eighth_of_the_bound_direct_sums", {"MMW_ARGMAX_DENSE_MIN": 1 << 30, "MMW_ARGMAX_BOUND_DIV": 8}))[:1 if args.only_default else 3]:
         for k in ("MMW_ARGMAX_DENSE_MIN", "MMW_ARGMAX_BOUND_DIV"):
             ctx.set_option(k, opts.get(k))
         run(count=True)
