@@ -13,11 +13,14 @@
 //   Z[s][k]   = FFT_C( hann(C)[c] x[s][c] )[k]         one 128-point float64 FFT per sample row: 256 rows, 1.1 MFLOP per plane
 //   X[r][k]   = sum_s hann(S)[s] W_S^(r s) Z[s][k]     256 complex multiply-adds per needed cell
 //
-// One 1024-thread workgroup per (frame, antenna of the list) walks the plane in passes of 64 rows: a group of 16 lanes
-// transforms one row (8 points per lane in registers, then a 16-point transform across the lanes through the row's own 2 KB
-// of LDS), the pass's spectra stay in the LDS (128 KB) and four lanes per needed cell add up their 16 rows each; the partial
-// sums live in registers across the passes.  Then k_argmax64_list runs the float64 angle DFT + first-maximum argmax per
-// flagged evaluation (argmax64_wave, the routine behind every other float64 argmax of the library).
+// One 512-thread workgroup per (frame, antenna of the list) walks the plane in passes of 64 rows: EIGHT lanes transform one row
+// -- 16 points per lane: a 16-point register FFT, the W_128 twiddles from registers, one exchange through the row's own slab of
+// the LDS (swizzled: element (k2, n1) at k2 * 8 + ((n1 + k2) & 7), so that the 128-byte runs a lane reads back spread over the
+// banks), two 8-point register FFTs per lane -- the pass's spectra stay in the LDS and eight lanes per needed cell add up their
+// 8 rows each; the partial sums live in registers across the passes.  Three 16-byte LDS operations per point (the first form --
+// 16 lanes x 8 points, a radix-2 split of the cross-lane level, twiddles and windows from LDS tables -- made six, and the 16-byte
+// stores cost 13 LDS cycles each: it was bound by them, 70 k clocks per plane).  Then k_argmax64_list runs the float64 angle
+// DFT + first-maximum argmax per flagged evaluation (argmax64_wave, the routine behind every other float64 argmax of the library).
 // The frame's flagged detections are found through flagpos[f][det] (1 + position in the flagged list, written by
 // k_angle_argmax next to the list itself), so nothing is sorted.
 #pragma once
@@ -40,28 +43,26 @@ struct Cells64Args {
     const cplx<double> *twS, *twC;
 };
 
-constexpr int C64_NT = 1024, C64_ROWS = 64;
-// LDS: the pass's spectra [64][C + 1], W_S, W_C, both windows, the needed cells (r << 16 | FFT bin; list position)
-inline size_t cells64_lds(int S, int C, int max_cells) {
-    return ((size_t)C64_ROWS * (C + 1) + S + C) * 16 + ((size_t)S + C) * 8 + (size_t)max_cells * 8 + 64;
+constexpr int C64_NT = 512, C64_ROWS = 64, C64_PITCH = 137, C64_CELLS = 256, C64_ITEMS = 8 * C64_CELLS / C64_NT;
+// LDS: the pass's spectra [64][137], W_S, both windows, the chunk's cells (r << 16 | FFT bin; list position), wave counts
+inline size_t cells64_lds(int S, int C, int) {
+    return ((size_t)C64_ROWS * C64_PITCH + S) * 16 + ((size_t)S + C) * 8 + (size_t)C64_CELLS * 8 + 64;
 }
-inline int cells64_max_cells(int S, int C) {
-    const long room = 160L * 1024 - 256 - (long)cells64_lds(S, C, 0);
-    return room < 8 * 64 ? 0 : (int)std::min<long>(room / 8, 1024);
+inline int cells64_max_cells(int S, int C) {        // cells per chunk of a frame (0: the plane's tables do not fit the LDS)
+    return C == 128 && cells64_lds(S, C, 0) <= 160 * 1024 - 512 ? C64_CELLS : 0;
 }
 
 template <int C>
 __global__ __launch_bounds__(C64_NT) void k_cells64(Cells64Args a) {
-    static_assert(C == 128, "one Doppler row = 16 lanes x 8 points");
-    constexpr int R = C / 16, P = C + 1;
+    static_assert(C == 128, "one Doppler row = 8 lanes x 16 points");
+    constexpr int P = C64_PITCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int n_cells_s;
     if (*a.n_flag < a.dense_min) return;
-    const int S = a.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n1 = lane & 15, g4 = lane >> 4;
+    const int S = a.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n1 = tid & 7, rl = tid >> 3;
     cplx<double> *Z = reinterpret_cast<cplx<double> *>(smem);
-    cplx<double> *twS = Z + C64_ROWS * P, *twC = twS + S;
-    double *wsl = reinterpret_cast<double *>(twC + C), *wcl = wsl + S;
-    int *cell_rk = reinterpret_cast<int *>(wcl + C), *cell_e = cell_rk + a.max_cells;
+    cplx<double> *twS = Z + C64_ROWS * P;
+    double *wsl = reinterpret_cast<double *>(twS + S), *wcl = wsl + S;
+    int *cell_rk = reinterpret_cast<int *>(wcl + C), *cell_e = cell_rk + C64_CELLS, *wcnt = cell_e + C64_CELLS;
     const long f = blockIdx.y;
     const int ai = blockIdx.x;
     int n_det = a.counts[f];
@@ -71,95 +72,106 @@ __global__ __launch_bounds__(C64_NT) void k_cells64(Cells64Args a) {
         twS[i] = a.twS[i];
         wsl[i] = a.ws[i];
     }
-    for (int i = tid; i < C; i += C64_NT) {
-        twC[i] = a.twC[i];
-        wcl[i] = a.wc[i];
-    }
-    const float2 *plane = a.cubes + (f * a.V + a.ants.idx[ai]) * (long)S * C;
-    // chunks of max_cells detections (one for every realistic frame): the flagged ones of a chunk are this pass's cells
-    for (int det0 = 0; det0 < n_det; det0 += a.max_cells) {
-        if (tid == 0) n_cells_s = 0;
-        __syncthreads();
-        for (int det = det0 + tid; det < n_det && det < det0 + a.max_cells; det += C64_NT) {
-            const int e = a.flagpos[f * a.cap + det] - 1;
-            if (e >= 0) {
-                const int r = a.dets[(f * a.cap + det) * 2];
-                int k = a.dets[(f * a.cap + det) * 2 + 1] - C / 2;         // FFT bin behind the fftshifted Doppler index
-                if (k < 0) k += C;
-                const int pos = atomicAdd(&n_cells_s, 1);
-                cell_rk[pos] = (r << 16) | k;
-                cell_e[pos] = e;
-            }
-        }
-        __syncthreads();
-        const int n_cells = n_cells_s;
-        if (n_cells == 0) continue;                                         // (uniform)
-        // four lanes per cell; a thread's items are the same in every pass: partial sums in registers
-        constexpr int ITEMS = 4;                                            // 4 * max_cells (<= 1024) / 1024 threads
-        cplx<double> acc[ITEMS];
+    for (int i = tid; i < C; i += C64_NT) wcl[i] = a.wc[i];
+    // W_128^(n1 k2), k2 = 1 .. 15: the lane's inter-level twiddles, in registers for the whole plane
+    cplx<double> tw1[16];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) acc[j] = cplx<double>{0.0, 0.0};
-        // the samples of the NEXT pass travel while this one is transformed and summed (one workgroup per CU: nothing else
-        // would cover the trip); unconditional clamped loads
-        const int rl = 4 * wave + g4;
-        float2 raw[R];
+    for (int k2 = 1; k2 < 16; ++k2) tw1[k2] = a.twC[(n1 * k2) & (C - 1)];
+    const float2 *plane = a.cubes + (f * a.V + a.ants.idx[ai]) * (long)S * C;
+    cplx<double> *slab = Z + rl * P;                                    // the row's own LDS: (k2, n1) swizzled first, [k] afterwards
+    // chunks of C64_CELLS flagged detections in list order (one chunk for every realistic frame)
+    for (int c0 = 0;; c0 += C64_CELLS) {
+        // ---- the chunk's cells: flagged detections with ordinal c0 .. c0 + 255 (ordinal = rank among the flagged, detection order)
+        int running = 0;
+        for (int det0 = 0; det0 < n_det; det0 += C64_NT) {
+            const int det = det0 + tid;
+            const int e = det < n_det ? a.flagpos[f * a.cap + det] - 1 : -1;
+            const unsigned long long bal = __ballot(e >= 0);
+            if (lane == 0) wcnt[wave] = __popcll(bal);
+            __syncthreads();
+            int before = running, total = running;
+#pragma unroll
+            for (int w = 0; w < C64_NT / 64; ++w) {
+                const int cw = wcnt[w];
+                if (w < wave) before += cw;
+                total += cw;
+            }
+            const int ord = before + __popcll(bal & ((1ull << lane) - 1ull)) - c0;
+            if (e >= 0 && ord >= 0 && ord < C64_CELLS) {
+                const int r = a.dets[(f * a.cap + det) * 2];
+                int k = a.dets[(f * a.cap + det) * 2 + 1] - C / 2;     // FFT bin behind the fftshifted Doppler index
+                if (k < 0) k += C;
+                cell_rk[ord] = (r << 16) | k;
+                cell_e[ord] = e;
+            }
+            running = total;
+            __syncthreads();
+        }
+        const int n_cells = running - c0 < C64_CELLS ? running - c0 : C64_CELLS;
+        if (n_cells <= 0) break;                                        // (uniform)
+        // eight lanes per cell; a thread's items are the same in every pass: partial sums in registers
+        cplx<double> acc[C64_ITEMS];
+#pragma unroll
+        for (int j = 0; j < C64_ITEMS; ++j) acc[j] = cplx<double>{0.0, 0.0};
+        // the samples of the NEXT pass travel while this one is transformed and summed; unconditional clamped loads
+        float2 raw[16];
         auto fetch = [&](int s0) {
             const int s = s0 + rl, sc = s < S ? s : S - 1;
             const float2 *rowp = plane + (long)sc * C;
 #pragma unroll
-            for (int n2 = 0; n2 < R; ++n2) raw[n2] = rowp[n1 + 16 * n2];
+            for (int n2 = 0; n2 < 16; ++n2) raw[n2] = rowp[n1 + 8 * n2];
         };
         fetch(0);
         for (int s0 = 0; s0 < S; s0 += C64_ROWS) {
-            // ---- Doppler FFT of rows s0 .. s0 + 63: wave w, lane group g4 -> row 4 w + g4; lane n1 holds c = n1 + 16 n2
+            // ---- Doppler FFT of rows s0 .. s0 + 63: lanes 8 rl .. 8 rl + 7 -> row rl; lane n1 holds c = n1 + 8 n2
             {
-                const int s = s0 + rl, sc = s < S ? s : S - 1;
-                const double wrow = s < S ? wsl[sc] : 0.0;                  // hann(S)[s] rides along; rows past the plane: zero
-                cplx<double> x[R];
+                const int s = s0 + rl;
+                const double wrow = s < S ? wsl[s] : 0.0;                   // hann(S)[s] rides along; rows past the plane: zero
+                cplx<double> x[16];
 #pragma unroll
-                for (int n2 = 0; n2 < R; ++n2) {
-                    const float2 t = raw[n2];
-                    const double w = wcl[n1 + 16 * n2] * wrow;
-                    x[n2] = cplx<double>{(double)t.x * w, (double)t.y * w};
+                for (int n2 = 0; n2 < 16; ++n2) {
+                    const double w = wcl[n1 + 8 * n2] * wrow;
+                    x[n2] = cplx<double>{(double)raw[n2].x * w, (double)raw[n2].y * w};
                 }
                 fetch(s0 + C64_ROWS < S ? s0 + C64_ROWS : s0);
-                RegFFT<R, double>::run(x);
-                cplx<double> *slab = Z + rl * P;                            // the row's own LDS: [k2][n1] now, [k] afterwards
-                static_for<R>([&](auto K) {
+                RegFFT<16, double>::run(x);                                 // over n2: X1[k2] in x[bitrev(k2)]
+                static_for<16>([&](auto K) {
                     constexpr int k2 = decltype(K)::value;
-                    slab[k2 * 16 + n1] = cmul(x[bitrev<R>(k2)], twC[(n1 * k2) & (C - 1)]);
+                    const cplx<double> v = x[bitrev<16>(k2)];
+                    slab[k2 * 8 + ((n1 + k2) & 7)] = k2 == 0 ? v : cmul(v, tw1[k2]);
                 });
-                // second level: lane (k2, h) = (n1 >> 1, n1 & 1) takes the bins k = k2 + 8 k1 with k1 = 2 j + h:
-                //   Y[j] = FFT_8( (in[n] +- in[n + 8]) W_16^(h n) )   -- a radix-2 split of the 16-point transform over n1.
-                // One wave, LDS operations in order: every lane's reads below are issued before any lane's writes.
-                const int k2 = n1 >> 1, h = n1 & 1;
-                cplx<double> y[8];
+                __builtin_amdgcn_wave_barrier();
+                // second level over n1 (the row's eight lanes, one wave: LDS operations of a wave execute in order): lane n1 takes
+                // k2 = n1 and n1 + 8, bins k = k2 + 16 k1
+                cplx<double> ya[8], yb[8];
 #pragma unroll
                 for (int n = 0; n < 8; ++n) {
-                    const cplx<double> p = slab[k2 * 16 + n], q = slab[k2 * 16 + n + 8];
-                    const cplx<double> d = h ? p - q : p + q;
-                    y[n] = h ? cmul(d, twC[(C / 16) * n]) : d;
+                    ya[n] = slab[n1 * 8 + ((n + n1) & 7)];
+                    yb[n] = slab[(n1 + 8) * 8 + ((n + n1) & 7)];           // ((n + n1 + 8) & 7 == (n + n1) & 7)
                 }
-                RegFFT<8, double>::run(y);
-                static_for<8>([&](auto J) {
-                    constexpr int j = decltype(J)::value;
-                    slab[k2 + R * (2 * j + h)] = y[bitrev<8>(j)];
+                RegFFT<8, double>::run(ya);
+                RegFFT<8, double>::run(yb);
+                __builtin_amdgcn_wave_barrier();
+                static_for<8>([&](auto K) {
+                    constexpr int k1 = decltype(K)::value;
+                    slab[n1 + 16 * k1] = ya[bitrev<8>(k1)];
+                    slab[n1 + 8 + 16 * k1] = yb[bitrev<8>(k1)];
                 });
             }
             __syncthreads();
-            // ---- range sums of the needed cells over this pass's rows (quarter q of a cell: rows s0 + 16 q .. + 15)
+            // ---- range sums of the needed cells over this pass's rows (eighth q of a cell: rows s0 + 8 q .. + 7)
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const int it = tid + j * C64_NT, i = it >> 2, q = it & 3;
+            for (int j = 0; j < C64_ITEMS; ++j) {
+                const int it = tid + j * C64_NT, i = it >> 3, q = it & 7;
                 if (i < n_cells) {
                     const int rk = cell_rk[i], r = rk >> 16, k = rk & 0xffff;
-                    const int sq = s0 + 16 * q;
+                    const int sq = s0 + 8 * q;
                     cplx<double> c = twS[(int)(((long)r * sq) % S)];
                     const cplx<double> step = twS[r % S];
-                    const cplx<double> *zp = Z + (16 * q) * P + k;
+                    const cplx<double> *zp = Z + (8 * q) * P + k;
                     cplx<double> sum = acc[j];
-#pragma unroll 4
-                    for (int t = 0; t < 16; ++t) {                          // (rows past the plane hold zeros)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {                           // (rows past the plane hold zeros)
                         const cplx<double> z = zp[t * P];
                         sum.x = fma(z.x, c.x, fma(-z.y, c.y, sum.x));
                         sum.y = fma(z.x, c.y, fma(z.y, c.x, sum.y));
@@ -170,17 +182,18 @@ __global__ __launch_bounds__(C64_NT) void k_cells64(Cells64Args a) {
             }
             __syncthreads();
         }
-        // ---- the four quarters of a cell sit in adjacent lanes
+        // ---- the eight parts of a cell sit in adjacent lanes
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int it = tid + j * C64_NT, i = it >> 2, q = it & 3;
+        for (int j = 0; j < C64_ITEMS; ++j) {
+            const int it = tid + j * C64_NT, i = it >> 3, q = it & 7;
             cplx<double> s = acc[j];
-            for (int d = 1; d < 4; d <<= 1) {
+            for (int d = 1; d < 8; d <<= 1) {
                 s.x += __shfl_xor(s.x, d, 64);
                 s.y += __shfl_xor(s.y, d, 64);
             }
             if (i < n_cells && q == 0) a.out[(long)cell_e[i] * a.n_ant + ai] = s;
         }
+        if (running <= c0 + C64_CELLS) break;                           // (uniform) no further chunk
         __syncthreads();
     }
 }

@@ -110,6 +110,14 @@ struct mmw_ctx {
     hipEvent_t det_begin = nullptr, det_rd_done = nullptr, det_scr_done = nullptr;
     hipStream_t q_side = nullptr;               // refinement of the flagged argmax evaluations, beside the exact CFAR cells
     hipEvent_t side_fork = nullptr, side_join = nullptr;
+    // deferred tail of mmw_detect_points (the exact cells + list insertion, beside the refinement on q_side): the context stream
+    // does not wait for it at the end of a call, so the range-Doppler kernel of the NEXT call runs beside it; every other entry
+    // point joins it first (join_pipe), as with the chain's queues
+    hipStream_t q_tail = nullptr;
+    hipEvent_t tail_done = nullptr;
+    bool tail_pending = false;
+    int rd_leave_cus = 0;                       // CUs the persistent range-Doppler launch leaves free (for a tail running beside it)
+    std::vector<std::pair<const char *, size_t>> tail_bufs;     // what the pending tail reads / writes (besides the scratch)
     bool det_unavailable = false;
     hipStream_t q_copy = nullptr;               // copy queue of the host-streaming API (mmw_memcpy_async), created lazily
     std::vector<void *> host_owned;             // mmw_host_alloc'ed pinned blocks still alive
@@ -194,8 +202,16 @@ template <typename T> int get_table(mmw_ctx *ctx, int kind, int N, const void **
 // chain does not do this itself so that back-to-back mmw_chain3d calls keep the RD || angle pipeline full;
 // every other entry point that touches the context stream calls it first.
 int chain_settle(mmw_ctx *ctx);     // mmwgpu.hip
-inline int join_pipe(mmw_ctx *ctx) {
+inline int join_tail(mmw_ctx *ctx) {
+    if (ctx->tail_pending) {
+        MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->tail_done, 0));
+        ctx->tail_pending = false;
+    }
+    return MMW_OK;
+}
+inline int join_pipe(mmw_ctx *ctx, bool keep_tail = false) {
     MMW_HIP(hipSetDevice(ctx->device));     // several contexts (devices) may live in one process
+    if (!keep_tail) MMW_TRY(join_tail(ctx));
     if (ctx->pipe_pending) {
         for (int i = 0; i < PIPE_RING_MAX; ++i)
             if (ctx->pipe_ang_used[i]) MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_ang[i], 0));
@@ -216,6 +232,9 @@ inline int ensure_scratch(mmw_ctx *ctx, size_t bytes) {
             MMW_HIP(hipStreamSynchronize(ctx->q_ang));
             MMW_HIP(hipStreamSynchronize(ctx->q_ang2));
         }
+        if (ctx->q_side) MMW_HIP(hipStreamSynchronize(ctx->q_side));
+        if (ctx->q_tail) MMW_HIP(hipStreamSynchronize(ctx->q_tail));
+        ctx->tail_pending = false;
         MMW_HIP(hipStreamSynchronize(ctx->stream));
         MMW_HIP(hipFree(ctx->scratch));
         ctx->scratch = nullptr;

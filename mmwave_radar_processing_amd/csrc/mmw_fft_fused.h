@@ -1251,6 +1251,7 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
     const int pf = ctx->active_cus > 0 ? 0 : 8;
     if (pf == 8 && rv.vskip <= 2) {
         int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu);
+        if (ctx->rd_leave_cus > 0 && grid > 2 * ctx->rd_leave_cus) grid -= ctx->rd_leave_cus;      // (one workgroup fills a CU)
         if (grid > planes) grid = planes;
         auto launch = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);

@@ -206,7 +206,11 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->q_side);
         (void)hipStreamDestroy(ctx->q_side);
     }
-    for (hipEvent_t e : {ctx->det_begin, ctx->det_rd_done, ctx->det_scr_done, ctx->side_fork, ctx->side_join})
+    if (ctx->q_tail) {
+        (void)hipStreamSynchronize(ctx->q_tail);
+        (void)hipStreamDestroy(ctx->q_tail);
+    }
+    for (hipEvent_t e : {ctx->det_begin, ctx->det_rd_done, ctx->det_scr_done, ctx->side_fork, ctx->side_join, ctx->tail_done})
         if (e) (void)hipEventDestroy(e);
     if (ctx->q_copy) {
         (void)hipStreamSynchronize(ctx->q_copy);
@@ -1885,7 +1889,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
                       int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap, const int *h_az,
                       int n_az, int shift_az, const int *h_el, int n_el, int shift_el, int A, int *h_stats) {
     MMW_REQUIRE(ctx && d_cubes && d_rd && d_l1 && d_dets && d_counts, "null argument");
-    MMW_JOIN(ctx);
+    MMW_TRY(join_pipe(ctx, true));      // (the previous call's deferred tail: joined below, behind this call's range-Doppler kernel)
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && cap >= 0 && A > 0, "bad shape");
     MMW_REQUIRE(train_r >= 0 && train_d >= 0 && guard_r >= 0 && guard_d >= 0, "negative window size");
     MMW_REQUIRE(n_az >= 0 && n_el >= 0 && (n_az == 0 || d_az_idx) && (n_el == 0 || d_el_idx), "antenna list without an index buffer");
@@ -1948,10 +1952,31 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     char *next = base + b_ctl + b_ff + b_cells + b_bits + b_sync;
     int *list = (n_az || n_el) ? (int *)next : nullptr;
     cplx<double> *part = (n_az || n_el) ? (cplx<double> *)(next + b_list2) : nullptr;
+    // Back-to-back calls (a frame loop over resident chunks): the previous call's tail -- exact cells, list insertion, float64
+    // refinement: ~0.15 ms of latency-bound launches that leave the chip almost idle -- is still running on its side queues.
+    // This call's range-Doppler kernel touches nothing the tail uses (the fused 256 x 128 kernel needs no scratch; its output
+    // buffers are checked against the tail's), so it goes first and the tail is joined in front of the screening stage.
+    bool rd_first = !overlap && ctx->tail_pending && fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0);
+    if (rd_first) {
+        const std::pair<const char *, size_t> outs[2] = {{(const char *)d_rd, (size_t)n_frames * V * S * C * 8},
+                                                         {(const char *)d_l1, (size_t)n_frames * V * sizeof(float)}};
+        for (const auto &o : outs)
+            for (const auto &t : ctx->tail_bufs)
+                if (o.first < t.first + t.second && t.first < o.first + o.second) rd_first = false;
+    }
+    if (rd_first) {
+        // the persistent kernel holds one workgroup per CU for its whole run: it leaves a few CUs to the tail's short workgroups
+        // (the kernel keeps its HBM rate down to ~224 CUs: DESIGN.md 4.9)
+        ctx->rd_leave_cus = std::max(0, std::min(opt_int(ctx, "MMW_DETECT_TAIL_CUS", 40), ctx->num_cu / 4));
+        const int rc = range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1);
+        ctx->rd_leave_cus = 0;
+        MMW_TRY(rc);
+    }
+    MMW_TRY(join_tail(ctx));
     MMW_HIP(hipMemsetAsync(a.ctl, 0, DCTL_WORDS * sizeof(int), ctx->stream));      // counters
     if (overlap) MMW_HIP(hipMemsetAsync(sync_words, 0, b_sync, ctx->stream));
     // range-Doppler of every antenna (float32) with the planes' L1 norms
-    if (!overlap) MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
+    if (!overlap && !rd_first) MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
     const float eps = 5.9604645e-8f, div = argmax_bound_div(ctx);
     const int ulps = rd_error_ulps(S, C);
     a.rd = (const float2 *)d_rd;
@@ -2092,13 +2117,26 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     // speculative slots --, then k_detect_insert puts the cells decided positive into their lists.
     const bool refine = cap > 0 && (n_az || n_el);
     hipStream_t main_stream = ctx->stream;
+    if (!ctx->q_side) {
+        MMW_HIP(hipStreamCreateWithFlags(&ctx->q_side, hipStreamNonBlocking));
+        MMW_HIP(hipStreamCreateWithFlags(&ctx->q_tail, hipStreamNonBlocking));
+        MMW_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+        MMW_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+        MMW_HIP(hipEventCreateWithFlags(&ctx->tail_done, hipEventDisableTiming));
+    }
+    MMW_HIP(hipEventRecord(ctx->side_fork, main_stream));
+    MMW_HIP(hipStreamWaitEvent(ctx->q_tail, ctx->side_fork, 0));
+    // from here on the context stream is only the point the tail is joined to: on error, or when the caller wants the
+    // statistics / the tail is not to be deferred (MMW_DETECT_DEFER_TAIL=0), before this call returns; else at the next entry point
+    auto tail_end = [&](bool join_now) -> int {
+        MMW_HIP(hipEventRecord(ctx->tail_done, ctx->q_tail));
+        ctx->tail_pending = true;
+        ctx->tail_bufs = {{(const char *)d_cubes, (size_t)n_frames * V * S * C * 8}, {(const char *)d_dets, (size_t)n_frames * cap * 8},
+                          {(const char *)d_counts, (size_t)n_frames * 4}, {(const char *)d_az_idx, d_az_idx ? (size_t)n_frames * cap * 4 : 0},
+                          {(const char *)d_el_idx, d_el_idx ? (size_t)n_frames * cap * 4 : 0}};
+        return join_now ? join_tail(ctx) : MMW_OK;
+    };
     if (refine) {
-        if (!ctx->q_side) {
-            MMW_HIP(hipStreamCreateWithFlags(&ctx->q_side, hipStreamNonBlocking));
-            MMW_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-            MMW_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
-        }
-        MMW_HIP(hipEventRecord(ctx->side_fork, main_stream));
         MMW_HIP(hipStreamWaitEvent(ctx->q_side, ctx->side_fork, 0));
         ctx->stream = ctx->q_side;
         int rc;
@@ -2126,11 +2164,14 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         }
         ctx->stream = main_stream;
         MMW_HIP(hipEventRecord(ctx->side_join, ctx->q_side));      // (joined below in any case)
+        MMW_HIP(hipStreamWaitEvent(ctx->q_tail, ctx->side_join, 0));
         if (rc != MMW_OK) {
-            MMW_HIP(hipStreamWaitEvent(main_stream, ctx->side_join, 0));
+            (void)tail_end(true);
             return rc;
         }
     }
+    ctx->stream = ctx->q_tail;
+    int rc_tail = MMW_OK;
     {
         ProfScope ps(ctx, "detect_exact");
         CellExactArgs ce{};
@@ -2169,11 +2210,17 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
             std::fprintf(stderr, "cfar_cell_exact clocks: tables %lld range sums %lld doppler sums %lld decision %lld\n", h[1] - h[0], h[2] - h[1],
                          h[3] - h[2], h[4] - h[3]);
         }
-        const int rc = check_launch("cfar_cell_exact");
-        if (refine) MMW_HIP(hipStreamWaitEvent(main_stream, ctx->side_join, 0));
-        MMW_TRY(rc);
-        hipLaunchKernelGGL(k_detect_insert, dim3(std::min(n_frames, 4 * ctx->num_cu)), dim3(INS_NT), 0, ctx->stream, a);
-        MMW_TRY(check_launch("detect_insert"));
+        rc_tail = check_launch("cfar_cell_exact");
+        if (rc_tail == MMW_OK) {
+            hipLaunchKernelGGL(k_detect_insert, dim3(std::min(n_frames, 4 * ctx->num_cu)), dim3(INS_NT), 0, ctx->stream, a);
+            rc_tail = check_launch("detect_insert");
+        }
+    }
+    ctx->stream = main_stream;
+    {
+        const int rc_end = tail_end(rc_tail != MMW_OK || h_stats != nullptr || !opt_int(ctx, "MMW_DETECT_DEFER_TAIL", 1));
+        MMW_TRY(rc_tail);
+        MMW_TRY(rc_end);
     }
     if (h_stats) {
         int h[DCTL_WORDS];
