@@ -1743,6 +1743,58 @@ def test_detect_points_edge_cases_and_pipeline_fallback(monkeypatch):
             np.testing.assert_allclose(pcs[f], pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
 
 
+def test_detect_points_deferred_tail_back_to_back():
+    """mmw_detect_points does not join its tail (exact cells, list insertion, float64 refinement) at the end of a call: the next
+    call's range-Doppler launch runs beside it, every other entry point joins it first.  Back-to-back calls -- same buffers
+    again, then other inputs into other buffers -- with the band widened (so that there ARE undecided cells and flagged
+    evaluations) leave exactly what calls that join their own tail leave (MMW_DETECT_DEFER_TAIL=0 / the statistics request)."""
+    shape, F, cap = (12, 256, 128), 96, 512
+    V, S, C = shape
+    ctx = _lib.Context(0)
+    ctx.set_option("MMW_DETECT_BAND_MULT", 20)
+    cfar = CaCFAR2D((4, 4), (2, 2), 1e-5)
+    az, el = list(range(8)), [8, 9, 10, 11]
+    a_az, n_az = _lib.int_array(az)
+    a_el, n_el = _lib.int_array(el)
+    d_a, d_b = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * V * S * C * 8)
+    _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_a.ptr, F, V, S, C, 515151, 8, 30.0))
+    _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_b.ptr, F, V, S, C, 626262, 8, 30.0))
+    ref_a = _detect_points_raw(ctx, d_a, F, shape, cfar, cap, az, el)      # (asks for the statistics: joins its own tail)
+    ref_b = _detect_points_raw(ctx, d_b, F, shape, cfar, cap, az, el)
+    assert ref_a[4][1] > 0 and ref_a[4][3] + ref_a[4][4] > 0, ref_a[4]      # undecided cells and flagged evaluations exist
+
+    def buffers():
+        return [ctx.alloc(n) for n in (F * V * S * C * 8, F * V * 4, F * cap * 8, F * 4, F * cap * 4, F * cap * 4)]
+
+    def call(d_in, b):
+        _lib.check(ctx.lib.mmw_detect_points(ctx.handle, d_in.ptr, b[0].ptr, b[1].ptr, None, b[2].ptr, b[3].ptr, b[4].ptr, b[5].ptr,
+                                             F, V, S, C, cfar.kind, 4, 4, 2, 2, float(cfar._scale()), 0, cap, a_az, n_az, 1, a_el, n_el,
+                                             0, 64, None))
+
+    def result(b):
+        return (b[3].download((F,), np.int32), b[2].download((F, cap, 2), np.int32), b[4].download((F, cap), np.int32),
+                b[5].download((F, cap), np.int32))
+
+    b1, b2 = buffers(), buffers()
+    for defer in (1, 0):
+        ctx.set_option("MMW_DETECT_DEFER_TAIL", defer)
+        for b in (b1, b2):
+            for x in b[2:]:
+                x.upload(np.full(x.nbytes // 4, -7, np.int32))
+        call(d_a, b1)           # A into b1 ...
+        call(d_a, b1)           # ... again into the same buffers (its range-Doppler launch runs beside the first call's tail)
+        call(d_b, b2)           # B into other buffers, behind A's tail
+        call(d_a, b1)
+        got_a, got_b = result(b1), result(b2)       # (a download joins the pending tail)
+        for got, ref in ((got_a, ref_a), (got_b, ref_b)):
+            np.testing.assert_array_equal(got[0], ref[0])
+            keep = ref[0] >= 0
+            _same_points(tuple(x[keep] for x in got), tuple(x[keep] for x in ref[:4]))
+    for b in b1 + b2 + [d_a, d_b]:
+        b.free()
+    ctx.close()
+
+
 def test_detect_points_overlapped_schedule(monkeypatch):
     """The device-synchronised form of mmw_detect_points (range-Doppler producer and screening consumer side by side on
     disjoint CU sets, frames handed over through counters; the default for large batches of 256 x 128 planes, forced here
