@@ -12,6 +12,7 @@
 //   Doppler fftshift and the digit reversal folded into the index          (processors/range_doppler_resp.py:94-103).
 #pragma once
 #include "mmw_fft_mixed.h"
+#include "mmw_bf16x3.h"
 
 namespace mmw {
 
@@ -57,10 +58,19 @@ constexpr int threads_for(int S, int C) {
 }
 }  // namespace mixct
 
-constexpr size_t mixct_lds_bytes(int S, int C) {     // plane, inter-level twiddles, big-prime table, Hann tables, SYNC control words
+constexpr size_t mixct_lds_base(int S, int C) {      // plane, inter-level twiddles, big-prime table, Hann tables, SYNC control words
     const bool big = mixct::best_n1(S) == mixct::BIG_PRIME || mixct::best_n1(C) == mixct::BIG_PRIME;
-    return ((size_t)S * (C | 1) + S + C + (big ? mixct::BIG_PRIME : 0) + (S + C + 1) / 2) * sizeof(cplx<float>) + 16 + 64;
+    return (((size_t)S * (C | 1) + S + C + (big ? mixct::BIG_PRIME : 0) + (S + C + 1) / 2) * sizeof(cplx<float>) + 16 + 64 + 15) & ~(size_t)15;
 }
+constexpr size_t MIXCT_ABF_BYTES = (size_t)2 * 2 * 4 * 3 * 64 * 16;      // the big-prime level's bfloat16 x 3 operand table
+// (254 x 50 -- 1024 threads, 128 registers each, the big prime on the range axis -- spills in the bfloat16 form: measured slower
+//  than the float32 MFMAs there, 1.13 against 1.02 us per 12-antenna frame; 63 x 127 and 127 x 32 have the room)
+constexpr bool mixct_abf_fits(int S, int C) {
+    const bool big = mixct::best_n1(S) == mixct::BIG_PRIME || mixct::best_n1(C) == mixct::BIG_PRIME;
+    const bool room = mixct::threads_for(S, C) <= 512 || mixct::best_n1(S) != mixct::BIG_PRIME;
+    return big && room && mixct_lds_base(S, C) + MIXCT_ABF_BYTES <= 160 * 1024 - 256;
+}
+constexpr size_t mixct_lds_bytes(int S, int C) { return mixct_lds_base(S, C) + (mixct_abf_fits(S, C) ? MIXCT_ABF_BYTES : 0); }
 
 struct RdMixedCtArgs {
     const void *in;             // complex64 planes
@@ -69,6 +79,7 @@ struct RdMixedCtArgs {
     const float *win_s, *win_c;
     const cplx<float> *tw2_s, *tw2_c;       // [S2][S1] and [C2][C1]: W_S^(n2 k1), W_C^(m2 k1)
     const float *cs_big;        // coefficient table of the big-prime level (nullptr when no axis has one)
+    const void *abf_big;        // the same coefficients as bfloat16 x 3 MFMA operands (get_bigprime_bf16_table; nullptr: float32 MFMAs)
     RawView raw;
     long planes;
     long long *clk;             // diagnostics (MMW_PHASE_CLOCKS=1): s_memtime at the phase boundaries of workgroup 0
@@ -123,9 +134,18 @@ typedef float mixct_v16f __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float lane_xor1(float v) {      // the value of lane ^ 1 (quad_perm [1, 0, 3, 2])
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
 }
+// abf != nullptr: the two products on v_mfma_f32_32x32x16_bf16 with exact three-way operand splits (mmw_bf16x3.h) -- the
+// float32 MFMAs above cannot overlap with the vector work next to them (operand reads, s / d, index updates: 64 x 64 MFMA cycles
+// PLUS ~1.3 k vector cycles per tile), the bfloat16 ones can, and six of nine partial products over 16 values of k cost 6 x 32
+// cycles where 8 float32 MFMAs cost 512.  The coefficient pieces are precomputed in operand layout (abf[matrix][kt][t][piece][lane],
+// 16 bytes each: get_bigprime_bf16_table); the data operand is split on the fly.  Error budget: all SMALL partial products of
+// the 64-term sum (a1 b2, a2 b1, a1 b3, a2 b2, a3 b1: <= 2^-7 of the leading ones) are accumulated FIRST, the four MFMAs of the
+// leading pieces last, so only those 4 x 17 float32 additions round at the scale of the result: 68 + 20 x 17 x 2^-7 (small
+// phase) + 3 (dropped products) + pair sums and the combine = under 80 eps sum |x_j|, the budget rd_error_ulps() books for this
+// level in either form.  (The leading pieces of the data are formed twice -- once per phase -- instead of being kept: registers.)
 template <int P, int NT, int N_INNER, int INNER_STRIDE, int N_OUTER, int OUTER_STRIDE, int ESTRIDE, bool TW>
 __device__ __forceinline__ void dft_level_bigprime_ct(cplx<float> *lds, const cplx<float> *tw2, const float *cst, int tid,
-                                                      long long *clk = nullptr) {
+                                                      long long *clk = nullptr, const void *abf = nullptr) {
     constexpr int H = (P - 1) / 2, N_GROUPS = N_INNER * N_OUTER, NCOL = 2 * N_GROUPS, NTILES = (NCOL + 31) / 32;
     constexpr int JOBS = 2 * NTILES, NW = NT / 64;
     static_assert(H + 1 == 64, "two 32-row output tiles");
@@ -138,7 +158,56 @@ __device__ __forceinline__ void dft_level_bigprime_ct(cplx<float> *lds, const cp
     const int g = valid ? n >> 1 : 0, comp = n & 1, o = g / N_INNER, i = g - o * N_INNER;
     const int boff = 2 * (i * INNER_STRIDE + o * OUTER_STRIDE) + comp;      // float index of element 0, this component
     mixct_v16f dc = {0}, ds = {0};
-    if (job < JOBS) {
+    if (abf) {
+        if (job < JOBS) {
+            const u32x4 *tc = reinterpret_cast<const u32x4 *>(abf) + (size_t)(kt * 4) * 3 * 64 + lane;          // cosines
+            const u32x4 *ts = reinterpret_cast<const u32x4 *>(abf) + (size_t)((2 + kt) * 4) * 3 * 64 + lane;    // sines
+            const float *pa = lf + boff + 16 * ESTRIDE * kk;             // x_j,     j = 16 t + 8 kk + i
+            const float *pb = lf + boff + 2 * ESTRIDE * (P - 8 * kk);    // x_{P-j}
+            const float *p0 = kk ? pb : pa;                              // (j = 0 has no partner: s_0 = x_0, d_0 = 0)
+            // SUM: s_j = x_j + x_{P-j}, else d_j = x_j - x_{P-j}
+            auto gather = [&](int t, auto SUM, float (&v)[8]) {
+                constexpr bool sum = decltype(SUM)::value;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xa = pa[2 * ESTRIDE * (16 * t + i)];
+                    const float xb = i == 0 ? (t == 0 ? p0 : pb - 2 * ESTRIDE * 16 * t)[0] : pb[-2 * ESTRIDE * (16 * t + i)];
+                    const bool first = i == 0 && t == 0 && kk == 0;
+                    v[i] = sum ? (first ? xa : xa + xb) : (first ? 0.f : xa - xb);
+                }
+            };
+            auto piece = [](const u32x4 *tab, int idx) { return __builtin_bit_cast(bf16x8, tab[idx * 64]); };
+            // One matrix at a time (registers: the persistent kernels hold the next plane's samples meanwhile), TWO accumulators
+            // taking the MFMAs in turn: a wave issues in order, so a chain of MFMAs on one accumulator stalls it for the whole
+            // latency of each -- nothing else of the wave, not even the next step's operand arithmetic, gets issued meanwhile.
+            auto product = [&](const u32x4 *tab, auto SUM) {
+                mixct_v16f acc0 = {0}, acc1 = {0};
+                bf16x8 lead[4];                                         // the data's leading pieces, for phase 2
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {                           // phase 1: every partial product below the leading one
+                    float v[8];
+                    gather(t, SUM, v);
+                    bf16x8 b2, b3;
+                    const bf16x8 a1 = piece(tab, t * 3), a2 = piece(tab, t * 3 + 1), a3 = piece(tab, t * 3 + 2);
+                    split_bf16x3(v, lead[t], b2, b3);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, lead[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, lead[t], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);                  // (keep the steps apart: unrolled freely, all 24 coefficient reads come first)
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t += 2) {                        // phase 2: the leading pieces
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(piece(tab, t * 3), lead[t], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(piece(tab, t * 3 + 3), lead[t + 1], acc0, 0, 0, 0);
+                }
+                return acc0 + acc1;
+            };
+            dc = product(tc, std::true_type{});
+            ds = product(ts, std::false_type{});
+        }
+    } else if (job < JOBS) {
         const int k = kt * 32 + (lane & 31);                // this lane's row of the A operand
         int idx = kk ? k : 0;                               // (j k) mod P, j = 2 t + kk
         const int step = 2 * k >= P ? 2 * k - P : 2 * k;
@@ -183,9 +252,9 @@ __device__ __forceinline__ void dft_level_bigprime_ct(cplx<float> *lds, const cp
 // level dispatch: register-resident radix or the big prime
 template <int R, int NT, int N_INNER, int INNER_STRIDE, int N_OUTER, int OUTER_STRIDE, int ESTRIDE, bool TW>
 __device__ __forceinline__ void dft_level_any_ct(cplx<float> *lds, const cplx<float> *tw2, const float *cs, int tid,
-                                                 long long *clk = nullptr) {
+                                                 long long *clk = nullptr, const void *abf = nullptr) {
     if constexpr (R == mixct::BIG_PRIME)
-        dft_level_bigprime_ct<R, NT, N_INNER, INNER_STRIDE, N_OUTER, OUTER_STRIDE, ESTRIDE, TW>(lds, tw2, cs, tid, clk);
+        dft_level_bigprime_ct<R, NT, N_INNER, INNER_STRIDE, N_OUTER, OUTER_STRIDE, ESTRIDE, TW>(lds, tw2, cs, tid, clk, abf);
     else
         dft_level_ct<R, NT, N_INNER, INNER_STRIDE, N_OUTER, OUTER_STRIDE, ESTRIDE, TW>(lds, tw2, tid);
 }
@@ -305,6 +374,16 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         for (int i = tid; i < C; i += NT) tw_c[i] = a.tw2_c[i];
     if constexpr (BIG)
         for (int i = tid; i < 2 * mixct::BIG_PRIME; i += NT) cst[i] = a.cs_big[i];
+    // the operand table of the bfloat16 form of the big-prime level lives in the LDS: a global load inside the level would
+    // have to wait (in-order vmcnt) for the next plane's prefetch
+    [[maybe_unused]] u32x4 *abf_l = reinterpret_cast<u32x4 *>(smem + mixct_lds_base(S, C));
+    const void *abf = nullptr;
+    if constexpr (mixct_abf_fits(S, C)) {
+        if (a.abf_big) {
+            for (int i = tid; i < (int)(MIXCT_ABF_BYTES / 16); i += NT) abf_l[i] = reinterpret_cast<const u32x4 *>(a.abf_big)[i];
+            abf = abf_l;
+        }
+    }
     for (int i = tid; i < S; i += NT) win_s[i] = a.win_s[i];
     for (int i = tid; i < C; i += NT) win_c[i] = a.win_c[i];
     __syncthreads();
@@ -354,7 +433,10 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
             }
         } else
             stash(t);
-        if constexpr (PERSIST && !SYNC) {
+        // (a big-prime FIRST level keeps two MFMA accumulators, operand pieces and coefficient pieces in registers: the next
+        //  plane's loads are issued behind it -- the three remaining levels and the store still cover their flight)
+        constexpr bool FETCH_LATE = S1 == mixct::BIG_PRIME && mixct_abf_fits(S, C);
+        if constexpr (PERSIST && !SYNC && !FETCH_LATE) {
             if (item + gridDim.x < n_items) fetch(in_base + skip_block_plane(item + gridDim.x, a.raw) * a.in_plane_stride);
         }
         if constexpr (!SYNC) {
@@ -374,11 +456,14 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         }
         phase_mark(a.clk, 1, tid);
         // ---- range axis: sample s = S2 n1 + n2 lives in row s.  A: groups (column, n2), radix S1; B: groups (column, k1), radix S2
-        dft_level_any_ct<S1, NT, C, 1, S2, Cp, S2 * Cp, (S2 > 1)>(lds, tw_s, cst, t, a.clk);
+        dft_level_any_ct<S1, NT, C, 1, S2, Cp, S2 * Cp, (S2 > 1)>(lds, tw_s, cst, t, a.clk, abf);
         if constexpr (SYNC) {
             if (tid == 0) lds_ctl[(iter + 1) & 1] = (int)next_ticket;      // the other waves learn it at this barrier
         }
         __syncthreads();
+        if constexpr (PERSIST && !SYNC && FETCH_LATE) {
+            if (item + gridDim.x < n_items) fetch(in_base + skip_block_plane(item + gridDim.x, a.raw) * a.in_plane_stride);
+        }
         long next_item = 0;
         if constexpr (SYNC) {
             next_item = __builtin_amdgcn_readfirstlane(lds_ctl[(iter + 1) & 1]);
@@ -391,7 +476,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
         }
         phase_mark(a.clk, 3, tid);
         // ---- Doppler axis: chirp c = C2 m1 + m2 lives in column c; lanes walk the rows (odd pitch: conflict free)
-        dft_level_any_ct<C1, NT, S, Cp, C2, 1, C2, (C2 > 1)>(lds, tw_c, cst, t, C1 == mixct::BIG_PRIME && S1 != mixct::BIG_PRIME ? a.clk : nullptr);
+        dft_level_any_ct<C1, NT, S, Cp, C2, 1, C2, (C2 > 1)>(lds, tw_c, cst, t, C1 == mixct::BIG_PRIME && S1 != mixct::BIG_PRIME ? a.clk : nullptr, abf);
         __syncthreads();
         phase_mark(a.clk, 4, tid);
         if constexpr (C2 > 1) {
@@ -501,6 +586,50 @@ inline int get_bigprime_table(mmw_ctx *ctx, int P, const void **out) {
     return MMW_OK;
 }
 
+// The same coefficients as operands of v_mfma_f32_32x32x16_bf16, split exactly into three bfloat16 pieces (truncation, as
+// split_bf16x3 does on the device): [matrix: cos, sin][kt][t][piece][lane] x 16 bytes -- lane (r = lane & 31, h = lane >> 5)
+// holds A[row k = 32 kt + r][j = 16 t + 8 h + i], i = 0 .. 7 (element 2 q in the low half of dword q).  48 KB, cached per context.
+inline int get_bigprime_bf16_table(mmw_ctx *ctx, int P, const void **out) {
+    const auto key = std::make_tuple(202, P, 0);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return MMW_OK;
+    }
+    std::vector<uint32_t> h((size_t)2 * 2 * 4 * 3 * 64 * 4);
+    auto bits = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; };
+    auto val = [](uint32_t u) { float v; std::memcpy(&v, &u, 4); return v; };
+    for (int m = 0; m < 2; ++m)
+        for (int kt = 0; kt < 2; ++kt)
+            for (int t = 0; t < 4; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k = kt * 32 + (lane & 31), hh = lane >> 5;
+                    uint16_t pc[3][8];
+                    for (int i = 0; i < 8; ++i) {
+                        const int j = 16 * t + 8 * hh + i;
+                        const long double ang = 2.0L * M_PIl * (long double)(((long)j * k) % P) / (long double)P;
+                        const float a = m ? (float)sinl(ang) : (float)cosl(ang);
+                        const uint32_t a1 = bits(a) & 0xffff0000u;
+                        const float ra = a - val(a1);
+                        const uint32_t a2 = bits(ra) & 0xffff0000u;
+                        const float sa = ra - val(a2);
+                        pc[0][i] = (uint16_t)(a1 >> 16);
+                        pc[1][i] = (uint16_t)(a2 >> 16);
+                        pc[2][i] = (uint16_t)(bits(sa) >> 16);
+                    }
+                    for (int p = 0; p < 3; ++p)
+                        for (int q = 0; q < 4; ++q)
+                            h[((((size_t)(m * 2 + kt) * 4 + t) * 3 + p) * 64 + lane) * 4 + q] = (uint32_t)pc[p][2 * q] | ((uint32_t)pc[p][2 * q + 1] << 16);
+                }
+    void *d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(uint32_t)) != hipSuccess) return set_error(MMW_ERR_NOMEM, "hipMalloc for DFT coefficient table failed");
+    MMW_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    MMW_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->tables[key] = d;
+    *out = d;
+    return MMW_OK;
+}
+
 // cs != nullptr: the device-synchronised producer (MODE 2) on sync_cus CUs; *sync_grid returns the workgroups launched
 // (each draws one ticket past the end, the host mirrors that in its counter base).  sync_grid only: just report the grid.
 template <int S, int C>
@@ -527,6 +656,10 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
     if constexpr (S1 == mixct::BIG_PRIME || C1 == mixct::BIG_PRIME) {
         MMW_TRY(get_bigprime_table(ctx, mixct::BIG_PRIME, &p));
         a.cs_big = (const float *)p;
+        if (opt_int(ctx, "MMW_BIGPRIME_BF16", 1)) {         // (0: the float32 MFMA form)
+            MMW_TRY(get_bigprime_bf16_table(ctx, mixct::BIG_PRIME, &p));
+            a.abf_big = p;
+        }
     }
     constexpr size_t lds_bytes = mixct_lds_bytes(S, C);
     if (cs || query_only) {
@@ -586,6 +719,7 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
         std::fprintf(stderr, "rd_mixed_ct %dx%d NT=%d clocks:", S, C, NT);
         for (int i = 1; i < 7; ++i) std::fprintf(stderr, " %lld", h[i] - h[i - 1]);
         if (h[9]) std::fprintf(stderr, " | bigprime mfma %lld", h[9] - h[S1 == mixct::BIG_PRIME ? 1 : 3]);
+        if (h[8]) std::fprintf(stderr, " (s / d pre-pass %lld)", h[8] - h[S1 == mixct::BIG_PRIME ? 1 : 3]);
         std::fprintf(stderr, "\n");
         return check_launch("rd_mixed_ct");
     }
