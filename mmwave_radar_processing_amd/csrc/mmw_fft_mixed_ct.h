@@ -54,6 +54,7 @@ constexpr int threads_for(int S, int C) {
     if ((S == 90 && C == 80) || (S == 200 && C == 40)) return 512;
     if (S == 63 && C == 115) return 512;        // RegDFT<23> spills under the 128-VGPR cap of 1024 threads
     if (S == 512 && C == 32) return 512;        // RegFFT<32> + the carried next plane spill at 1024 threads (same speed)
+    if (S == 254 && C == 50) return 512;        // the bfloat16 form of the 127-point level needs ~150 VGPRs (two tile jobs per wave)
     return wgs < 3 ? 1024 : (wgs < 6 ? 512 : 256);
 }
 }  // namespace mixct
@@ -63,11 +64,11 @@ constexpr size_t mixct_lds_base(int S, int C) {      // plane, inter-level twidd
     return (((size_t)S * (C | 1) + S + C + (big ? mixct::BIG_PRIME : 0) + (S + C + 1) / 2) * sizeof(cplx<float>) + 16 + 64 + 15) & ~(size_t)15;
 }
 constexpr size_t MIXCT_ABF_BYTES = (size_t)2 * 2 * 4 * 3 * 64 * 16;      // the big-prime level's bfloat16 x 3 operand table
-// (254 x 50 -- 1024 threads, 128 registers each, the big prime on the range axis -- spills in the bfloat16 form: measured slower
-//  than the float32 MFMAs there, 1.13 against 1.02 us per 12-antenna frame; 63 x 127 and 127 x 32 have the room)
+// (254 x 50 with 1024 threads -- 128 registers each, the big prime on the range axis -- spills in the bfloat16 form: measured
+//  slower than the float32 MFMAs, 1.13 against 1.02 us per 12-antenna frame; it runs with 512 threads, two tile jobs per wave)
 constexpr bool mixct_abf_fits(int S, int C) {
     const bool big = mixct::best_n1(S) == mixct::BIG_PRIME || mixct::best_n1(C) == mixct::BIG_PRIME;
-    const bool room = mixct::threads_for(S, C) <= 512 || mixct::best_n1(S) != mixct::BIG_PRIME;
+    const bool room = mixct::threads_for(S, C) <= 512 || mixct::best_n1(S) != mixct::BIG_PRIME;     // (1024 threads: 128 registers)
     return big && room && mixct_lds_base(S, C) + MIXCT_ABF_BYTES <= 160 * 1024 - 256;
 }
 constexpr size_t mixct_lds_bytes(int S, int C) { return mixct_lds_base(S, C) + (mixct_abf_fits(S, C) ? MIXCT_ABF_BYTES : 0); }
@@ -147,103 +148,126 @@ template <int P, int NT, int N_INNER, int INNER_STRIDE, int N_OUTER, int OUTER_S
 __device__ __forceinline__ void dft_level_bigprime_ct(cplx<float> *lds, const cplx<float> *tw2, const float *cst, int tid,
                                                       long long *clk = nullptr, const void *abf = nullptr) {
     constexpr int H = (P - 1) / 2, N_GROUPS = N_INNER * N_OUTER, NCOL = 2 * N_GROUPS, NTILES = (NCOL + 31) / 32;
-    constexpr int JOBS = 2 * NTILES, NW = NT / 64;
+    constexpr int JOBS = 2 * NTILES, NW = NT / 64, JPW = (JOBS + NW - 1) / NW;      // jobs per wave: job = wave, wave + NW, ...
     static_assert(H + 1 == 64, "two 32-row output tiles");
-    static_assert(JOBS <= NW, "one output tile per wave");
+    static_assert(JPW <= 2, "at most two output tiles per wave (their accumulators wait in registers for the barrier)");
     float *lf = reinterpret_cast<float *>(lds);
-    const int lane = tid & 63, job = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kt = job / NTILES, nt = job - kt * NTILES, kk = lane >> 5;
-    const int n = nt * 32 + (lane & 31);
-    const bool valid = n < NCOL;
-    const int g = valid ? n >> 1 : 0, comp = n & 1, o = g / N_INNER, i = g - o * N_INNER;
-    const int boff = 2 * (i * INNER_STRIDE + o * OUTER_STRIDE) + comp;      // float index of element 0, this component
-    mixct_v16f dc = {0}, ds = {0};
-    if (abf) {
-        if (job < JOBS) {
-            const u32x4 *tc = reinterpret_cast<const u32x4 *>(abf) + (size_t)(kt * 4) * 3 * 64 + lane;          // cosines
-            const u32x4 *ts = reinterpret_cast<const u32x4 *>(abf) + (size_t)((2 + kt) * 4) * 3 * 64 + lane;    // sines
-            const float *pa = lf + boff + 16 * ESTRIDE * kk;             // x_j,     j = 16 t + 8 kk + i
-            const float *pb = lf + boff + 2 * ESTRIDE * (P - 8 * kk);    // x_{P-j}
-            const float *p0 = kk ? pb : pa;                              // (j = 0 has no partner: s_0 = x_0, d_0 = 0)
-            // SUM: s_j = x_j + x_{P-j}, else d_j = x_j - x_{P-j}
-            auto gather = [&](int t, auto SUM, float (&v)[8]) {
-                constexpr bool sum = decltype(SUM)::value;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kk = lane >> 5;
+    mixct_v16f dcs[JPW], dss[JPW];
+    // the columns of job q of this wave: n = (group, re | im), float index of the group's element 0 for this component
+    auto job_cols = [&](int job, int &kt, bool &valid, int &comp, int &o, int &boff) {
+        kt = job / NTILES;
+        const int nt = job - kt * NTILES, n = nt * 32 + (lane & 31);
+        valid = n < NCOL;
+        const int g = valid ? n >> 1 : 0;
+        comp = n & 1;
+        o = g / N_INNER;
+        const int i = g - o * N_INNER;
+        boff = 2 * (i * INNER_STRIDE + o * OUTER_STRIDE) + comp;
+    };
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float xa = pa[2 * ESTRIDE * (16 * t + i)];
-                    const float xb = i == 0 ? (t == 0 ? p0 : pb - 2 * ESTRIDE * 16 * t)[0] : pb[-2 * ESTRIDE * (16 * t + i)];
-                    const bool first = i == 0 && t == 0 && kk == 0;
-                    v[i] = sum ? (first ? xa : xa + xb) : (first ? 0.f : xa - xb);
-                }
-            };
-            auto piece = [](const u32x4 *tab, int idx) { return __builtin_bit_cast(bf16x8, tab[idx * 64]); };
-            // One matrix at a time (registers: the persistent kernels hold the next plane's samples meanwhile), TWO accumulators
-            // taking the MFMAs in turn: a wave issues in order, so a chain of MFMAs on one accumulator stalls it for the whole
-            // latency of each -- nothing else of the wave, not even the next step's operand arithmetic, gets issued meanwhile.
-            auto product = [&](const u32x4 *tab, auto SUM) {
-                mixct_v16f acc0 = {0}, acc1 = {0};
-                bf16x8 lead[4];                                         // the data's leading pieces, for phase 2
+    for (int q = 0; q < JPW; ++q) {
+        const int job = wave + q * NW;
+        int kt, comp, o, boff;
+        bool valid;
+        job_cols(job, kt, valid, comp, o, boff);
+        mixct_v16f dc = {0}, ds = {0};
+        if (abf) {
+            if (job < JOBS) {
+                const u32x4 *tc = reinterpret_cast<const u32x4 *>(abf) + (size_t)(kt * 4) * 3 * 64 + lane;          // cosines
+                const u32x4 *ts = reinterpret_cast<const u32x4 *>(abf) + (size_t)((2 + kt) * 4) * 3 * 64 + lane;    // sines
+                const float *pa = lf + boff + 16 * ESTRIDE * kk;             // x_j,     j = 16 t + 8 kk + i
+                const float *pb = lf + boff + 2 * ESTRIDE * (P - 8 * kk);    // x_{P-j}
+                const float *p0 = kk ? pb : pa;                              // (j = 0 has no partner: s_0 = x_0, d_0 = 0)
+                // SUM: s_j = x_j + x_{P-j}, else d_j = x_j - x_{P-j}
+                auto gather = [&](int t, auto SUM, float (&v)[8]) {
+                    constexpr bool sum = decltype(SUM)::value;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {                           // phase 1: every partial product below the leading one
-                    float v[8];
-                    gather(t, SUM, v);
-                    bf16x8 b2, b3;
-                    const bf16x8 a1 = piece(tab, t * 3), a2 = piece(tab, t * 3 + 1), a3 = piece(tab, t * 3 + 2);
-                    split_bf16x3(v, lead[t], b2, b3);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, lead[t], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, lead[t], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc0, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);                  // (keep the steps apart: unrolled freely, all 24 coefficient reads come first)
-                }
+                    for (int i = 0; i < 8; ++i) {
+                        const float xa = pa[2 * ESTRIDE * (16 * t + i)];
+                        const float xb = i == 0 ? (t == 0 ? p0 : pb - 2 * ESTRIDE * 16 * t)[0] : pb[-2 * ESTRIDE * (16 * t + i)];
+                        const bool first = i == 0 && t == 0 && kk == 0;
+                        v[i] = sum ? (first ? xa : xa + xb) : (first ? 0.f : xa - xb);
+                    }
+                };
+                auto piece = [](const u32x4 *tab, int idx) { return __builtin_bit_cast(bf16x8, tab[idx * 64]); };
+                // One matrix at a time (registers), TWO accumulators taking the MFMAs in turn: a wave issues in order, so a chain
+                // of MFMAs on one accumulator stalls it for the whole latency of each -- nothing else of the wave, not even the
+                // next step's operand arithmetic, gets issued meanwhile.
+                auto product = [&](const u32x4 *tab, auto SUM) {
+                    mixct_v16f acc0 = {0}, acc1 = {0};
+                    bf16x8 lead[4];                                         // the data's leading pieces, for phase 2
 #pragma unroll
-                for (int t = 0; t < 4; t += 2) {                        // phase 2: the leading pieces
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(piece(tab, t * 3), lead[t], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(piece(tab, t * 3 + 3), lead[t + 1], acc0, 0, 0, 0);
-                }
-                return acc0 + acc1;
-            };
-            dc = product(tc, std::true_type{});
-            ds = product(ts, std::false_type{});
-        }
-    } else if (job < JOBS) {
-        const int k = kt * 32 + (lane & 31);                // this lane's row of the A operand
-        int idx = kk ? k : 0;                               // (j k) mod P, j = 2 t + kk
-        const int step = 2 * k >= P ? 2 * k - P : 2 * k;
-        const float *pa = lf + boff + 2 * ESTRIDE * kk;             // x_j
-        const float *pb = lf + boff + 2 * ESTRIDE * (P - kk);       // x_{P-j}
+                    for (int t = 0; t < 4; ++t) {                           // phase 1: every partial product below the leading one
+                        float v[8];
+                        gather(t, SUM, v);
+                        bf16x8 b2, b3;
+                        const bf16x8 a1 = piece(tab, t * 3), a2 = piece(tab, t * 3 + 1), a3 = piece(tab, t * 3 + 2);
+                        split_bf16x3(v, lead[t], b2, b3);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, lead[t], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, lead[t], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc0, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);                  // (keep the steps apart: unrolled freely, all 24 coefficient reads come first)
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; t += 2) {                        // phase 2: the leading pieces
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(piece(tab, t * 3), lead[t], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(piece(tab, t * 3 + 3), lead[t + 1], acc0, 0, 0, 0);
+                    }
+                    return acc0 + acc1;
+                };
+                dc = product(tc, std::true_type{});
+                ds = product(ts, std::false_type{});
+            }
+        } else if (job < JOBS) {
+            const int k = kt * 32 + (lane & 31);                // this lane's row of the A operand
+            int idx = kk ? k : 0;                               // (j k) mod P, j = 2 t + kk
+            const int step = 2 * k >= P ? 2 * k - P : 2 * k;
+            const float *pa = lf + boff + 2 * ESTRIDE * kk;             // x_j
+            const float *pb = lf + boff + 2 * ESTRIDE * (P - kk);       // x_{P-j}
 #pragma unroll 8
-        for (int t = 0; t < 32; ++t) {
-            const float xa = pa[4 * ESTRIDE * t];
-            const float xb = (t == 0 && kk == 0) ? xa : pb[-4 * ESTRIDE * t];
-            const float sj = (t == 0 && kk == 0) ? xa : xa + xb, dj = xa - xb;
-            const float c = cst[idx], sn = cst[P + idx];
-            dc = __builtin_amdgcn_mfma_f32_32x32x2f32(c, sj, dc, 0, 0, 0);
-            ds = __builtin_amdgcn_mfma_f32_32x32x2f32(sn, dj, ds, 0, 0, 0);
-            idx += step;
-            if (idx >= P) idx -= P;
+            for (int t = 0; t < 32; ++t) {
+                const float xa = pa[4 * ESTRIDE * t];
+                const float xb = (t == 0 && kk == 0) ? xa : pb[-4 * ESTRIDE * t];
+                const float sj = (t == 0 && kk == 0) ? xa : xa + xb, dj = xa - xb;
+                const float c = cst[idx], sn = cst[P + idx];
+                dc = __builtin_amdgcn_mfma_f32_32x32x2f32(c, sj, dc, 0, 0, 0);
+                ds = __builtin_amdgcn_mfma_f32_32x32x2f32(sn, dj, ds, 0, 0, 0);
+                idx += step;
+                if (idx >= P) idx -= P;
+            }
         }
+        dcs[q] = dc;
+        dss[q] = ds;
     }
     __syncthreads();            // every wave has read the x it needs: the groups may be overwritten
     phase_mark(clk, 9, tid);
-    if (job < JOBS) {
-        const float sgn = comp ? -1.f : 1.f;
-        // C/D map of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const float pr = lane_xor1(ds[r]);              // Ds of the other component
-            float lo = dc[r] + sgn * pr, hi = dc[r] - sgn * pr;     // re: Dc.re + Ds.im | im: Dc.im - Ds.re, and mirrored
-            if constexpr (TW) {
-                const float lo_o = lane_xor1(lo), hi_o = lane_xor1(hi);
-                const cplx<float> wl = tw2[o * P + k], wh = tw2[o * P + (k ? P - k : 0)];
-                lo = lo * wl.x - sgn * lo_o * wl.y;          // re: a.x b.x - a.y b.y | im: a.y b.x + a.x b.y
-                hi = hi * wh.x - sgn * hi_o * wh.y;
-            }
-            if (valid) {
-                lf[boff + 2 * ESTRIDE * k] = lo;
-                if (k > 0) lf[boff + 2 * ESTRIDE * (P - k)] = hi;
+    for (int q = 0; q < JPW; ++q) {
+        const int job = wave + q * NW;
+        int kt, comp, o, boff;
+        bool valid;
+        job_cols(job, kt, valid, comp, o, boff);
+        if (job < JOBS) {
+            const float sgn = comp ? -1.f : 1.f;
+            // C/D map of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const float pr = lane_xor1(dss[q][r]);          // Ds of the other component
+                float lo = dcs[q][r] + sgn * pr, hi = dcs[q][r] - sgn * pr;     // re: Dc.re + Ds.im | im: Dc.im - Ds.re, and mirrored
+                if constexpr (TW) {
+                    const float lo_o = lane_xor1(lo), hi_o = lane_xor1(hi);
+                    const cplx<float> wl = tw2[o * P + k], wh = tw2[o * P + (k ? P - k : 0)];
+                    lo = lo * wl.x - sgn * lo_o * wl.y;          // re: a.x b.x - a.y b.y | im: a.y b.x + a.x b.y
+                    hi = hi * wh.x - sgn * hi_o * wh.y;
+                }
+                if (valid) {
+                    lf[boff + 2 * ESTRIDE * k] = lo;
+                    if (k > 0) lf[boff + 2 * ESTRIDE * (P - k)] = hi;
+                }
             }
         }
     }
