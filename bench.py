@@ -429,16 +429,21 @@ def main():
                "path": wl.path if wl is not None else args.detect_path,
                "workload": ("range-Doppler of all antennas (float32) + OS-CFAR((5,5),(3,2), rho 0.7, alpha 2: the reference's GUI / "
                             "analysis default) on the float64 |RD| of antenna 0 + ordered detections + 8-antenna azimuth / 4-antenna "
-                            "elevation argmax with the worst-case error bound, flagged evaluations refined from float64 cells "
-                            "(dense form: mmw_cells64.h)") if os_kind else
+                            "elevation argmax (float32, one lane per detection, worst-case error bound), flagged evaluations "
+                            "refined from float64 cells (dense form: mmw_cells64.h)") if os_kind else
                            ("range-Doppler of all antennas (float32) + CA-CFAR((4,4),(2,2),1e-5) on antenna 0 (float32 screening "
                             "with the worst-case error band, undecided cells in float64) + ordered detections + 8-antenna azimuth / "
                             "4-antenna elevation argmax, float64-exact (BASELINE configs[2])")}
         if fam:
             rec["kernels_ms_per_step"] = {k: ms / max(n, 1) * (2 if k == "argmax" else 1) for k, (ms, n) in fam.items() if n}
-            # consistency: stages run back to back on one stream (the exact-cell and refinement kernels side by side), so the
-            # sum of the per-stage event spans brackets the step time from above
+            # consistency: the stages of the float64 / OS pipeline run back to back on one stream (sum of spans ~ step time); the
+            # fused CA pipeline defers its tail (exact cells, insertion, refinement: spans `detect_exact`, `argmax_refine`) behind
+            # the NEXT step's range-Doppler launch, so there the spans overlap and their sum exceeds the step time
             rec["kernels_ms_sum_over_ms_per_step"] = sum(rec["kernels_ms_per_step"].values()) / (1e3 * dt / args.steps)
+            if not os_kind:
+                rec["schedule"] = ("RD -> screening on the context stream; exact cells + insertion and the float64 refinement on side "
+                                   "queues, joined in front of the next call's screening (MMW_DETECT_DEFER_TAIL=1, the next "
+                                   "range-Doppler launch leaves MMW_DETECT_TAIL_CUS=40 CUs free for them)")
             rd_ms, rd_n = fam.get("rd", (0.0, 0))
             if rd_n:
                 avg_s = rd_ms * 1e-3 / rd_n

@@ -246,7 +246,11 @@ int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_ma
  *   h_stats (may be NULL; passing it synchronises): [0] frames with undecided cells, [1] undecided cells, [2] frames
  *   returned with count -1, [3] / [4] azimuth / elevation detections re-evaluated in float64.
  *   MMW_ERR_UNSUPPORTED (nothing launched) when mmw_detect_points_supported(...) == 0: CA-CFAR only, S * C float32
- *   magnitudes must fit the LDS, at most 8 antennas per list. */
+ *   magnitudes must fit the LDS, at most 8 antennas per list.
+ *   The call's tail (exact cells, list insertion, float64 refinement) stays on side queues when the call returns: the
+ *   range-Doppler launch of a following mmw_detect_points runs beside it; every other entry point of the context
+ *   (mmw_sync, the copies, any other kernel) joins it first, so results are complete whenever they can be observed
+ *   through this API.  Context option MMW_DETECT_DEFER_TAIL=0: each call joins its own tail. */
 int mmw_detect_points_supported(int S, int C, int cfar_kind, int train_r, int train_d, int guard_r, int guard_d,
                                 int n_az, int n_el);
 int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1, float *d_mag32, int32_t *d_dets,
@@ -264,10 +268,10 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
  * mmw_plane_l1: d_l1[F][V] float32 = sum over each plane of hann(S) hann(C) (|re| + |im|): the scale of the rounding-
  *   error bound the exact variant uses (computed once per batch, shared by the azimuth and elevation calls).
  * mmw_angle_argmax_exact: same result contract as the reference's complex128 computation (:186-206).  The float32
- *   pass bounds how far its magnitudes can be from the float64 ones (from d_l1 and the gathered cells: 1/8 of the
- *   worst-case rounding bound of the kernel that produced the cube, ~10x above the largest error measured;
- *   MMW_ARGMAX_BOUND_DIV=1 selects the worst case itself -- a proof, at 4x the run time on noise-level detections, see
- *   DESIGN.md 4.6); a detection whose winner is not certainly the float64 one -- best and second-best closer than twice
+ *   pass bounds how far its magnitudes can be from the float64 ones (from d_l1 and the gathered cells: the WORST-CASE
+ *   rounding bound of the kernel that produced the cube -- a proof; the context option MMW_ARGMAX_BOUND_DIV=8 restores
+ *   round 3's empirical eighth of it); a detection whose winner is not certainly the float64 one --
+ *   best and second-best closer than twice
  *   that bound and, for lists of up to 8 antennas, some bin also failing the pairwise form of the test that treats the two
  *   bins' errors as the same cell errors seen through two steering vectors -- is re-evaluated in float64 from the raw cube
  *   d_cubes (its range-Doppler cells as direct float64 2-D DFT sums, then the float64 angle DFT + argmax).

@@ -26,6 +26,7 @@
 #pragma once
 #include "mmw_ctx.h"
 #include "mmw_misc.h"
+#include "mmw_bf16x3.h"
 
 namespace mmw {
 
@@ -195,6 +196,141 @@ __global__ __launch_bounds__(C64_NT) void k_cells64(Cells64Args a) {
         }
         if (running <= c0 + C64_CELLS) break;                           // (uniform) no further chunk
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// |RD| of ONE antenna in float64 for 256 x 128 planes, one launch (mmw_range_doppler_mag64: the plane the reference's detectors
+// threshold, range_doppler_detector.py:62-80).  The generic path is two launches around a complex128 plane in memory
+// (0.57 us per frame).  Here a 512-thread workgroup walks frames:
+//   A  Doppler FFT of the rows in passes of 64 rows -- the 8 lanes x 16 points form of k_cells64 above --, each pass's spectra
+//      leave the LDS TRANSPOSED into the workgroup's own 512 KB of scratch, T[k][s] (1 KB runs);
+//   B  range FFT down the columns, 32 columns at a time: 16 lanes x 16 points per column (16-point register FFT over s2, the
+//      W_256 twiddles, one swizzled exchange through the LDS, a second 16-point register FFT), |.| = hypot, fftshifted
+//      Doppler index, straight to the output (32 consecutive doubles per row and store).
+// The scratch is written and read by the same workgroup only and rewritten every frame: it lives in the L2 / Infinity Cache;
+// the reads bypass the CU's L1 (sc0), which may still hold the previous frame's lines.
+struct Rd64Args {
+    const float2 *cubes;        // first sample of frame 0's plane
+    long frame_stride;          // complex elements between the planes of consecutive frames
+    double *mag;                // [F][256][128]
+    cplx<double> *scratch;      // [grid][128][256]
+    int n_frames;
+    const double *ws, *wc;      // np.hanning(256), np.hanning(128)
+    const cplx<double> *twS, *twC;
+};
+constexpr int R64_S = 256, R64_C = 128, R64_COLS = 32, R64_CP = 257;
+inline size_t rd64_lds() { return (std::max((size_t)C64_ROWS * C64_PITCH, (size_t)R64_COLS * R64_CP) + R64_S + R64_C) * 16 + (R64_S + R64_C) * 8; }
+
+__global__ __launch_bounds__(C64_NT) void k_rd_mag64_256x128(Rd64Args a) {
+    constexpr int S = R64_S, C = R64_C, P = C64_PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    cplx<double> *Z = reinterpret_cast<cplx<double> *>(smem);
+    cplx<double> *twl = Z + (C64_ROWS * P > R64_COLS * R64_CP ? C64_ROWS * P : R64_COLS * R64_CP);       // W_256
+    cplx<double> *twc = twl + S;                                                                          // W_128
+    double *wsl = reinterpret_cast<double *>(twc + C), *wcl = wsl + S;
+    for (int i = tid; i < S; i += C64_NT) {
+        wsl[i] = a.ws[i];
+        twl[i] = a.twS[i];
+    }
+    for (int i = tid; i < C; i += C64_NT) {
+        wcl[i] = a.wc[i];
+        twc[i] = a.twC[i];
+    }
+    cplx<double> *T = a.scratch + (size_t)blockIdx.x * S * C;
+    const auto t_rs = __builtin_amdgcn_make_buffer_rsrc(T, 0, S * C * 16, 0x00020000);
+    __syncthreads();
+    for (long f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
+        const float2 *plane = a.cubes + f * a.frame_stride;
+        // ---- A: Doppler
+        {
+            const int n1 = tid & 7, rl = tid >> 3;
+            cplx<double> *slab = Z + rl * P;
+            float2 raw[16];
+            auto fetch = [&](int s0) {
+                const float2 *rowp = plane + (long)(s0 + rl) * C;
+#pragma unroll
+                for (int n2 = 0; n2 < 16; ++n2) raw[n2] = rowp[n1 + 8 * n2];
+            };
+            fetch(0);
+            for (int s0 = 0; s0 < S; s0 += C64_ROWS) {
+                const double wrow = wsl[s0 + rl];
+                cplx<double> x[16];
+#pragma unroll
+                for (int n2 = 0; n2 < 16; ++n2) {
+                    const double w = wcl[n1 + 8 * n2] * wrow;
+                    x[n2] = cplx<double>{(double)raw[n2].x * w, (double)raw[n2].y * w};
+                }
+                fetch(s0 + C64_ROWS < S ? s0 + C64_ROWS : s0);
+                RegFFT<16, double>::run(x);
+                static_for<16>([&](auto K) {
+                    constexpr int k2 = decltype(K)::value;
+                    const cplx<double> v = x[bitrev<16>(k2)];
+                    slab[k2 * 8 + ((n1 + k2) & 7)] = k2 == 0 ? v : cmul(v, twc[(n1 * k2) & (C - 1)]);
+                });
+                __builtin_amdgcn_wave_barrier();
+                cplx<double> ya[8], yb[8];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    ya[n] = slab[n1 * 8 + ((n + n1) & 7)];
+                    yb[n] = slab[(n1 + 8) * 8 + ((n + n1) & 7)];
+                }
+                RegFFT<8, double>::run(ya);
+                RegFFT<8, double>::run(yb);
+                __builtin_amdgcn_wave_barrier();
+                static_for<8>([&](auto K) {
+                    constexpr int k1 = decltype(K)::value;
+                    slab[n1 + 16 * k1] = ya[bitrev<8>(k1)];
+                    slab[n1 + 8 + 16 * k1] = yb[bitrev<8>(k1)];
+                });
+                __syncthreads();
+                // the pass's spectra, transposed: T[k][s0 .. s0 + 63]
+#pragma unroll 4
+                for (int i = tid; i < C * C64_ROWS; i += C64_NT) {
+                    const int k = i >> 6, r = i & 63;
+                    T[k * S + s0 + r] = Z[r * P + k];
+                }
+                __syncthreads();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's stores of T have left ...
+        __syncthreads();                                         // ... before any wave reads T
+        // ---- B: range, 32 columns at a time
+        {
+            const int m1 = tid & 15, cl = tid >> 4;             // lane of the column, column of the round
+            cplx<double> *slab = Z + cl * R64_CP;
+            double *out = a.mag + f * (long)S * C;
+            for (int k0 = 0; k0 < C; k0 += R64_COLS) {
+                const int k = k0 + cl;
+                cplx<double> x[16];
+#pragma unroll
+                for (int m2 = 0; m2 < 16; ++m2) {
+                    const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(t_rs, (unsigned)((k * S + m1 + 16 * m2) * 16), 0, 1));
+                    x[m2] = __builtin_bit_cast(cplx<double>, v);
+                }
+                RegFFT<16, double>::run(x);                     // over m2: Y1[q] in x[bitrev(q)]
+                static_for<16>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    const cplx<double> v = x[bitrev<16>(q)];
+                    slab[q * 16 + ((m1 + q) & 15)] = q == 0 ? v : cmul(v, twl[(m1 * q) & (S - 1)]);
+                });
+                __builtin_amdgcn_wave_barrier();
+                cplx<double> y[16];
+#pragma unroll
+                for (int n = 0; n < 16; ++n) y[n] = slab[m1 * 16 + ((n + m1) & 15)];
+                RegFFT<16, double>::run(y);                     // over m1: range bin r = m1 + 16 p in y[bitrev(p)]
+                int d = k + C / 2;
+                if (d >= C) d -= C;
+                static_for<16>([&](auto Pp) {
+                    constexpr int p = decltype(Pp)::value;
+                    const cplx<double> v = y[bitrev<16>(p)];
+                    out[(long)(m1 + 16 * p) * C + d] = hypot(v.x, v.y);
+                });
+                __builtin_amdgcn_wave_barrier();                // (the column's slab is reused by the same lanes in the next round)
+            }
+        }
+        __syncthreads();                                         // the LDS goes back to phase A
     }
 }
 

@@ -518,6 +518,31 @@ static int range_doppler_mag64_impl(mmw_ctx *ctx, const void *d_cubes, double *d
     MMW_REQUIRE(n_frames >= 0 && V > 0 && S > 0 && C > 0 && rx_idx >= 0 && rx_idx < V, "bad shape / rx_idx");
     if (n_frames == 0) return MMW_OK;
     ProfScope ps(ctx, "rd64");
+    if (S == R64_S && C == R64_C && n_frames >= 8 && opt_int(ctx, "MMW_RD64_FUSED", 1)) {
+        // one launch, the complex128 intermediate in per-workgroup scratch that never leaves the caches (mmw_cells64.h); a whole
+        // frame per workgroup: batches only (a single frame is spread over the chip by the two generic launches)
+        const int grid = std::min(n_frames, ctx->num_cu);
+        MMW_TRY(ensure_scratch(ctx, (size_t)grid * S * C * sizeof(cplx<double>)));
+        Rd64Args ra{};
+        ra.cubes = (const float2 *)d_cubes + (long)rx_idx * S * C;
+        ra.frame_stride = (long)V * S * C;
+        ra.mag = d_mag;
+        ra.scratch = (cplx<double> *)ctx->scratch;
+        ra.n_frames = n_frames;
+        const void *p;
+        MMW_TRY(get_table<double>(ctx, TAB_HANN, S, &p));
+        ra.ws = (const double *)p;
+        MMW_TRY(get_table<double>(ctx, TAB_HANN, C, &p));
+        ra.wc = (const double *)p;
+        MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, S, &p));
+        ra.twS = (const cplx<double> *)p;
+        MMW_TRY(get_table<double>(ctx, TAB_TWIDDLE, C, &p));
+        ra.twC = (const cplx<double> *)p;
+        const size_t lds = rd64_lds();
+        MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rd_mag64_256x128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_rd_mag64_256x128, dim3((unsigned)grid), dim3(C64_NT), lds, ctx->stream, ra);
+        return check_launch("rd_mag64_256x128");
+    }
     RdMixedPlan mp;
     // LDS-resident single-pass kernel for every plane that fits in float64 except small power-of-two ones, where the
     // two-kernel register-FFT path is as fast (64 x 64, 512 x 8: equal; 128 x 64, 256 x 32: single pass +18 %)
