@@ -71,7 +71,10 @@ constexpr bool mixct_abf_fits(int S, int C) {
     const bool room = mixct::threads_for(S, C) <= 512 || mixct::best_n1(S) != mixct::BIG_PRIME;     // (1024 threads: 128 registers)
     return big && room && mixct_lds_base(S, C) + MIXCT_ABF_BYTES <= 160 * 1024 - 256;
 }
-constexpr size_t mixct_lds_bytes(int S, int C) { return mixct_lds_base(S, C) + (mixct_abf_fits(S, C) ? MIXCT_ABF_BYTES : 0); }
+constexpr size_t mixct_lds_bytes(int S, int C, bool bf = false) { return mixct_lds_base(S, C) + (bf && mixct_abf_fits(S, C) ? MIXCT_ABF_BYTES : 0); }
+// which launches take the bfloat16 form: 63 x 127 and 254 x 50 (one workgroup per CU in either form) always; 127 x 32 only as the
+// producer of the device-synchronised chain (+12 %) -- stand-alone, four small float32-form workgroups per CU are faster
+constexpr bool mixct_use_bf(int S, int C, bool sync) { return mixct_abf_fits(S, C) && (sync || !(S == 127 && C == 32)); }
 
 struct RdMixedCtArgs {
     const void *in;             // complex64 planes
@@ -291,7 +294,9 @@ __device__ __forceinline__ void dft_level_any_ct(cplx<float> *lds, const cplx<fl
 // kernel (k_rd_fused_256x128_persist<SYNC>): items (frame, live antenna) from a ticket counter, the output plane goes to
 // the ring slot of its frame with sc1 (write-through) stores once the slot's previous frame has been consumed, every
 // storing wave drains its stores, and one lane bumps the slot's counter after the workgroup barrier.
-template <int S, int C, int NT, int MODE>
+// BF: the big-prime level on bfloat16 x 3 MFMAs (a separate instantiation: the form needs ~150 registers and 48 KB of LDS,
+// which the float32 form's callers -- e.g. four small 127 x 32 workgroups per CU -- must not pay for)
+template <int S, int C, int NT, int MODE, bool BF = false>
 __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     constexpr bool PERSIST = MODE >= 1, SYNC = MODE >= 2, RAWSYNC = MODE == 3;     // MODE 3: SYNC on the raw [F][nrx][S][ntx C] cube
     constexpr int S1 = mixct::best_n1(S), S2 = S / S1, C1 = mixct::best_n1(C), C2 = C / C1;
@@ -402,11 +407,9 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
     // have to wait (in-order vmcnt) for the next plane's prefetch
     [[maybe_unused]] u32x4 *abf_l = reinterpret_cast<u32x4 *>(smem + mixct_lds_base(S, C));
     const void *abf = nullptr;
-    if constexpr (mixct_abf_fits(S, C)) {
-        if (a.abf_big) {
-            for (int i = tid; i < (int)(MIXCT_ABF_BYTES / 16); i += NT) abf_l[i] = reinterpret_cast<const u32x4 *>(a.abf_big)[i];
-            abf = abf_l;
-        }
+    if constexpr (BF && mixct_abf_fits(S, C)) {
+        for (int i = tid; i < (int)(MIXCT_ABF_BYTES / 16); i += NT) abf_l[i] = reinterpret_cast<const u32x4 *>(a.abf_big)[i];
+        abf = abf_l;
     }
     for (int i = tid; i < S; i += NT) win_s[i] = a.win_s[i];
     for (int i = tid; i < C; i += NT) win_c[i] = a.win_c[i];
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(NT) void k_rd_mixed_ct(RdMixedCtArgs a) {
             stash(t);
         // (a big-prime FIRST level keeps two MFMA accumulators, operand pieces and coefficient pieces in registers: the next
         //  plane's loads are issued behind it -- the three remaining levels and the store still cover their flight)
-        constexpr bool FETCH_LATE = S1 == mixct::BIG_PRIME && mixct_abf_fits(S, C);
+        constexpr bool FETCH_LATE = BF && S1 == mixct::BIG_PRIME && mixct_abf_fits(S, C);
         if constexpr (PERSIST && !SYNC && !FETCH_LATE) {
             if (item + gridDim.x < n_items) fetch(in_base + skip_block_plane(item + gridDim.x, a.raw) * a.in_plane_stride);
         }
@@ -685,15 +688,19 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
             a.abf_big = p;
         }
     }
-    constexpr size_t lds_bytes = mixct_lds_bytes(S, C);
+    const bool sync_call = cs || query_only;
+    const bool raw_call = (cs && cs->ntx > 1) || (query_only && rv.ntx > 1);        // the raw-cube producer: the float32 form (measured:
+    const bool bf = a.abf_big != nullptr && mixct_use_bf(S, C, sync_call) && !raw_call;     // its registers leave the other no room)
+    const size_t lds_bytes = mixct_lds_bytes(S, C, bf);
     if (cs || query_only) {
         const bool raw_sync = (cs && cs->ntx > 1) || (query_only && rv.ntx > 1);
-        auto kern = raw_sync ? k_rd_mixed_ct<S, C, NT, 3> : k_rd_mixed_ct<S, C, NT, 2>;
+        auto kern = raw_sync ? (bf ? k_rd_mixed_ct<S, C, NT, 3, mixct_abf_fits(S, C)> : k_rd_mixed_ct<S, C, NT, 3>)
+                             : (bf ? k_rd_mixed_ct<S, C, NT, 2, mixct_abf_fits(S, C)> : k_rd_mixed_ct<S, C, NT, 2>);
         // (the attribute is per device: set it on every call, a process may drive several devices)
         if (lds_bytes > 64 * 1024)
             MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        static int per_cu_tab[2] = {0, 0};
-        int &per_cu = per_cu_tab[raw_sync ? 1 : 0];
+        static int per_cu_tab[4] = {0, 0, 0, 0};
+        int &per_cu = per_cu_tab[(raw_sync ? 1 : 0) + (bf ? 2 : 0)];
         if (!per_cu) {
             int nb = 0;
             MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), NT, lds_bytes));
@@ -708,19 +715,24 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
         return check_launch("rd_mixed_ct_sync");
     }
     // persistent + next-plane prefetch where nothing else would overlap the load phase
-    static int persist_dflt = -1;       // persistent where only ONE one-plane workgroup would be resident per CU (LDS or registers)
+    static int persist_tab[2] = {-1, -1};       // persistent where only ONE one-plane workgroup would be resident per CU (LDS or registers)
+    int &persist_dflt = persist_tab[bf ? 1 : 0];
     if (persist_dflt < 0) {
         int nb = 0;
-        MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k_rd_mixed_ct<S, C, NT, 0>), NT, lds_bytes));
+        const void *k0 = bf ? reinterpret_cast<const void *>(k_rd_mixed_ct<S, C, NT, 0, mixct_abf_fits(S, C)>)
+                            : reinterpret_cast<const void *>(k_rd_mixed_ct<S, C, NT, 0>);
+        MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k0, NT, lds_bytes));
         persist_dflt = nb <= 1 ? 1 : 0;
     }
     const bool persist = rv.ntx <= 1 && persist_dflt != 0;
-    auto kern = persist ? k_rd_mixed_ct<S, C, NT, 1> : k_rd_mixed_ct<S, C, NT, 0>;
+    auto kern = persist ? (bf ? k_rd_mixed_ct<S, C, NT, 1, mixct_abf_fits(S, C)> : k_rd_mixed_ct<S, C, NT, 1>)
+                        : (bf ? k_rd_mixed_ct<S, C, NT, 0, mixct_abf_fits(S, C)> : k_rd_mixed_ct<S, C, NT, 0>);
     if (lds_bytes > 64 * 1024)
         MMW_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = rv.ntx > 1 ? (unsigned)raw_grid(planes, rv) : (unsigned)skip_planes(planes, rv);
     if (persist) {
-        static int per_cu = 0;          // residency by LDS AND registers (per shape: this function is a template)
+        static int per_cu_tab2[2] = {0, 0};     // residency by LDS AND registers (per shape: this function is a template; per form)
+        int &per_cu = per_cu_tab2[bf ? 1 : 0];
         if (!per_cu) {
             int nb = 0;
             MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), NT, lds_bytes));

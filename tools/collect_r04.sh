@@ -18,8 +18,7 @@ timeout -k 10 300 python tools/os_pipeline.py > gpurun_out/r04/os_pipeline.json 
 ( timeout -k 10 300 python tools/detect_cus.py --mag32 --splits 32,64,96 && timeout -k 10 100 python tools/detect_cus.py --clocks --splits 32 2>&1 | grep -A1 clocks ) > gpurun_out/r04/detect_schedules.log 2>&1; echo "schedules rc=$?"
 python tools/bench_summary.py gpurun_out/r04/bench_line.json
 else
-MMW_SWEEP_FRAMES=10000 timeout -k 10 900 python -m pytest tests/test_gpu_sweep.py -x -q -s -k test_detection_indices > gpurun_out/r04/sweep_10k.log 2>&1; echo "sweep rc=$?"; tail -3 gpurun_out/r04/sweep_10k.log
-MMW_SWEEP_FRAMES=640 timeout -k 10 600 python -m pytest tests/test_gpu_sweep.py -x -q -s -k "standalone_exact_argmax" > gpurun_out/r04/argmax_os_sweep.log 2>&1; echo "argmax sweep rc=$?"; tail -3 gpurun_out/r04/argmax_os_sweep.log
+# (the exactness sweeps: tools/collect_r04_sweeps.sh)
 timeout -k 10 400 python tools/kbench.py --frames 1250 --reps 20 > gpurun_out/r04/kbench.json 2> gpurun_out/r04/kbench.err; echo "kbench rc=$?"
 timeout -k 10 500 python tools/shapes_bench.py > gpurun_out/r04/shapes.json 2> gpurun_out/r04/shapes.err; echo "shapes rc=$?"
 timeout -k 10 300 python tools/api_latency.py > gpurun_out/r04/api_latency.json 2> gpurun_out/r04/api_latency.err; echo "api rc=$?"
