@@ -404,14 +404,14 @@ def main():
         return dt, ev
 
     elapsed, ev_ms = timed(step, args.profile_every if args.profile_every > 0 else (1 if n_launch == 1 else 7))
-    prof = {k: ctx.profile_get(k) for k in ("rd", "angle", "detect", "detect_tail", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
+    prof = {k: ctx.profile_get(k) for k in ("rd", "angle", "detect", "detect_tail", "detect_exact", "argmax_tail", "argmax_refine", "rd64", "cfar", "compact",
                                             "plane_l1", "argmax")} if not args.no_profile else {}
     # BASELINE configs[2] beside the headline: the detection pipeline on the same resident frames, same K / W
     det_extra = None
     if not detect and not args.no_detect_record:
         work = DetectWorkload(ctx, F, args.detect_path)
         det_elapsed, det_ev = timed(lambda: work.step(d_in), 1)
-        det_prof = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_tail", "detect_exact", "argmax_refine", "rd64", "cfar", "compact",
+        det_prof = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_tail", "detect_exact", "argmax_tail", "argmax_refine", "rd64", "cfar", "compact",
                                                     "plane_l1", "argmax")} if not args.no_profile else {}
         det_extra = (det_elapsed, det_ev, det_prof)
         work_os = DetectWorkload(ctx, F, cfar=OS_CFAR)

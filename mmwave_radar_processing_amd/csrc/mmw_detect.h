@@ -46,7 +46,7 @@ constexpr int DET_MAX_ANT = 8;           // antennas per list inside the fused k
 constexpr int DET_LIST2 = 16;            // first lane of the second list's cells
 constexpr int DET_SPEC = 32;             // undecided cells a frame may carry speculatively (more: the frame is handed back)
 enum { DST_UNDECIDED = 1, DST_OVERFLOW = 2, DST_DEGENERATE = 4 };
-enum { DCTL_FLAG_FRAMES = 0, DCTL_CELLS = 1, DCTL_FALLBACK = 2, DCTL_ARGMAX = 16, DCTL_EL = 32, DCTL_WORDS = 64 };   // ARGMAX: flagged
+enum { DCTL_FLAG_FRAMES = 0, DCTL_CELLS = 1, DCTL_FALLBACK = 2, DCTL_RECS = 3, DCTL_ARGMAX = 16, DCTL_EL = 32, DCTL_WORDS = 64 };   // ARGMAX: flagged
                                                     // evaluations of both lists (the refinement list's length), EL: those of the second
 
 struct DetAnt {            // antenna list of one angle estimate (n == 0: not wanted)
@@ -79,6 +79,14 @@ struct DetectArgs {
     unsigned *sy_ctl, *sy_frame_cnt;
     unsigned long long sy_timeout;      // s_memrealtime ticks a wait may last
     int sy_naps, n_frames;
+    // late argmax (rec_cells != nullptr): instead of estimating the angles itself the frame's workgroup appends one RECORD per
+    // detection (certain and speculative) to a flat list -- rec_slot[rec] = f * cap + slot, rec_cells[rec][n_az + n_el] = its
+    // range-Doppler cells, azimuth list first -- and copies the frame's plane norms into l1_copy; k_angle_argmax_recs works
+    // from those (ctl[DCTL_RECS] = records so far)
+    float2 *rec_cells;
+    int32_t *rec_slot;
+    float *l1_copy;
+    int rec_cap;
 };
 
 __device__ __forceinline__ void det_mark(const DetectArgs &a, int i) {
@@ -391,11 +399,132 @@ __global__ __launch_bounds__(256) void k_angle_argmax_lanes(const float2 *rd, co
 //     test does not clear: p_k >= (m1 - 2B)^2 less a rounding allowance); a wave loops as long as its busiest lane.
 // Flagged evaluations join rf.list / rf.flagpos with one atomic per wave.  Every index it reports unflagged is the float64
 // one by the same proof as before; what it flags is re-evaluated in float64 by the caller.
+// the evaluation of one lane's detection: cells x (zeros past the list), error scales e (be = their sum), sum_abs = sum |re| + |im|
+template <int N, bool SHIFT>
+__device__ __forceinline__ void argmax_lane_eval(const cplx<float> (&x)[N], const float (&e)[N], float be, float sum_abs, const float2 *tw,
+                                                 const ArgmaxRefine &rf, bool active, long slot, int32_t *__restrict__ out_idx, int lane) {
+    constexpr int A = 64, G = A / N;
+    // ---- all 64 bins: p[k] = |S_k|^2
+    unsigned key[A];
+    static_for<G>([&](auto B) {
+        constexpr int b = decltype(B)::value;
+        cplx<float> y[N];
+        static_for<N>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            y[i] = mul_w<64, i * b, float>(x[i]);
+        });
+        RegFFT<N, float>::run(y);
+        static_for<N>([&](auto Aa) {
+            constexpr int a = decltype(Aa)::value;
+            const cplx<float> sk = y[bitrev<N>(a)];
+            key[b + G * a] = mag_key(fmaf(sk.x, sk.x, sk.y * sk.y));
+        });
+    });
+    // ---- first maximum in output order (np.argmax), largest other value
+    unsigned k1key = 0u, k2key = 0u;
+    int wi = 0;
+    static_for<A>([&](auto KK) {
+        constexpr int kk = decltype(KK)::value;
+        constexpr int k = SHIFT ? (kk + A / 2) % A : kk;
+        const unsigned v = key[k];
+        if constexpr (kk == 0) {
+            k1key = v;
+        } else {
+            const bool up = v > k1key;
+            k2key = up ? k1key : max(k2key, v);
+            k1key = up ? v : k1key;
+            wi = up ? kk : wi;
+        }
+    });
+    const float m1p = __fsqrt_rn(key_mag(k1key)), m2p = __fsqrt_rn(key_mag(k2key));
+    const float c_ang = rf.k_ang * sum_abs, two_b = 2.f * (be + c_ang);
+    bool bad = !(m1p - m2p > two_b);                            // (also for a NaN winner)
+    if (bad && m1p == m1p) {
+        // candidate bins: everything the generic test does not clear against the winner
+        const float thr = m1p - two_b, t2 = thr > 0.f ? thr * thr * (1.f - 2e-6f) : 0.f;
+        unsigned long long cand = 0ull;
+        static_for<A>([&](auto KK) {
+            constexpr int kk = decltype(KK)::value;
+            constexpr int k = SHIFT ? (kk + A / 2) % A : kk;
+            if (!(key_mag(key[k]) < t2)) cand |= 1ull << k;
+        });
+        const int k1 = SHIFT ? (wi + A - A / 2) % A : wi;
+        cand &= ~(1ull << k1);
+        // the winner by direct sums (the arithmetic of detect_argmax_list), conj(u_1) W^(i k_1)
+        float2 t1[N];
+        float re1 = 0.f, im1 = 0.f;
+        {
+            int t = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float2 w = tw[t];
+                t1[i] = w;
+                re1 += x[i].x * w.x - x[i].y * w.y;
+                im1 += x[i].x * w.y + x[i].y * w.x;
+                t = (t + k1) & (A - 1);
+            }
+        }
+        const float m1 = __fsqrt_rn(fmaf(re1, re1, im1 * im1));
+        const float inv1 = 1.f / m1, u1x = re1 * inv1, u1y = im1 * inv1;
+#pragma unroll
+        for (int i = 0; i < N; ++i) t1[i] = make_float2(u1x * t1[i].x + u1y * t1[i].y, u1x * t1[i].y - u1y * t1[i].x);
+        bad = !(m1 > 0.f);                                      // (a zero or non-finite winner stays flagged)
+        while (__ballot(cand != 0ull) != 0ull) {
+            if (cand != 0ull) {
+                const int k = __ffsll((long long)cand) - 1;
+                cand &= cand - 1ull;
+                float2 w[N];
+                float re = 0.f, im = 0.f;
+                int t = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    w[i] = tw[t];
+                    t = (t + k) & (A - 1);
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    re += x[i].x * w[i].x - x[i].y * w[i].y;
+                    im += x[i].x * w[i].y + x[i].y * w[i].x;
+                }
+                const float m = __fsqrt_rn(fmaf(re, re, im * im)), margin = m1 - m;
+                bool ok = margin > two_b;
+                if (!ok && m > 0.f) {
+                    const float inv = 1.f / m, ux = re * inv, uy = im * inv;
+                    float lin = 0.f;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const float dx = t1[i].x - (ux * w[i].x + uy * w[i].y), dy = t1[i].y - (ux * w[i].y - uy * w[i].x);
+                        lin += e[i] * __fsqrt_rn(fmaf(dx, dx, dy * dy));
+                    }
+                    ok = margin > 1.001f * (lin + be * be / (2.f * fminf(m1, m))) + 2.f * c_ang;
+                }
+                bad |= !ok;
+            }
+        }
+    }
+    const bool flag = active && bad;
+    if (active) out_idx[slot] = wi;
+    const unsigned long long fm = __ballot(flag);
+    if (fm != 0ull) {
+        int base = 0;
+        if (lane == 0) {
+            base = atomicAdd(rf.n_flag, __popcll(fm));
+            if (rf.n_tagged) atomicAdd(rf.n_tagged, __popcll(fm));
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (flag) {
+            const int pos = base + __popcll(fm & ((1ull << lane) - 1ull));
+            if (pos < rf.list_cap) rf.list[pos] = (int)slot | rf.tag;
+            if (rf.flagpos && pos < rf.dense_cap) rf.flagpos[slot] = pos + 1;
+        }
+    }
+}
+
 template <int N, bool SHIFT>
 __global__ __launch_bounds__(256) void k_angle_argmax_dets(const float2 *__restrict__ rd, const int32_t *__restrict__ dets,
                                                             const int32_t *__restrict__ counts, int32_t *__restrict__ out_idx, int V, int S,
                                                             int C, int cap, AntList ants, const float2 *__restrict__ twA, ArgmaxRefine rf) {
-    constexpr int A = 64, G = A / N;
+    constexpr int A = 64;
     static_assert(N == 4 || N == 8, "lists of up to 4 / up to 8 antennas");
     __shared__ float2 tw[A];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -427,117 +556,45 @@ __global__ __launch_bounds__(256) void k_angle_argmax_dets(const float2 *__restr
             x[i] = i < n ? cplx<float>{v.x, v.y} : cplx<float>{0.f, 0.f};
             sum_abs += fabsf(x[i].x) + fabsf(x[i].y);
         }
-        // ---- all 64 bins: p[k] = |S_k|^2
-        unsigned key[A];
-        static_for<G>([&](auto B) {
-            constexpr int b = decltype(B)::value;
-            cplx<float> y[N];
-            static_for<N>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                y[i] = mul_w<64, i * b, float>(x[i]);
-            });
-            RegFFT<N, float>::run(y);
-            static_for<N>([&](auto Aa) {
-                constexpr int a = decltype(Aa)::value;
-                const cplx<float> sk = y[bitrev<N>(a)];
-                key[b + G * a] = mag_key(fmaf(sk.x, sk.x, sk.y * sk.y));
-            });
-        });
-        // ---- first maximum in output order (np.argmax), largest other value
-        unsigned k1key = 0u, k2key = 0u;
-        int wi = 0;
-        static_for<A>([&](auto KK) {
-            constexpr int kk = decltype(KK)::value;
-            constexpr int k = SHIFT ? (kk + A / 2) % A : kk;
-            const unsigned v = key[k];
-            if constexpr (kk == 0) {
-                k1key = v;
-            } else {
-                const bool up = v > k1key;
-                k2key = up ? k1key : max(k2key, v);
-                k1key = up ? v : k1key;
-                wi = up ? kk : wi;
-            }
-        });
-        const float m1p = __fsqrt_rn(key_mag(k1key)), m2p = __fsqrt_rn(key_mag(k2key));
-        const float c_ang = rf.k_ang * sum_abs, two_b = 2.f * (be + c_ang);
-        bool bad = !(m1p - m2p > two_b);                            // (also for a NaN winner)
-        if (bad && m1p == m1p) {
-            // candidate bins: everything the generic test does not clear against the winner
-            const float thr = m1p - two_b, t2 = thr > 0.f ? thr * thr * (1.f - 2e-6f) : 0.f;
-            unsigned long long cand = 0ull;
-            static_for<A>([&](auto KK) {
-                constexpr int kk = decltype(KK)::value;
-                constexpr int k = SHIFT ? (kk + A / 2) % A : kk;
-                if (!(key_mag(key[k]) < t2)) cand |= 1ull << k;
-            });
-            const int k1 = SHIFT ? (wi + A - A / 2) % A : wi;
-            cand &= ~(1ull << k1);
-            // the winner by direct sums (the arithmetic of detect_argmax_list), conj(u_1) W^(i k_1)
-            float2 t1[N];
-            float re1 = 0.f, im1 = 0.f;
-            {
-                int t = 0;
+        argmax_lane_eval<N, SHIFT>(x, e, be, sum_abs, tw, rf, active, slot, out_idx, lane);
+    }
+}
+
+// The same evaluation over a flat list of RECORDS (the late argmax of mmw_detect_points): the screening workgroup of a frame
+// copied the cells of its detections -- rec_cells[rec][NV], list 1 at [off, off + n) -- and the frame's plane norms (l1c) into
+// scratch of the context, so this launch reads nothing the caller's next range-Doppler call overwrites; rec_slot[rec] = f * cap
+// + slot.  Every lane of every wave has work (a frame's ~76 CA-CFAR detections fill 1.2 waves of the per-frame form).
+template <int N, bool SHIFT>
+__global__ __launch_bounds__(256) void k_angle_argmax_recs(const float2 *__restrict__ rec_cells, const int32_t *__restrict__ rec_slot,
+                                                            const int *__restrict__ n_recs, int rec_cap, int NV, int off,
+                                                            const float *__restrict__ l1c, int32_t *__restrict__ out_idx, int V, int cap,
+                                                            AntList ants, const float2 *__restrict__ twA, ArgmaxRefine rf) {
+    constexpr int A = 64;
+    __shared__ float2 tw[A];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < A) tw[tid] = twA[tid];
+    __syncthreads();
+    int total = *n_recs;
+    if (total > rec_cap) total = rec_cap;
+    const int n = ants.n;
+    for (int r0 = (blockIdx.x * 4 + wave) * 64; r0 < total; r0 += gridDim.x * 256) {
+        const int rec = r0 + lane;
+        const bool active = rec < total;
+        const long q = active ? rec : r0;
+        const long slot = rec_slot[q];
+        const long f = slot / cap;
+        cplx<float> x[N];
+        float e[N], be = 0.f, sum_abs = 0.f;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const float2 w = tw[t];
-                    t1[i] = w;
-                    re1 += x[i].x * w.x - x[i].y * w.y;
-                    im1 += x[i].x * w.y + x[i].y * w.x;
-                    t = (t + k1) & (A - 1);
-                }
-            }
-            const float m1 = __fsqrt_rn(fmaf(re1, re1, im1 * im1));
-            const float inv1 = 1.f / m1, u1x = re1 * inv1, u1y = im1 * inv1;
-#pragma unroll
-            for (int i = 0; i < N; ++i) t1[i] = make_float2(u1x * t1[i].x + u1y * t1[i].y, u1x * t1[i].y - u1y * t1[i].x);
-            bad = !(m1 > 0.f);                                      // (a zero or non-finite winner stays flagged)
-            while (__ballot(cand != 0ull) != 0ull) {
-                if (cand != 0ull) {
-                    const int k = __ffsll((long long)cand) - 1;
-                    cand &= cand - 1ull;
-                    float2 w[N];
-                    float re = 0.f, im = 0.f;
-                    int t = 0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        w[i] = tw[t];
-                        t = (t + k) & (A - 1);
-                    }
-#pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        re += x[i].x * w[i].x - x[i].y * w[i].y;
-                        im += x[i].x * w[i].y + x[i].y * w[i].x;
-                    }
-                    const float m = __fsqrt_rn(fmaf(re, re, im * im)), margin = m1 - m;
-                    bool ok = margin > two_b;
-                    if (!ok && m > 0.f) {
-                        const float inv = 1.f / m, ux = re * inv, uy = im * inv;
-                        float lin = 0.f;
-#pragma unroll
-                        for (int i = 0; i < N; ++i) {
-                            const float dx = t1[i].x - (ux * w[i].x + uy * w[i].y), dy = t1[i].y - (ux * w[i].y - uy * w[i].x);
-                            lin += e[i] * __fsqrt_rn(fmaf(dx, dx, dy * dy));
-                        }
-                        ok = margin > 1.001f * (lin + be * be / (2.f * fminf(m1, m))) + 2.f * c_ang;
-                    }
-                    bad |= !ok;
-                }
-            }
+        for (int i = 0; i < N; ++i) {
+            const float2 v = rec_cells[q * NV + off + (i < n ? i : 0)];
+            const float l = l1c[f * V + ants.idx[i < n ? i : 0]];
+            x[i] = i < n ? cplx<float>{v.x, v.y} : cplx<float>{0.f, 0.f};
+            e[i] = i < n ? rf.k_fft * l : 0.f;
+            be += e[i];
+            sum_abs += fabsf(x[i].x) + fabsf(x[i].y);
         }
-        const bool flag = active && bad;
-        if (active) out_idx[slot] = wi;
-        const unsigned long long fm = __ballot(flag);
-        if (fm != 0ull) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(rf.n_flag, __popcll(fm));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (flag) {
-                const int pos = base + __popcll(fm & ((1ull << lane) - 1ull));
-                if (pos < rf.list_cap) rf.list[pos] = (int)slot;
-                if (rf.flagpos && pos < rf.dense_cap) rf.flagpos[slot] = pos + 1;
-            }
-        }
+        argmax_lane_eval<N, SHIFT>(x, e, be, sum_abs, tw, rf, active, slot, out_idx, lane);
     }
 }
 
@@ -613,6 +670,29 @@ __device__ __forceinline__ bool detect_finish(const DetectArgs &a, long f, const
         }
         return v;
     };
+    if (a.rec_cells) {
+        // late argmax: the cells of every evaluation into the context's record list (one cold strided read per cell, all of a
+        // frame's in flight together: no arithmetic follows them here)
+        const int NV = n_az + n_el;
+        if (tid == 0) ws[41] = atomicAdd(a.ctl + DCTL_RECS, n_det);
+        for (int i = tid; i < a.V; i += DET_NT) a.l1_copy[f * a.V + i] = SYNC ? __hip_atomic_load(a.l1 + f * a.V + i, MMW_RLX_AGENT) : a.l1[f * a.V + i];
+        __syncthreads();
+        const int rec0 = ws[41];
+        for (int j = tid; j < n_det * NV; j += DET_NT) {
+            const int det = j / NV, i = j - det * NV, rec = rec0 + det;
+            if (rec >= a.rec_cap) continue;                 // (cannot happen: rec_cap = frames x cap)
+            const long slot = f * a.cap + slot_of(det);
+            const long cell = (long)a.dets[slot * 2] * C + a.dets[slot * 2 + 1];
+            const long av = tab[i < n_az ? i : DET_LIST2 + i - n_az];
+            float2 v;
+            if constexpr (SYNC)
+                v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(frame_rs, (unsigned)((av * a.S * C + cell) * 8), 0, 16));
+            else v = a.rd[(f * a.V + av) * (long)a.S * C + cell];
+            a.rec_cells[(long)rec * NV + i] = v;
+            if (i == 0) a.rec_slot[rec] = (int32_t)slot;
+        }
+        return true;
+    }
     // The cells of the wave's next PD detections travel while it works on this one (each fetch is a cold, strided read --
     // 2-4 k clocks from the memory side under load, against ~1 k clocks of arithmetic per detection: with one detection of
     // look-ahead the phase was latency bound, 33 k clocks for ~5 detections per wave).

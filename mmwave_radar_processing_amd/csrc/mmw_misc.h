@@ -339,6 +339,8 @@ struct ArgmaxRefine {
     float k_fft, k_ang;     // error-bound constants (see below)
     int *flagpos;           // optional [F][cap]: 1 + list position of a flagged detection (the dense refinement finds a frame's
     int dense_cap;          // flagged detections through it: mmw_cells64.h); positions from dense_cap on are not recorded
+    int tag;                // ORed into the list entries (REFINE_SECOND: the second list of a call that refines two at once)
+    int *n_tagged;          // optional: counts the flagged evaluations of a tagged list
 };
 
 // One wave per detection: gather rd[f][ant[i]][r][v], lane k evaluates angle bins k, k+64, ... of the

@@ -1967,6 +1967,20 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     const size_t b_sync = overlap ? up((CTL_CNT + (size_t)n_frames) * sizeof(unsigned)) : 0;
     size_t total = b_ctl + b_ff + b_cells + b_bits + b_sync;
     if (n_az || n_el) total += b_list2 + b_part;
+    // Late argmax (64 angle bins -- the reference's az_el_fft_size --, MMW_DETECT_LATE_ARGMAX=0: in the screening kernel): the
+    // screening workgroup stops at the ordered detection list and copies each detection's range-Doppler cells into a flat
+    // record list of the context; both angle estimates are launches of the lane-per-detection routine over those records
+    // (k_angle_argmax_recs: the same float32 test with the same worst-case bound) on the side queue, in front of the float64
+    // refinement -- part of the tail, so with the tail deferred they run beside the NEXT call's range-Doppler kernel, and they
+    // read nothing that call overwrites.  The in-kernel form (one wave per detection, ~1.2 detections' worth of lanes busy)
+    // cost the screening launch a third of its time: 0.27 -> 0.18 ms per 1250 frames.
+    const int NV = n_az + n_el;
+    const size_t b_rec = up((size_t)list_cap * NV * sizeof(float2)), b_rslot = up((size_t)list_cap * sizeof(int32_t)),
+                 b_l1c = up((size_t)n_frames * V * sizeof(float));
+    const bool late = cap > 0 && NV > 0 && A == 64 && b_rec + b_rslot + b_l1c <= ((size_t)1 << 30) &&
+                      opt_int(ctx, "MMW_ARGMAX_FORM", 1) == 1 && opt_int(ctx, "MMW_DETECT_LATE_ARGMAX", 1) != 0;
+    const size_t off_rec = total;
+    if (late) total += b_rec + b_rslot + b_l1c;
     MMW_TRY(ensure_scratch(ctx, total));
     char *base = (char *)ctx->scratch;
     a.ctl = (int *)base;
@@ -2036,7 +2050,16 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     a.twA = (const float2 *)twA;
     a.rf_az = ArgmaxRefine{d_l1, a.ctl + DCTL_ARGMAX, list, list_cap2, (float)ulps * eps / div, 4.f * (float)(n_az + 4) * eps / div};
     a.rf_el = ArgmaxRefine{d_l1, a.ctl + DCTL_ARGMAX, list, list_cap2, (float)ulps * eps / div, 4.f * (float)(n_el + 4) * eps / div};
+    a.rf_el.tag = REFINE_SECOND;
+    a.rf_el.n_tagged = a.ctl + DCTL_EL;
     a.n_frames = n_frames;
+    if (late) {
+        a.rec_cells = (float2 *)(base + off_rec);
+        a.rec_slot = (int32_t *)(base + off_rec + b_rec);
+        a.l1_copy = (float *)(base + off_rec + b_rec + b_rslot);
+        a.rec_cap = list_cap;
+        a.rf_az.l1 = a.rf_el.l1 = a.l1_copy;
+    }
     if (overlap) {
         a.sy_ctl = sync_words;
         a.sy_frame_cnt = sync_words + CTL_CNT;
@@ -2164,8 +2187,29 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     if (refine) {
         MMW_HIP(hipStreamWaitEvent(ctx->q_side, ctx->side_fork, 0));
         ctx->stream = ctx->q_side;
-        int rc;
-        {
+        int rc = MMW_OK;
+        if (late) {
+            // angle estimates of every record (one lane each), then the float64 refinement of what they flag
+            ProfScope ps(ctx, "argmax_tail");
+            const unsigned grid = (unsigned)std::max(1, std::min((list_cap + 255) / 256, 2 * ctx->num_cu));
+            auto recs = [&](auto kern, int off, int32_t *idx, const AntList &ants, const ArgmaxRefine &rf) {
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, ctx->stream, (const float2 *)a.rec_cells, (const int32_t *)a.rec_slot,
+                                   (const int *)(a.ctl + DCTL_RECS), a.rec_cap, NV, off, (const float *)a.l1_copy, idx, V, cap, ants,
+                                   (const float2 *)twA, rf);
+            };
+            auto one_list = [&](int off, int32_t *idx, const AntList &ants, int shift, const ArgmaxRefine &rf) {
+                if (ants.n == 0) return;
+                if (ants.n <= 4) {
+                    if (shift) recs(k_angle_argmax_recs<4, true>, off, idx, ants, rf); else recs(k_angle_argmax_recs<4, false>, off, idx, ants, rf);
+                } else {
+                    if (shift) recs(k_angle_argmax_recs<8, true>, off, idx, ants, rf); else recs(k_angle_argmax_recs<8, false>, off, idx, ants, rf);
+                }
+            };
+            one_list(0, d_az_idx, az_full, shift_az, a.rf_az);
+            one_list(n_az, d_el_idx, el_full, shift_el, a.rf_el);
+            rc = check_launch("angle_argmax_recs");
+        }
+        if (rc == MMW_OK) {
             ProfScope ps(ctx, "argmax_refine");
             RefineArgs ra{};
             rc = fill_refine_args(ctx, &ra, S, C, A);
@@ -2188,9 +2232,9 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
             if (rc == MMW_OK) rc = launch_argmax_refine(ctx, ra);
         }
         ctx->stream = main_stream;
-        MMW_HIP(hipEventRecord(ctx->side_join, ctx->q_side));      // (joined below in any case)
-        MMW_HIP(hipStreamWaitEvent(ctx->q_tail, ctx->side_join, 0));
+        MMW_HIP(hipEventRecord(ctx->side_join, ctx->q_side));      // (joined below in any case: in front of the list insertion)
         if (rc != MMW_OK) {
+            MMW_HIP(hipStreamWaitEvent(ctx->q_tail, ctx->side_join, 0));
             (void)tail_end(true);
             return rc;
         }
@@ -2236,6 +2280,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
                          h[3] - h[2], h[4] - h[3]);
         }
         rc_tail = check_launch("cfar_cell_exact");
+        if (refine) MMW_HIP(hipStreamWaitEvent(ctx->q_tail, ctx->side_join, 0));       // the refinement is done with the speculative slots
         if (rc_tail == MMW_OK) {
             hipLaunchKernelGGL(k_detect_insert, dim3(std::min(n_frames, 4 * ctx->num_cu)), dim3(INS_NT), 0, ctx->stream, a);
             rc_tail = check_launch("detect_insert");

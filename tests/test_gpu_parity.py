@@ -1094,6 +1094,44 @@ def test_mixed_radix_rd_kernel_all_shipped_shapes(S, C, monkeypatch):
         b.free()
 
 
+@pytest.mark.parametrize("S,C", [(63, 127), (127, 32), (254, 50)])
+def test_both_forms_of_the_127_point_level_meet_the_oracle(S, C):
+    """The 127-point DFT level of the shipped 63x127 / 127x32 / 254x50 planes has two forms: float32 MFMAs and the exact
+    three-way bfloat16 split (MMW_BIGPRIME_BF16, the default where it fits).  Both against the oracle at the 1e-5 bar, stand-alone
+    and as the producer of the device-synchronised chain, and against each other to float32 rounding."""
+    ctx = _lib.default_context()
+    L, h = ctx.lib, ctx.handle
+    F, V, A = 40, 12, 64
+    n = V * S * C
+    cubes = np.stack([synth.synth_cube(9100 + S + C + f, (V, S, C)) for f in range(F)]).astype(np.complex64)
+    d_in, d_rd, d_out = ctx.alloc(F * n * 8), ctx.alloc(F * n * 8), ctx.alloc(F * A * S * C * 8)
+    d_in.upload(cubes)
+    rd, ch = {}, {}
+    try:
+        for form in (0, 1):
+            ctx.set_option("MMW_BIGPRIME_BF16", form)
+            ctx.set_option("MMW_CHAIN_PIPELINE", 1)
+            d_rd.zero()
+            d_out.zero()
+            _lib.check(L.mmw_range_doppler(h, d_in.ptr, d_rd.ptr, None, F, V, S, C))
+            _lib.check(L.mmw_chain3d(h, d_in.ptr, None, d_out.ptr, F, V, S, C, A, 0))
+            rd[form] = d_rd.download((F, V, S, C), np.complex64)
+            ch[form] = d_out.download((F, A, S, C), np.complex64)
+    finally:
+        ctx.set_option("MMW_BIGPRIME_BF16", None)
+        ctx.set_option("MMW_CHAIN_PIPELINE", None)
+    for f in (0, F // 2, F - 1):
+        ref_rd, ref_ch = O.range_doppler(cubes[f]), O.fft3d_windowed(cubes[f], A)
+        for form in (0, 1):
+            assert rel_err(rd[form][f], ref_rd) <= SPEC_TOL, (form, f)
+            assert rel_err(ch[form][f], ref_ch) <= SPEC_TOL, (form, f)
+    dev_rd, dev_ch = cross_schedule_dev(rd[1], rd[0]), cross_schedule_dev(ch[1], ch[0])
+    print(f"127-point level {S}x{C}: bfloat16 x 3 against float32 MFMAs: RD {dev_rd:.2e}, chain {dev_ch:.2e} of the peak")
+    assert max(dev_rd, dev_ch) <= CROSS_SCHEDULE_TOL
+    for b in (d_in, d_rd, d_out):
+        b.free()
+
+
 @pytest.mark.parametrize("nrx,ntx,S,C", [(4, 3, 256, 128), (4, 3, 64, 32), (4, 3, 63, 70), (4, 2, 100, 30), (2, 2, 512, 64),
                                          (4, 3, 63, 127), (2, 2, 256, 256)])
 def test_raw_cube_entry_points_fold_the_virtual_array_reformat(nrx, ntx, S, C):
@@ -1484,10 +1522,23 @@ def test_raw_cube_device_synchronised_chain_on_shipped_shapes(monkeypatch, nrx, 
         monkeypatch.setenv("MMW_CHAIN_MODE", "sync")
 
     plan("sync")
-    _lib.check(L.mmw_chain3d(h, d_virt.ptr, None, d_a.ptr, F, V, S, C, A, 0))
-    _lib.check(L.mmw_chain3d_raw(h, d_raw.ptr, None, d_b.ptr, F, nrx, ntx, S, C, A, 0))
-    a, b = d_a.download((F, A, S, C), np.complex64), d_b.download((F, A, S, C), np.complex64)
-    np.testing.assert_array_equal(a, b)
+    # planes with a 127-point level: the virtual-array producer takes the bfloat16 x 3 form of that level by default, the
+    # raw-cube producer keeps the float32 MFMAs (registers) -- bit-identical with both on the float32 form, float32
+    # rounding apart with the defaults
+    big_prime = 127 in (S, C) or 254 in (S, C)
+    try:
+        if big_prime:
+            ctx.set_option("MMW_BIGPRIME_BF16", 0)
+        _lib.check(L.mmw_chain3d(h, d_virt.ptr, None, d_a.ptr, F, V, S, C, A, 0))
+        _lib.check(L.mmw_chain3d_raw(h, d_raw.ptr, None, d_b.ptr, F, nrx, ntx, S, C, A, 0))
+        a, b = d_a.download((F, A, S, C), np.complex64), d_b.download((F, A, S, C), np.complex64)
+        np.testing.assert_array_equal(a, b)
+    finally:
+        ctx.set_option("MMW_BIGPRIME_BF16", None)
+    if big_prime:
+        _lib.check(L.mmw_chain3d(h, d_virt.ptr, None, d_a.ptr, F, V, S, C, A, 0))
+        a = d_a.download((F, A, S, C), np.complex64)
+        assert cross_schedule_dev(b, a) <= CROSS_SCHEDULE_TOL
     plan("serial")
     d_b.zero()
     _lib.check(L.mmw_chain3d_raw(h, d_raw.ptr, None, d_b.ptr, F, nrx, ntx, S, C, A, 0))
@@ -1681,6 +1732,13 @@ def test_detect_points_screening_equals_the_float64_path(shape, frames, monkeypa
             r, v = dets_ref[:, 0].astype(int), dets_ref[:, 1].astype(int)
             np.testing.assert_array_equal(got[2][f, :k], O.angle_argmax(raw, r, v, az, 64, True)[0])
             np.testing.assert_array_equal(got[3][f, :k], O.angle_argmax(raw, r, v, el, 64, False)[0])
+    # the angle estimates come from the tail's record kernels by default (late argmax); the in-kernel form gives the same
+    try:
+        ctx.set_option("MMW_DETECT_LATE_ARGMAX", 0)
+        inside = _detect_points_raw(ctx, d_in, frames, shape, cfar, 1024, az, el)
+    finally:
+        ctx.set_option("MMW_DETECT_LATE_ARGMAX", None)
+    _same_points(inside, ref)
     monkeypatch.setenv("MMW_DETECT_BAND_MULT", "50")
     wide = _detect_points_raw(ctx, d_in, frames, shape, cfar, 1024, az, el)
     handed_back = wide[0] < 0
