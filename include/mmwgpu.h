@@ -51,7 +51,7 @@ typedef struct mmw_ctx mmw_ctx;
 const char *mmw_version(void);
 /* Bumped whenever an exported signature changes: a binding checks it at load (the argtypes of a ctypes binding are
  * hard-coded, so a library of another revision would reinterpret ints as device pointers). */
-#define MMWGPU_ABI_VERSION 4
+#define MMWGPU_ABI_VERSION 5
 int mmw_abi_version(void);
 const char *mmw_last_error(void);
 int mmw_device_count(int *count);
@@ -246,13 +246,15 @@ int mmw_detect_batch(mmw_ctx *ctx, const void *d_cubes, void *d_rd, double *d_ma
  *   h_stats (may be NULL; passing it synchronises): [0] frames with undecided cells, [1] undecided cells, [2] frames
  *   returned with count -1, [3] / [4] azimuth / elevation detections re-evaluated in float64.
  *   MMW_ERR_UNSUPPORTED (nothing launched) when mmw_detect_points_supported(...) == 0: CA-CFAR only, S * C float32
- *   magnitudes must fit the LDS, at most 8 antennas per list.
+ *   magnitudes must fit the LDS, at most 8 antennas per list -- at most 16 with A = 64 angle bins (the reference's
+ *   az_el_fft_size): then the angle estimates are launches of their own in the call's tail, one lane per detection, over
+ *   the cells the screening kernel copied aside (the "late argmax", the default whenever A = 64).
  *   The call's tail (exact cells, list insertion, float64 refinement) stays on side queues when the call returns: the
  *   range-Doppler launch of a following mmw_detect_points runs beside it; every other entry point of the context
  *   (mmw_sync, the copies, any other kernel) joins it first, so results are complete whenever they can be observed
  *   through this API.  Context option MMW_DETECT_DEFER_TAIL=0: each call joins its own tail. */
 int mmw_detect_points_supported(int S, int C, int cfar_kind, int train_r, int train_d, int guard_r, int guard_d,
-                                int n_az, int n_el);
+                                int n_az, int n_el, int A);
 int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1, float *d_mag32, int32_t *d_dets,
                       int32_t *d_counts, int32_t *d_az_idx, int32_t *d_el_idx, int n_frames, int V, int S, int C,
                       int cfar_kind, int train_r, int train_d, int guard_r, int guard_d, double scale, int k_rank, int cap,

@@ -20,7 +20,7 @@ MMW_OK = 0
 MMW_ERR_INVALID = -1
 MMW_ERR_TRUNCATED = -4
 MMW_ERR_UNSUPPORTED = -5
-ABI_VERSION = 4          # include/mmwgpu.h MMWGPU_ABI_VERSION: the argtypes below are for exactly this revision
+ABI_VERSION = 5          # include/mmwgpu.h MMWGPU_ABI_VERSION: the argtypes below are for exactly this revision
 CFAR_CA, CFAR_OS, CFAR_GO, CFAR_SO = 0, 1, 2, 3
 ANGLE_MAGNITUDE, ANGLE_NO_WINDOW, ANGLE_NO_SHIFT = 1, 2, 4
 QUEUE_COMPUTE, QUEUE_COPY = 0, 1
@@ -82,7 +82,7 @@ _SIGNATURES = {
     "mmw_cfar1d": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i],
     "mmw_compact2d": [_vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "mmw_detect_batch": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i],
-    "mmw_detect_points_supported": [_i, _i, _i, _i, _i, _i, _i, _i, _i],
+    "mmw_detect_points_supported": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i],
     "mmw_detect_points": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i, _i,
                           _ip, _i, _i, _ip, _i, _i, _i, _ip],
     "mmw_angle_argmax": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ip, _i, _i, _i],

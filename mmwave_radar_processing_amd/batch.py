@@ -287,7 +287,7 @@ class FramePipeline:
     def _fused_supported(self, with_angles: bool) -> bool:
         kind, tr, td, gr, gd, _, _ = self._cfar_args()
         n_az, n_el = (len(self.az), len(self.el)) if with_angles else (0, 0)
-        return bool(self.ctx.lib.mmw_detect_points_supported(self.S, self.C, kind, tr, td, gr, gd, n_az, n_el))
+        return bool(self.ctx.lib.mmw_detect_points_supported(self.S, self.C, kind, tr, td, gr, gd, n_az, n_el, self.A))
 
     def _detect_fused(self, with_angles: bool):
         """``mmw_detect_points``: RD + screened CFAR (undecided cells settled in float64) + ordered compaction (+ the

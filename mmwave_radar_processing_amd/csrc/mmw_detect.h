@@ -43,6 +43,8 @@ constexpr int DET_NT = 512;              // threads of the per-frame workgroup: 
                                          // VGPRs): one's barriers and load waits are the other's issue slots -- 8 % faster than one of 1024
 constexpr int DET_MAX_ANT = 8;           // antennas per list inside the fused kernels (cells, twiddles and error scales of a
                                          // list live in registers; lists of 9+ antennas take mmw_angle_argmax_exact)
+constexpr int DET_LATE_MAX_ANT = 16;     // ... per list with the late argmax (64 angle bins: k_angle_argmax_recs, one lane per detection,
+                                         // 64 / N register FFTs of length N = 4, 8 or 16)
 constexpr int DET_LIST2 = 16;            // first lane of the second list's cells
 constexpr int DET_SPEC = 32;             // undecided cells a frame may carry speculatively (more: the frame is handed back)
 enum { DST_UNDECIDED = 1, DST_OVERFLOW = 2, DST_DEGENERATE = 4 };
@@ -51,7 +53,7 @@ enum { DCTL_FLAG_FRAMES = 0, DCTL_CELLS = 1, DCTL_FALLBACK = 2, DCTL_RECS = 3, D
 
 struct DetAnt {            // antenna list of one angle estimate (n == 0: not wanted)
     int n;
-    int idx[DET_MAX_ANT];
+    int idx[DET_LATE_MAX_ANT];
 };
 
 struct DetectArgs {
@@ -136,11 +138,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int *ws, int *total, int t
     return excl;
 }
 
-// antenna tables of the two lists in LDS (tab[0..8) azimuth, tab[16..24) elevation): constant kernel-argument indices
+// antenna tables of the two lists in LDS (tab[0..16) azimuth, tab[16..32) elevation): constant kernel-argument indices
 // here, lane-indexed reads later
 __device__ __forceinline__ void detect_ant_table(const DetectArgs &a, int *tab) {
     if (threadIdx.x == 0) {
-        static_for<DET_MAX_ANT>([&](auto I) {
+        static_for<DET_LATE_MAX_ANT>([&](auto I) {
             constexpr int i = decltype(I)::value;
             tab[i] = a.az.idx[i];
             tab[DET_LIST2 + i] = a.el.idx[i];
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256) void k_angle_argmax_dets(const float2 *__restr
                                                             const int32_t *__restrict__ counts, int32_t *__restrict__ out_idx, int V, int S,
                                                             int C, int cap, AntList ants, const float2 *__restrict__ twA, ArgmaxRefine rf) {
     constexpr int A = 64;
-    static_assert(N == 4 || N == 8, "lists of up to 4 / up to 8 antennas");
+    static_assert(N == 4 || N == 8 || N == 16, "lists of up to 4 / 8 / 16 antennas");
     __shared__ float2 tw[A];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < A) tw[tid] = twA[tid];

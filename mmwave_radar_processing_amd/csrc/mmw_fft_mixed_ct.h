@@ -72,9 +72,13 @@ constexpr bool mixct_abf_fits(int S, int C) {
     return big && room && mixct_lds_base(S, C) + MIXCT_ABF_BYTES <= 160 * 1024 - 256;
 }
 constexpr size_t mixct_lds_bytes(int S, int C, bool bf = false) { return mixct_lds_base(S, C) + (bf && mixct_abf_fits(S, C) ? MIXCT_ABF_BYTES : 0); }
-// which launches take the bfloat16 form: 63 x 127 and 254 x 50 (one workgroup per CU in either form) always; 127 x 32 only as the
-// producer of the device-synchronised chain (+12 %) -- stand-alone, four small float32-form workgroups per CU are faster
-constexpr bool mixct_use_bf(int S, int C, bool sync) { return mixct_abf_fits(S, C) && (sync || !(S == 127 && C == 32)); }
+// which launches take the bfloat16 form (A/B at 2048 frames, tools/bigprime_ab.sh -> profiles/r04_bigprime_ab.log): the stand-alone
+// range-Doppler of 63 x 127 and 254 x 50 (+8-10 % at 12 antennas, +2-7 % at 8).  NOT the producer of the device-synchronised
+// chain: there the two forms are within 2 % of each other for 63 x 127 / 254 x 50 (the chain is paced by the angle stage and by
+// the producer's CU share, not by this level) and the bfloat16 form's 96 KB table costs 127 x 32 its second workgroup per CU
+// (12 antennas: 0.67 against 0.51 us/frame) -- so every chain producer, raw-cube or not, runs the float32 form and the two
+// stay bit-identical.  127 x 32 stand-alone: four small float32-form workgroups per CU are faster.
+constexpr bool mixct_use_bf(int S, int C, bool sync) { return mixct_abf_fits(S, C) && !sync && !(S == 127 && C == 32); }
 
 struct RdMixedCtArgs {
     const void *in;             // complex64 planes

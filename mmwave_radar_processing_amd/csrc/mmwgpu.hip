@@ -1569,15 +1569,17 @@ static void launch_angle_argmax(mmw_ctx *ctx, dim3 grid, const float2 *rd, const
 #define MMW_ARGMAX(NA) \
     hipLaunchKernelGGL(k_angle_argmax<NA>, grid, dim3(256), 0, ctx->stream, rd, dets, counts, idx, V, S, C, cap, ants, A, shift, twA, rf)
     // lists of up to 8 antennas with the error bound: the lane-resident routine of the fused detection stage
-    if (rf.l1 && ants.n <= DET_MAX_ANT && A == 64 && opt_int(ctx, "MMW_ARGMAX_FORM", 1) == 1) {
+    if (rf.l1 && ants.n <= DET_LATE_MAX_ANT && A == 64 && opt_int(ctx, "MMW_ARGMAX_FORM", 1) == 1) {
         // one lane per detection (64 bins as register FFTs): 256 detections of a frame per workgroup and pass
         const dim3 g2((unsigned)std::min((cap + 255) / 256, 4), grid.y);
 #define MMW_ARGMAX_DETS(NA, SH) \
     hipLaunchKernelGGL((k_angle_argmax_dets<NA, SH>), g2, dim3(256), 0, ctx->stream, rd, dets, counts, idx, V, S, C, cap, ants, twA, rf)
         if (ants.n <= 4) {
             if (shift) MMW_ARGMAX_DETS(4, true); else MMW_ARGMAX_DETS(4, false);
-        } else {
+        } else if (ants.n <= 8) {
             if (shift) MMW_ARGMAX_DETS(8, true); else MMW_ARGMAX_DETS(8, false);
+        } else {
+            if (shift) MMW_ARGMAX_DETS(16, true); else MMW_ARGMAX_DETS(16, false);
         }
 #undef MMW_ARGMAX_DETS
         return;
@@ -1871,7 +1873,9 @@ DetectPlan detect_plan(int S, int C, int kind, int tr, int td, int gr, int gd, i
     DetectPlan p{};
     const long n = (long)S * C;
     const int hr = tr + gr, hd = td + gd;
-    if (kind != MMW_CFAR_CA || n_az > DET_MAX_ANT || n_el > DET_MAX_ANT || n > (1L << 20) || A < 1 || A > 1024) return p;
+    // lists of up to 8 antennas: any angle FFT size; 9 to 16: the late argmax only, i.e. 64 angle bins
+    const int n_max = A == 64 ? DET_LATE_MAX_ANT : DET_MAX_ANT;
+    if (kind != MMW_CFAR_CA || n_az > n_max || n_el > n_max || n > (1L << 20) || A < 1 || A > 1024) return p;
     if (0) return p;
     p.words = (int)((n + 31) / 32);
     p.lds_cell = cell_exact_lds(S, C, 2 * hr + 1, 2 * hd + 1);
@@ -1898,15 +1902,15 @@ int fill_det_ant(const int *h_ant, int n_ant, int V, int A, DetAnt *out, AntList
     if (n_ant == 0) return MMW_OK;
     MMW_TRY(fill_ant_list(h_ant, n_ant, V, A, full));
     out->n = full->n;
-    for (int i = 0; i < full->n && i < DET_MAX_ANT; ++i) out->idx[i] = full->idx[i];
+    for (int i = 0; i < full->n && i < DET_LATE_MAX_ANT; ++i) out->idx[i] = full->idx[i];
     return MMW_OK;
 }
 }  // namespace
 
 int mmw_detect_points_supported(int S, int C, int cfar_kind, int train_r, int train_d, int guard_r, int guard_d, int n_az,
-                                int n_el) {
+                                int n_el, int A) {
     if (S <= 0 || C <= 0 || train_r < 0 || train_d < 0 || guard_r < 0 || guard_d < 0 || n_az < 0 || n_el < 0) return 0;
-    return detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el).ok ? 1 : 0;
+    return detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el, A).ok ? 1 : 0;
 }
 
 int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1, float *d_mag32, int32_t *d_dets,
@@ -1922,8 +1926,8 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     const DetectPlan plan = detect_plan(S, C, cfar_kind, train_r, train_d, guard_r, guard_d, n_az, n_el, A);
     if (!plan.ok)
         return set_error(MMW_ERR_UNSUPPORTED, "mmw_detect_points: no screening kernel for this request (CA-CFAR on planes whose "
-                         "float32 magnitudes fit the LDS, <= %d antennas per list): use mmw_detect_batch + mmw_angle_argmax_exact",
-                         DET_MAX_ANT);
+                         "float32 magnitudes fit the LDS, <= %d antennas per list, <= %d with 64 angle bins): use mmw_detect_batch + "
+                         "mmw_angle_argmax_exact", DET_MAX_ANT, DET_LATE_MAX_ANT);
     const int hr = train_r + guard_r, hd = train_d + guard_d;
     const long n_train = (long)(2 * hr + 1) * (2 * hd + 1) - (long)(2 * guard_r + 1) * (2 * guard_d + 1);
     MMW_REQUIRE(n_train >= 1 && n_train < (1L << 30), "empty training window");
@@ -1979,6 +1983,9 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
                  b_l1c = up((size_t)n_frames * V * sizeof(float));
     const bool late = cap > 0 && NV > 0 && A == 64 && b_rec + b_rslot + b_l1c <= ((size_t)1 << 30) &&
                       opt_int(ctx, "MMW_ARGMAX_FORM", 1) == 1 && opt_int(ctx, "MMW_DETECT_LATE_ARGMAX", 1) != 0;
+    if ((n_az > DET_MAX_ANT || n_el > DET_MAX_ANT) && !late)
+        return set_error(MMW_ERR_UNSUPPORTED, "mmw_detect_points: lists of more than %d antennas need the late argmax (64 angle bins, "
+                         "MMW_DETECT_LATE_ARGMAX / MMW_ARGMAX_FORM at their defaults, a detection capacity whose records fit 1 GiB)", DET_MAX_ANT);
     const size_t off_rec = total;
     if (late) total += b_rec + b_rslot + b_l1c;
     MMW_TRY(ensure_scratch(ctx, total));
@@ -2201,8 +2208,10 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
                 if (ants.n == 0) return;
                 if (ants.n <= 4) {
                     if (shift) recs(k_angle_argmax_recs<4, true>, off, idx, ants, rf); else recs(k_angle_argmax_recs<4, false>, off, idx, ants, rf);
-                } else {
+                } else if (ants.n <= 8) {
                     if (shift) recs(k_angle_argmax_recs<8, true>, off, idx, ants, rf); else recs(k_angle_argmax_recs<8, false>, off, idx, ants, rf);
+                } else {
+                    if (shift) recs(k_angle_argmax_recs<16, true>, off, idx, ants, rf); else recs(k_angle_argmax_recs<16, false>, off, idx, ants, rf);
                 }
             };
             one_list(0, d_az_idx, az_full, shift_az, a.rf_az);

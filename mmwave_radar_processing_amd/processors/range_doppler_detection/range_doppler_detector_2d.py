@@ -29,7 +29,7 @@ class RangeDopplerDetector2D(RangeDopplerDetector):
         (tr, td), (gr, gd) = det.num_train, det.num_guard
         return det.kind, int(tr), int(td), int(gr), int(gd), float(det._scale()), int(det._k_rank())
 
-    def _fused_supported(self, S, C, n_az=0, n_el=0) -> bool:
+    def _fused_supported(self, S, C, n_az=0, n_el=0, num_angle_bins=64) -> bool:
         det = self.detector
         if type(self)._detect is not RangeDopplerDetector2D._detect:
             return False        # a subclass with its own _detect (the reference's extension point) is never bypassed
@@ -37,14 +37,14 @@ class RangeDopplerDetector2D(RangeDopplerDetector):
             return False
         kind, tr, td, gr, gd, _, _ = self._cfar_args()
         ctx, _ = self._device()
-        return bool(ctx.lib.mmw_detect_points_supported(S, C, kind, tr, td, gr, gd, n_az, n_el))
+        return bool(ctx.lib.mmw_detect_points_supported(S, C, kind, tr, td, gr, gd, n_az, n_el, int(num_angle_bins)))
 
     def process_points(self, adc_cube: np.ndarray, az=(), el=(), shift_az=True, shift_el=False, num_angle_bins=64):
         """Detections AND the argmax angle bins of both antenna lists in one device call (``mmw_detect_points``); returns
         ``dets`` and leaves ``self.points = (az_idx, el_idx)`` (None for an empty list).  None when the request has no
         fused kernel (the caller then takes ``process()`` + ``mmw_angle_argmax_exact``)."""
         ctx, bufs, d_cube, (V, S, C) = self._upload_cube(adc_cube)
-        if not self._fused_supported(S, C, len(az), len(el)):
+        if not self._fused_supported(S, C, len(az), len(el), num_angle_bins):
             return None
         L, h = ctx.lib, ctx.handle
         cap = S * C

@@ -1715,7 +1715,7 @@ def test_detect_points_screening_equals_the_float64_path(shape, frames, monkeypa
     az, el = list(range(min(8, V))), list(range(max(0, V - 4), V))
     d_in = ctx.alloc(frames * V * S * C * 8)
     _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, frames, V, S, C, 424242, 8, 30.0))
-    assert ctx.lib.mmw_detect_points_supported(S, C, cfar.kind, 4, 4, 2, 2, len(az), len(el)) == 1
+    assert ctx.lib.mmw_detect_points_supported(S, C, cfar.kind, 4, 4, 2, 2, len(az), len(el), 64) == 1
     ref = _detect_float64_raw(ctx, d_in, frames, shape, cfar, 1024, az, el)
     got = _detect_points_raw(ctx, d_in, frames, shape, cfar, 1024, az, el)
     _same_points(got, ref)
@@ -1746,6 +1746,48 @@ def test_detect_points_screening_equals_the_float64_path(shape, frames, monkeypa
     keep = ~handed_back
     _same_points(tuple(x[keep] for x in wide[:4]), tuple(x[keep] for x in ref))
     print(f"  band x50: {wide[4][1]} undecided cells in {wide[4][0]} frames, {wide[4][2]} frames handed back")
+    d_in.free()
+
+
+@pytest.mark.parametrize("shape,frames,az,el", [((16, 64, 32), 200, list(range(12)), list(range(7, 16))),
+                                                ((12, 256, 128), 48, list(range(12)), [11, 3, 7, 0, 5, 9, 1, 8, 2, 10]),
+                                                ((16, 63, 100), 120, list(range(16)), [15, 14, 13])])
+def test_detect_points_with_lists_of_nine_to_sixteen_antennas(shape, frames, az, el):
+    """Antenna lists of 9 to 16 entries (point_cloud_generator.py:143-214 accepts any list) through the fused stage: with 64
+    angle bins the angle estimates are the tail's lane-per-detection launches (16 / N register FFTs of N = 16 points), with
+    the same worst-case bound and pairwise test; identical to the float64 path and to the oracle.  The band is widened so
+    that speculative slots and flagged evaluations occur.  Without the late argmax such lists have no fused kernel."""
+    ctx = _lib.default_context()
+    V, S, C = shape
+    cfar = CaCFAR2D((4, 4), (2, 2), 1e-4)
+    d_in = ctx.alloc(frames * V * S * C * 8)
+    _lib.check(ctx.lib.mmw_synth_cubes(ctx.handle, d_in.ptr, frames, V, S, C, 171717, 8, 30.0))
+    assert ctx.lib.mmw_detect_points_supported(S, C, cfar.kind, 4, 4, 2, 2, len(az), len(el), 64) == 1
+    assert ctx.lib.mmw_detect_points_supported(S, C, cfar.kind, 4, 4, 2, 2, len(az), len(el), 128) == 0
+    ref = _detect_float64_raw(ctx, d_in, frames, shape, cfar, 512, az, el)
+    try:
+        ctx.set_option("MMW_DETECT_BAND_MULT", 20)
+        got = _detect_points_raw(ctx, d_in, frames, shape, cfar, 512, az, el)
+        ctx.set_option("MMW_DETECT_LATE_ARGMAX", 0)
+        with pytest.raises(_lib.MmwGpuError):
+            _detect_points_raw(ctx, d_in, frames, shape, cfar, 512, az, el)
+    finally:
+        ctx.set_option("MMW_DETECT_BAND_MULT", None)
+        ctx.set_option("MMW_DETECT_LATE_ARGMAX", None)
+    keep = got[0] >= 0
+    assert keep.sum() >= frames // 2 and ref[0].sum() > frames
+    _same_points(tuple(x[keep] for x in got[:4]), tuple(x[keep] for x in ref))
+    print(f"{shape}, lists of {len(az)} / {len(el)} antennas: {int(ref[0].sum())} detections in {frames} frames, {got[4][1]} cells decided in "
+          f"float64, {got[4][3]} + {got[4][4]} evaluations refined, {int((~keep).sum())} frames handed back")
+    for f in np.nonzero(keep)[0][:3]:
+        cube = d_in.download((V, S, C), np.complex64, int(f) * V * S * C * 8)
+        raw, _, dets_ref, _, _ = O.rd_detect_2d(cube, (4, 4), (2, 2), 1e-4)
+        k = int(got[0][f])
+        np.testing.assert_array_equal(got[1][f, :k], dets_ref)
+        if k:
+            r, v = dets_ref[:, 0].astype(int), dets_ref[:, 1].astype(int)
+            np.testing.assert_array_equal(got[2][f, :k], O.angle_argmax(raw, r, v, az, 64, True)[0])
+            np.testing.assert_array_equal(got[3][f, :k], O.angle_argmax(raw, r, v, el, 64, False)[0])
     d_in.free()
 
 

@@ -13,6 +13,7 @@ ap.add_argument("--shape", default="12,63,100")
 ap.add_argument("--frames", type=int, default=2048)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--tag", default="")
+ap.add_argument("--rd", action="store_true", help="time mmw_range_doppler (cube out) instead of the chain")
 args = ap.parse_args()
 V, S, C = (int(x) for x in args.shape.split(","))
 A = 64
@@ -22,10 +23,13 @@ n = V * S * C * 8
 d_in, d_out = ctx.alloc(args.frames * n), ctx.alloc(args.frames * A * S * C * 8)
 _lib.check(L.mmw_synth_cubes(ctx.handle, d_in.ptr, args.frames, V, S, C, 5, 8, 30.0))
 fn = lambda: _lib.check(L.mmw_chain3d(ctx.handle, d_in.ptr, None, d_out.ptr, args.frames, V, S, C, A, 0))
+if args.rd:
+    fn = lambda: _lib.check(L.mmw_range_doppler(ctx.handle, d_in.ptr, d_out.ptr, None, args.frames, V, S, C))
 fn()
 ctx.sync()
 ctx.timer_start()
 for _ in range(args.reps):
     fn()
 ms = ctx.timer_stop() / args.reps
-print(f"{args.tag} chain {args.shape}: {1e3 * ms / args.frames:.3f} us/frame, {(n + A * S * C * 8) * args.frames / ms / 1e6:.0f} GB/s", flush=True)
+moved = 2 * n if args.rd else n + A * S * C * 8
+print(f"{args.tag} {'rd' if args.rd else 'chain'} {args.shape}: {1e3 * ms / args.frames:.3f} us/frame, {moved * args.frames / ms / 1e6:.0f} GB/s", flush=True)

@@ -129,7 +129,7 @@ def main():
     d_az, d_el, d_l1p, d_m32 = ctx.alloc(F * cap * 4), ctx.alloc(F * cap * 4), ctx.alloc(F * V * 4), ctx.alloc(F * S * C * 4)
     az8, n_az = _lib.int_array(range(min(8, V)))
     el4, n_el = _lib.int_array(range(max(0, V - 4), V))
-    if L.mmw_detect_points_supported(S, C, 0, 4, 4, 2, 2, n_az, n_el):
+    if L.mmw_detect_points_supported(S, C, 0, 4, 4, 2, 2, n_az, n_el, 64):
         run("detect_points_config3", lambda: _lib.check(L.mmw_detect_points(
             ctx.handle, d_in.ptr, d_rd.ptr, d_l1p.ptr, d_m32.ptr, d_dets.ptr, d_cnt.ptr, d_az.ptr, d_el.ptr, F, V, S, C, 0, 4, 4, 2, 2,
             alpha, 0, cap, az8, n_az, 1, el4, n_el, 0, A, None)), F * (2 * cube_b + S * C * 4))
