@@ -492,6 +492,102 @@ __global__ __launch_bounds__(64 * NW) void k_bartlett_tile(const cplx<float> *__
     mark(4);
 }
 
+// ONE frame at the reference's size (256 x 256 x 60-64) is sixteen 32 x 32 tiles: sixteen workgroups, each a single latency
+// chain (positions -> rows -> phases -> 48 MFMAs + 16 sines / cosines per lane -> LDS reduction) on a chip of 256 CUs.  The
+// same kernel on 16 x 16 tiles (v_mfma_f32_16x16x32_bf16, the bfloat16 x 3 form only) spreads the frame over 64 workgroups
+// whose waves steer 8 values of k each (group g = lane >> 4 feeds k0 + 8 g + j) and issue 24 MFMAs of 16 cycles: the chain
+// per workgroup is half as long.  Used while the 32 x 32 tiling would leave three quarters of the chip without a workgroup.
+template <int NW, bool FAST>
+__global__ __launch_bounds__(64 * NW) void k_bartlett_tile16(const cplx<float> *__restrict__ X, const double *__restrict__ P,
+                                                              const double *__restrict__ dirs, const float *__restrict__ hamming,
+                                                              cplx<float> *__restrict__ Cm, int S, int E, int T, int tiles_s, int NT,
+                                                              int MT, double inv_lambda) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, i16 = lane & 15;
+    const int slot = blockIdx.x >> 3, st = slot / NT, nt = slot - st * NT;
+    const int mt = st * 8 + (blockIdx.x & 7);
+    if (mt >= MT) return;                               // padding of the row-tile count to the 8 XCDs (whole workgroup)
+    const int fi = mt / tiles_s;
+    const long f = fi;
+    const int m0 = (mt - fi * tiles_s) * 16, n0 = nt * 16;
+    double *Ps = reinterpret_cast<double *>(smem + wave * BT_STRIP);
+    float *hs = reinterpret_cast<float *>(smem + wave * BT_STRIP + 3 * 64 * 8);
+    float *red = reinterpret_cast<float *>(smem + NW * BT_STRIP);                     // [NW][2][4][64]
+    const int tc = n0 + i16 < T ? n0 + i16 : T - 1;
+    const double dx = dirs[tc] * inv_lambda, dy = dirs[T + tc] * inv_lambda, dz = dirs[2 * T + tc] * inv_lambda;
+    const int gm = m0 + i16 < S ? m0 + i16 : S - 1;
+    const cplx<float> *xrow = X + (f * S + gm) * (long)E;
+    const double *Pf = P + f * 3 * E;
+    v4f acc_r = {0}, acc_i = {0}, acc_r2 = {0}, acc_i2 = {0};
+    const int n_chunks = (E + CH - 1) / CH;
+    for (int q = wave; q < n_chunks; q += NW) {
+        const int k0 = q * CH, kb = k0 + 8 * g;
+        const int e_st = k0 + lane < E ? k0 + lane : E - 1;
+        const bool st_on = lane < CH;
+        const double p0 = Pf[e_st], p1 = Pf[E + e_st], p2 = Pf[2 * E + e_st];
+        const float hv = (st_on && k0 + lane < E) ? hamming[e_st] : 0.f;
+        f32x4 ra[4];
+        if (FAST) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(xrow + kb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[j] = src[j];
+        } else {                                        // last chunk / odd row pitch: clamped 8-byte loads, taper 0 beyond E
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ka = kb + 2 * j < E ? kb + 2 * j : E - 1, kc = kb + 2 * j + 1 < E ? kb + 2 * j + 1 : E - 1;
+                const cplx<float> a = xrow[ka], c = xrow[kc];
+                ra[j] = f32x4{a.x, a.y, c.x, c.y};
+            }
+        }
+        if (st_on) {
+            Ps[lane] = p0;
+            Ps[64 + lane] = p1;
+            Ps[128 + lane] = p2;
+            hs[lane] = hv;
+        }
+        wave_lds_sync();
+        float arv[8], aiv[8], brv[8], biv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ke = 8 * g + j;
+            const double turns = dx * Ps[ke] + dy * Ps[64 + ke] + dz * Ps[128 + ke];
+            const float rt = (float)__builtin_amdgcn_fract(turns), hm = hs[ke];
+            brv[j] = __builtin_amdgcn_cosf(rt) * hm;
+            biv[j] = __builtin_amdgcn_sinf(rt) * hm;
+            arv[j] = (j & 1) ? ra[j >> 1].z : ra[j >> 1].x;
+            aiv[j] = (j & 1) ? ra[j >> 1].w : ra[j >> 1].y;
+        }
+        bf16x8 ar3[3], ai3[3], br3[3], bi3[3];
+        split_bf16x3(arv, ar3[0], ar3[1], ar3[2]);
+        split_bf16x3(aiv, ai3[0], ai3[1], ai3[2]);
+        split_bf16x3(brv, br3[0], br3[1], br3[2]);
+        split_bf16x3(biv, bi3[0], bi3[1], bi3[2]);
+        acc_r = mfma16_bf16x3(ar3, br3, acc_r);
+        acc_i = mfma16_bf16x3(ar3, bi3, acc_i);
+        acc_r2 = mfma16_bf16x3(ai3, bi3, acc_r2);         // (subtracted below)
+        acc_i2 = mfma16_bf16x3(ai3, br3, acc_i2);
+        wave_lds_sync();                                // the strip is rewritten by the next chunk
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc_r[r] - acc_r2[r];
+        red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc_i[r] + acc_i2[r];
+    }
+    __syncthreads();
+    // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg; partial tiles added in wave order
+    for (int r = wave; r < 4; r += NW) {
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            sr += red[((w * 2 + 0) * 4 + r) * 64 + lane];
+            si += red[((w * 2 + 1) * 4 + r) * 64 + lane];
+        }
+        const int row = m0 + 4 * g + r, col = n0 + i16;
+        if (row < S && col < T) Cm[(f * S + row) * (long)T + col] = cplx<float>{sr, si};
+    }
+}
+
 // d_X [F][S][E] c64, d_P [F][3][E] f64, d_dirs [3][T] f64 -> d_out [F][S][T] c64
 inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const double *d_dirs, void *d_out, int n_frames, int S,
                     int E, int T, double lambda_m) {
@@ -525,6 +621,18 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
         const bool poly = opt_int(ctx, "MMW_BARTLETT_POLY", 0) != 0;       // polynomial sine / cosine instead of v_sin / v_cos
         // MMW_BARTLETT_BF16 (default 1): the contraction on bf16 x 3 MFMAs; 0: float32 MFMAs
         const bool bf3 = opt_int(ctx, "MMW_BARTLETT_BF16", 1) != 0 && !poly;
+        // a frame or two (less than a 32 x 32 tile per four CUs): 16 x 16 tiles (MMW_BARTLETT_TILE16=0: never, 1: always)
+        const int t16 = opt_int(ctx, "MMW_BARTLETT_TILE16", -1);
+        if (bf3 && !tune_int("MMW_PHASE_CLOCKS", 0) && (t16 == 1 || (t16 != 0 && MT * NT * 4 <= ctx->num_cu))) {
+            const int tiles16 = (S + 15) / 16, NT16 = (T + 15) / 16;
+            const long MT16 = (long)n_frames * tiles16;
+            const unsigned grid16 = (unsigned)(8 * NT16 * ((MT16 + 7) / 8));
+            const size_t lds16 = (size_t)nw * BT_STRIP + (size_t)nw * 2 * 4 * 64 * 4;
+            auto k16 = (E & 31) == 0 ? k_bartlett_tile16<8, true> : k_bartlett_tile16<8, false>;
+            hipLaunchKernelGGL(k16, dim3(grid16), dim3(64 * nw), lds16, ctx->stream, (const cplx<float> *)d_X, d_P, d_dirs,
+                               (const float *)ham, Cm, S, E, T, tiles16, NT16, (int)MT16, 1.0 / lambda_m);
+            MMW_TRY(check_launch("bartlett_tile16"));
+        } else {
         auto kern = bf3 ? k_bartlett_tile<8, 16, false, 3> : k_bartlett_tile<8, 16, false, 1>;
         if ((E & 31) == 0) kern = poly ? k_bartlett_tile<8, 16, true, 0> : bf3 ? k_bartlett_tile<8, 16, true, 3> : k_bartlett_tile<8, 16, true, 1>;
         else if (poly) kern = k_bartlett_tile<8, 16, false, 0>;
@@ -545,6 +653,7 @@ inline int bartlett(mmw_ctx *ctx, const void *d_X, const double *d_P, const doub
                          h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3]);
         }
         MMW_TRY(check_launch("bartlett_tile"));
+        }
     } else {
         const long nW = (long)E * Tp;
         hipLaunchKernelGGL(k_steer, dim3((unsigned)((nW + 255) / 256), (unsigned)n_frames), dim3(256), 0, ctx->stream, W, d_P, d_dirs,

@@ -43,6 +43,19 @@ __device__ __forceinline__ v16f mfma_bf16x3(const bf16x8 (&a)[3], const bf16x8 (
     return acc;
 }
 
+// the same on 16 x 16 tiles over 32 values of k (v_mfma_f32_16x16x32_bf16: lane l holds A[row l & 15][k = 8 (l >> 4) + j],
+// B[k = 8 (l >> 4) + j][col l & 15]; C/D: col = l & 15, row = 4 (l >> 4) + reg)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f mfma16_bf16x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], v4f acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
 // the leading piece alone (element j = v[j] truncated to 8 significant bits)
 __device__ __forceinline__ bf16x8 top_bf16(const float (&v)[8]) {
     u32x4 p1;

@@ -456,7 +456,8 @@ def test_bartlett_mfma_vs_oracle_shapes(S, E, naz, nel):
 def test_bartlett_both_contraction_paths():
     """The steering-matrix contraction has two kernels: the fused tile kernel (small problems: steering evaluated in the
     kernel) and the LDS-tiled GEMM behind k_steer (large ones).  A problem big enough for the second by default, and the small
-    shapes forced through each path and through the polynomial sine / cosine variant of the tile kernel (context options)."""
+    shapes forced through each path, through the polynomial sine / cosine variant of the tile kernel, through its 16 x 16-tile
+    form (the default for a frame or two) and through the float32-MFMA form (context options)."""
     from mmwave_radar_processing_amd.processors.steering_beamformers import SyntheticArrayBeamformerCore
     rng = np.random.default_rng(77)
     S, E = 512, 128
@@ -468,7 +469,8 @@ def test_bartlett_both_contraction_paths():
     for f in range(3):
         assert rel_err(out[f], O.bartlett_response(X[f].astype(complex), P[f], O.steering_dirs(az, el), lam)) <= SPEC_TOL
     ctx = _lib.default_context()
-    for knobs in ({"MMW_BARTLETT_PATH": 2}, {"MMW_BARTLETT_PATH": 1}, {"MMW_BARTLETT_PATH": 1, "MMW_BARTLETT_POLY": 1}):
+    for knobs in ({"MMW_BARTLETT_PATH": 2}, {"MMW_BARTLETT_PATH": 1, "MMW_BARTLETT_TILE16": 0}, {"MMW_BARTLETT_PATH": 1, "MMW_BARTLETT_POLY": 1},
+                  {"MMW_BARTLETT_PATH": 1, "MMW_BARTLETT_TILE16": 1}, {"MMW_BARTLETT_PATH": 1, "MMW_BARTLETT_BF16": 0}):
         for k, v in knobs.items():
             ctx.set_option(k, v)
         try:
