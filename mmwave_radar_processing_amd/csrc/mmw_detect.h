@@ -29,9 +29,10 @@
 // k_detect_finish once their bit masks are complete.  A frame whose input is not finite, or that has more undecided cells
 // than the list holds, gets counts[f] = -1: the caller runs it through the float64 path (mmw_detect_batch).
 //
-// Compaction is ordered (np.where order, base.py:229-230); the per-detection angle argmax (azimuth and elevation lists
-// in the same pass, float32 with the error bound of k_angle_argmax, flagged near-ties re-evaluated in float64 by the
-// k_argmax_refine_* kernels) runs in the same workgroup.
+// Compaction is ordered (np.where order, base.py:229-230); the per-detection angle argmax (azimuth and elevation lists,
+// float32 with the error bound of k_angle_argmax, flagged near-ties re-evaluated in float64 by the k_argmax_refine_* kernels)
+// runs in the same workgroup -- or, with 64 angle bins (the default: "late argmax"), as launches of their own in the call's
+// tail over the cells this workgroup copied into the context's record list (DetectArgs::rec_cells, k_angle_argmax_recs).
 #pragma once
 #include "mmw_ctx.h"
 #include "mmw_misc.h"
