@@ -159,6 +159,7 @@ DET_CFAR = dict(kind=0, train=(4, 4), guard=(2, 2), pfa=1e-5)      # CaCFAR2D((4
 OS_CFAR = dict(kind=1, train=(5, 5), guard=(3, 2), rho=0.7, alpha=2.0)
 AZ_ANT, EL_ANT = list(range(8)), [8, 9, 10, 11]
 DET_CAP = 2048
+SUB_WARMUP = 25         # untimed calls in front of the timed steps of the `detect` / `detect_os` sub-records
 DET_BYTES_PER_FRAME = 2 * CUBE_BYTES + S * C * 4    # RD cube in + out, antenna-0 magnitude (+ 8 B / detection)
 
 
@@ -379,9 +380,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def timed(step_fn, profile_every):
+    def timed(step_fn, profile_every, warmup=None):
         """W untimed + exactly K timed steps between barriers; (max-over-ranks wall seconds, rank-local HIP-event ms)."""
-        for _ in range(args.warmup):
+        for _ in range(args.warmup if warmup is None else warmup):
             step_fn()
         barrier()
         if not args.no_profile:
@@ -404,18 +405,20 @@ def main():
         return dt, ev
 
     elapsed, ev_ms = timed(step, args.profile_every if args.profile_every > 0 else (1 if n_launch == 1 else 7))
-    prof = {k: ctx.profile_get(k) for k in ("rd", "angle", "detect", "detect_tail", "detect_exact", "argmax_tail", "argmax_refine", "rd64", "cfar", "compact",
+    prof = {k: ctx.profile_get(k) for k in ("rd", "angle", "detect", "detect_tail", "detect_exact", "argmax_tail", "argmax_refine", "rd_help", "rd64", "cfar", "compact",
                                             "plane_l1", "argmax")} if not args.no_profile else {}
     # BASELINE configs[2] beside the headline: the detection pipeline on the same resident frames, same K / W
     det_extra = None
     if not detect and not args.no_detect_record:
         work = DetectWorkload(ctx, F, args.detect_path)
-        det_elapsed, det_ev = timed(lambda: work.step(d_in), 1)
-        det_prof = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_tail", "detect_exact", "argmax_tail", "argmax_refine", "rd64", "cfar", "compact",
+        # (sub-records: the detection pipeline's rate settles over its first ~20 calls -- 1.99, 1.79, 1.76, 1.74, 1.72 ms per call in
+        #  blocks of six, profiles/r04_detect_probe.log -- so they warm up for SUB_WARMUP calls; the headline keeps --warmup)
+        det_elapsed, det_ev = timed(lambda: work.step(d_in), 1, max(args.warmup, SUB_WARMUP))
+        det_prof = {k: ctx.profile_get(k) for k in ("rd", "detect", "detect_tail", "detect_exact", "argmax_tail", "argmax_refine", "rd_help", "rd64", "cfar", "compact",
                                                     "plane_l1", "argmax")} if not args.no_profile else {}
         det_extra = (det_elapsed, det_ev, det_prof)
         work_os = DetectWorkload(ctx, F, cfar=OS_CFAR)
-        os_elapsed, os_ev = timed(lambda: work_os.step(d_in), 1)
+        os_elapsed, os_ev = timed(lambda: work_os.step(d_in), 1, max(args.warmup, SUB_WARMUP))
         os_prof = {k: ctx.profile_get(k) for k in ("rd", "rd64", "cfar", "compact", "plane_l1", "argmax")} if not args.no_profile else {}
         os_extra = (os_elapsed, os_ev, os_prof)
 
@@ -424,6 +427,7 @@ def main():
         v = world * F * args.steps / dt
         os_kind = wl is not None and wl.cfar["kind"] != 0
         rec = {"value": v, "unit": "frames/s", "ms_per_step": 1e3 * dt / args.steps, "hip_event_ms_per_step_rank0": ev / args.steps,
+               "steps": args.steps, "warmup": args.warmup if detect else max(args.warmup, SUB_WARMUP),
                "algorithmic_bytes_per_frame": DET_BYTES_PER_FRAME,
                "hbm_frac_of_8TBs": v / world * DET_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),
                "path": wl.path if wl is not None else args.detect_path,
@@ -441,9 +445,11 @@ def main():
             # the NEXT step's range-Doppler launch, so there the spans overlap and their sum exceeds the step time
             rec["kernels_ms_sum_over_ms_per_step"] = sum(rec["kernels_ms_per_step"].values()) / (1e3 * dt / args.steps)
             if not os_kind:
-                rec["schedule"] = ("RD -> screening on the context stream; exact cells + insertion and the float64 refinement on side "
-                                   "queues, joined in front of the next call's screening (MMW_DETECT_DEFER_TAIL=1, the next "
-                                   "range-Doppler launch leaves MMW_DETECT_TAIL_CUS=40 CUs free for them)")
+                rec["schedule"] = ("RD -> screening on the context stream; angle estimates (one lane per detection record), float64 "
+                                   "refinement, exact cells + insertion on side queues, joined in front of the next call's screening "
+                                   "(MMW_DETECT_DEFER_TAIL=1).  Behind a pending tail the range-Doppler planes are handed out by tickets "
+                                   "to two launches of one kernel: num_cu - 40 workgroups at once (span `rd`), 40 more queued behind the "
+                                   "tail (span `rd_help`, inside `rd`)")
             rd_ms, rd_n = fam.get("rd", (0.0, 0))
             if rd_n:
                 avg_s = rd_ms * 1e-3 / rd_n
@@ -458,7 +464,10 @@ def main():
                                        " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 "
                                        "note) x frames per launch; not measured in this run")
                 rec["roofline"] = {"bound": "hbm", "kernel": "k_rd_fused_256x128_persist (range-Doppler of all 12 planes: the "
-                                   "largest stage of the pipeline)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "largest stage of the pipeline" + ("" if os_kind or "rd_help" not in fam or not fam["rd_help"][1] else
+                                   "; two launches of it share the planes through a ticket counter -- avg_launch_us is the span of "
+                                   "the first, num_cu - 40 workgroups, which the second, 40 workgroups behind the previous step's "
+                                   "tail, lies within; a kernel trace lists both") + ")", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                    "avg_launch_us": avg_s * 1e6,
                                    "launches": rd_n, "frames_per_launch": F,

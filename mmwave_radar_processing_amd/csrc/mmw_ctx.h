@@ -115,6 +115,9 @@ struct mmw_ctx {
     // point joins it first (join_pipe), as with the chain's queues
     hipStream_t q_tail = nullptr;
     hipEvent_t tail_done = nullptr;
+    hipEvent_t help_begin = nullptr, help_done = nullptr;      // the helper range-Doppler launch behind a pending tail (mmw_detect_points)
+    unsigned *help_sync = nullptr;              // its ticket counter + per-frame counters (not in the scratch: the pending tail owns that)
+    size_t help_sync_words = 0;
     bool tail_pending = false;
     int rd_leave_cus = 0;                       // CUs the persistent range-Doppler launch leaves free (for a tail running beside it)
     std::vector<std::pair<const char *, size_t>> tail_bufs;     // what the pending tail reads / writes (besides the scratch)

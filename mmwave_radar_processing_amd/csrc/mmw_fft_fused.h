@@ -1185,6 +1185,22 @@ inline bool rd_fused_supported(int S, int C) { return S == RD_S && C == RD_C; }
 int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid);   // cs.ntx > 1: raw input
 // the detection pipeline's producer: plain output cube + L1 norms, planes published per frame in cs.frame_cnt
 int launch_rd_fused_det(mmw_ctx *ctx, const void *d_in, void *d_out, float *d_l1, int n_planes, ChainSync cs, int grid);
+// Counters of a ticketed range-Doppler launch outside the chain (tickets, abort word, one counter per frame) + a float per plane
+// for callers that do not want the L1 norms: an allocation of the context's own (mmw_detect_points runs such launches beside a
+// pending tail that owns the scratch).  Grows by reallocation behind a synchronisation of the queues that may use it.
+inline int ensure_help_sync(mmw_ctx *ctx, size_t words) {
+    if (ctx->help_sync_words >= words) return MMW_OK;
+    if (ctx->help_sync) {
+        if (ctx->q_tail) MMW_HIP(hipStreamSynchronize(ctx->q_tail));
+        MMW_HIP(hipStreamSynchronize(ctx->stream));
+        MMW_HIP(hipFree(ctx->help_sync));
+        ctx->help_sync = nullptr;
+        ctx->help_sync_words = 0;
+    }
+    MMW_HIP(hipMalloc((void **)&ctx->help_sync, words * sizeof(unsigned)));
+    ctx->help_sync_words = words;
+    return MMW_OK;
+}
 
 #ifdef MMW_TU_RD
 int launch_rd_fused_sync(mmw_ctx *ctx, const void *d_in, void *d_ring, int n_items, ChainSync cs, int grid) {
@@ -1249,6 +1265,23 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
     // Standalone launches use the persistent variant with 8 rows prefetched (+12 %); inside the overlapped
     // chain the one-plane-per-workgroup kernel is faster (measured), so the chain sets active_cus and gets it.
     const int pf = ctx->active_cus > 0 ? 0 : 8;
+    // Large stand-alone batches: planes handed out by TICKETS (the detection pipeline's producer kernel: it waits for nobody;
+    // sc1 stores, L1 norms into a dummy when the caller wants none): workgroups that finish early draw more instead of all of
+    // them marching through their strided lists in step -- 1.37-1.46 against 1.50 ms per 15000 planes.  MMW_RD_TICKETS=0: strided.
+    if (pf == 8 && rv.vskip <= 2 && ctx->rd_leave_cus == 0 && planes > 4 * ctx->num_cu && opt_int(ctx, "MMW_RD_TICKETS", 1) != 0) {
+        const size_t words = CTL_CNT + 2 * (size_t)planes;
+        MMW_TRY(ensure_help_sync(ctx, words));
+        MMW_HIP(hipMemsetAsync(ctx->help_sync, 0, (CTL_CNT + (size_t)planes) * sizeof(unsigned), ctx->stream));
+        ChainSync cs{};
+        cs.ctl = ctx->help_sync;
+        cs.frame_cnt = ctx->help_sync + CTL_CNT;
+        cs.V = cs.v_live = 1;
+        cs.n_frames = planes;
+        cs.ntx = 1;
+        float *l1 = d_l1 ? d_l1 : reinterpret_cast<float *>(ctx->help_sync + CTL_CNT + planes);
+        if (d_l1 && l1_done) *l1_done = true;
+        return launch_rd_fused_det(ctx, d_in, d_out, l1, planes, cs, ctx->num_cu);
+    }
     if (pf == 8 && rv.vskip <= 2) {
         int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu);
         if (ctx->rd_leave_cus > 0 && grid > 2 * ctx->rd_leave_cus) grid -= ctx->rd_leave_cus;      // (one workgroup fills a CU)

@@ -210,7 +210,9 @@ int mmw_ctx_destroy(mmw_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->q_tail);
         (void)hipStreamDestroy(ctx->q_tail);
     }
-    for (hipEvent_t e : {ctx->det_begin, ctx->det_rd_done, ctx->det_scr_done, ctx->side_fork, ctx->side_join, ctx->tail_done})
+    if (ctx->help_sync) (void)hipFree(ctx->help_sync);
+    for (hipEvent_t e : {ctx->det_begin, ctx->det_rd_done, ctx->det_scr_done, ctx->side_fork, ctx->side_join, ctx->tail_done,
+                         ctx->help_begin, ctx->help_done})
         if (e) (void)hipEventDestroy(e);
     if (ctx->q_copy) {
         (void)hipStreamSynchronize(ctx->q_copy);
@@ -2010,19 +2012,75 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
             for (const auto &t : ctx->tail_bufs)
                 if (o.first < t.first + t.second && t.first < o.first + o.second) rd_first = false;
     }
+    // Range-Doppler of 256 x 128 batches with the planes handed out by TICKETS (the producer kernel of the overlapped schedule: it
+    // never waits for anybody; same arithmetic, sc1 stores): workgroups that finish early draw more -- 1.46 against 1.50 ms per
+    // 1250 frames for the statically strided launch -- and, behind a pending tail, a second launch of the same kernel can join in.
+    // The counters are an allocation of their own: the scratch belongs to the pending tail.
+    const int n_planes_all = n_frames * V;
+    const bool tickets = !overlap && fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && n_planes_all > 4 * ctx->num_cu &&
+                         opt_int(ctx, "MMW_DETECT_RD_TICKETS", 1) != 0;
+    auto ticketed_rd = [&](int grid_main, int grid_help) -> int {
+        const size_t words = CTL_CNT + (size_t)n_frames;
+        MMW_TRY(ensure_help_sync(ctx, words));
+        ChainSync cs{};
+        cs.ctl = ctx->help_sync;
+        cs.frame_cnt = ctx->help_sync + CTL_CNT;
+        cs.V = cs.v_live = V;
+        cs.n_frames = n_frames;
+        cs.ntx = 1;
+        hipStream_t main_q = ctx->stream;
+        MMW_HIP(hipMemsetAsync(ctx->help_sync, 0, words * sizeof(unsigned), main_q));
+        if (grid_help > 0) {
+            MMW_HIP(hipEventRecord(ctx->help_begin, main_q));
+            MMW_HIP(hipStreamWaitEvent(ctx->q_tail, ctx->help_begin, 0));
+        }
+        int rc;
+        {
+            ProfScope ps(ctx, "rd");
+            rc = launch_rd_fused_det(ctx, d_cubes, d_rd, d_l1, n_planes_all, cs, grid_main);
+        }
+        if (grid_help > 0) {
+            if (rc == MMW_OK) {
+                ctx->stream = ctx->q_tail;
+                ProfScope ps(ctx, "rd_help");
+                rc = launch_rd_fused_det(ctx, d_cubes, d_rd, d_l1, n_planes_all, cs, grid_help);
+                ctx->stream = main_q;
+            }
+            MMW_HIP(hipEventRecord(ctx->help_done, ctx->q_tail));       // (in any case: joined by the caller)
+            if (rc != MMW_OK) MMW_HIP(hipStreamWaitEvent(main_q, ctx->help_done, 0));
+        }
+        return rc;
+    };
+    bool helper = false;
     if (rd_first) {
         // the persistent kernel holds one workgroup per CU for its whole run: it leaves a few CUs to the tail's short workgroups
-        // (the kernel keeps its HBM rate down to ~224 CUs: DESIGN.md 4.9)
-        ctx->rd_leave_cus = std::max(0, std::min(opt_int(ctx, "MMW_DETECT_TAIL_CUS", 40), ctx->num_cu / 4));
-        const int rc = range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1);
-        ctx->rd_leave_cus = 0;
-        MMW_TRY(rc);
+        // (32 at least: with fewer some shader engine has no free CU, and the dispatcher -- which places a launch's workgroups
+        // engine by engine -- holds the tail's launches back until the range-Doppler launch ends)
+        const int leave = std::max(0, std::min(opt_int(ctx, "MMW_DETECT_TAIL_CUS", 40), ctx->num_cu / 4));
+        helper = tickets && leave > 0 && opt_int(ctx, "MMW_DETECT_RD_HELPER", 1) != 0;
+        if (helper) {
+            // On num_cu - leave CUs the launch is bound by CU-time (15000 planes x 23 us on 216 CUs: 1.60 ms), and the tail needs
+            // its CUs for the first ~0.7-1.0 ms only: a second launch, `leave` workgroups, sits in the tail's queue BEHIND the
+            // tail -- when the tail is done its CUs draw tickets too.
+            MMW_TRY(ticketed_rd(ctx->num_cu - leave, leave));
+        } else if (tickets) {
+            MMW_TRY(ticketed_rd(ctx->num_cu - leave, 0));
+        } else {
+            ctx->rd_leave_cus = leave;
+            const int rc = range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1);
+            ctx->rd_leave_cus = 0;
+            MMW_TRY(rc);
+        }
     }
     MMW_TRY(join_tail(ctx));
+    if (helper) MMW_HIP(hipStreamWaitEvent(ctx->stream, ctx->help_done, 0));
     MMW_HIP(hipMemsetAsync(a.ctl, 0, DCTL_WORDS * sizeof(int), ctx->stream));      // counters
     if (overlap) MMW_HIP(hipMemsetAsync(sync_words, 0, b_sync, ctx->stream));
     // range-Doppler of every antenna (float32) with the planes' L1 norms
-    if (!overlap && !rd_first) MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
+    if (!overlap && !rd_first) {
+        if (tickets) MMW_TRY(ticketed_rd(ctx->num_cu, 0));
+        else MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
+    }
     const float eps = 5.9604645e-8f, div = argmax_bound_div(ctx);
     const int ulps = rd_error_ulps(S, C);
     a.rd = (const float2 *)d_rd;
@@ -2178,6 +2236,8 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
         MMW_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
         MMW_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
         MMW_HIP(hipEventCreateWithFlags(&ctx->tail_done, hipEventDisableTiming));
+        MMW_HIP(hipEventCreateWithFlags(&ctx->help_begin, hipEventDisableTiming));
+        MMW_HIP(hipEventCreateWithFlags(&ctx->help_done, hipEventDisableTiming));
     }
     MMW_HIP(hipEventRecord(ctx->side_fork, main_stream));
     MMW_HIP(hipStreamWaitEvent(ctx->q_tail, ctx->side_fork, 0));

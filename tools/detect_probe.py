@@ -20,13 +20,18 @@ def main():
     ap.add_argument("--frames", type=int, default=1250)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--tail-cus", default="40,32,24")
+    ap.add_argument("--cap", type=int, default=1024)
+    ap.add_argument("--settle", action="store_true")
+    ap.add_argument("--ballast-gb", type=float, default=0.0, help="allocate this much before the pipeline's buffers (bench.py holds 21 GB of chain output)")
     ap.add_argument("--opts", default="", help="extra context options NAME=VALUE[,NAME=VALUE...] tried one at a time")
     args = ap.parse_args()
     F, reps = args.frames, args.reps
     ctx = _lib.Context(0)
     L = ctx.lib
-    cube_b, cap = V * S * C * 8, 1024
-    d_in, d_rd = ctx.alloc(F * cube_b), ctx.alloc(F * cube_b)
+    cube_b, cap = V * S * C * 8, args.cap
+    d_in = ctx.alloc(F * cube_b)
+    ballast = ctx.alloc(int(args.ballast_gb * 2**30)) if args.ballast_gb > 0 else None
+    d_rd = ctx.alloc(F * cube_b)
     _lib.check(L.mmw_synth_cubes(ctx.handle, d_in.ptr, F, V, S, C, 99, 8, 30.0))
     d_dets, d_cnt = ctx.alloc(F * cap * 8), ctx.alloc(F * 4)
     d_az, d_el, d_l1 = ctx.alloc(F * cap * 4), ctx.alloc(F * cap * 4), ctx.alloc(F * V * 4)
@@ -58,6 +63,11 @@ def main():
         ctx.profile_enable(False)
         print(json.dumps(out), flush=True)
 
+    if args.settle:        # how many calls until the rate settles: the same case over and over, 5 calls each
+        for i in range(12):
+            measure5 = reps
+            measure(f"lists, defer=1, block {i} of {reps} calls", True)
+        return
     for defer in (1, 0):
         ctx.set_option("MMW_DETECT_DEFER_TAIL", defer)
         measure(f"lists, defer={defer}", True)
