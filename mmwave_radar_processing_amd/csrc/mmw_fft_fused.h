@@ -969,7 +969,11 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128_persist(const f32x4 *
                         constexpr int kc = ((16 * k2d) ^ 64) * 8;
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e[bitrev<8>(k2d)]), ring_rs,
                                                               (unsigned)((kr * RD_C + k1d) * 8 + kc), ring_soff, 16);
-                    } else dst[kr * RD_C + kk] = e[bitrev<8>(k2d)];
+                    } else {
+                        // non-temporal: the cube is written once and is larger than any cache (a plain store here cost the
+                        // stand-alone launch 9 %: 1.50 -> 1.37 ms per 15000 planes, found through the sc1 stores of the SYNC form)
+                        __builtin_nontemporal_store(e[bitrev<8>(k2d)], &dst[kr * RD_C + kk]);
+                    }
                 });
             }
             if constexpr (SYNC && !DET && h == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
@@ -1265,23 +1269,6 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
     // Standalone launches use the persistent variant with 8 rows prefetched (+12 %); inside the overlapped
     // chain the one-plane-per-workgroup kernel is faster (measured), so the chain sets active_cus and gets it.
     const int pf = ctx->active_cus > 0 ? 0 : 8;
-    // Large stand-alone batches: planes handed out by TICKETS (the detection pipeline's producer kernel: it waits for nobody;
-    // sc1 stores, L1 norms into a dummy when the caller wants none): workgroups that finish early draw more instead of all of
-    // them marching through their strided lists in step -- 1.37-1.46 against 1.50 ms per 15000 planes.  MMW_RD_TICKETS=0: strided.
-    if (pf == 8 && rv.vskip <= 2 && ctx->rd_leave_cus == 0 && planes > 4 * ctx->num_cu && opt_int(ctx, "MMW_RD_TICKETS", 1) != 0) {
-        const size_t words = CTL_CNT + 2 * (size_t)planes;
-        MMW_TRY(ensure_help_sync(ctx, words));
-        MMW_HIP(hipMemsetAsync(ctx->help_sync, 0, (CTL_CNT + (size_t)planes) * sizeof(unsigned), ctx->stream));
-        ChainSync cs{};
-        cs.ctl = ctx->help_sync;
-        cs.frame_cnt = ctx->help_sync + CTL_CNT;
-        cs.V = cs.v_live = 1;
-        cs.n_frames = planes;
-        cs.ntx = 1;
-        float *l1 = d_l1 ? d_l1 : reinterpret_cast<float *>(ctx->help_sync + CTL_CNT + planes);
-        if (d_l1 && l1_done) *l1_done = true;
-        return launch_rd_fused_det(ctx, d_in, d_out, l1, planes, cs, ctx->num_cu);
-    }
     if (pf == 8 && rv.vskip <= 2) {
         int grid = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu);
         if (ctx->rd_leave_cus > 0 && grid > 2 * ctx->rd_leave_cus) grid -= ctx->rd_leave_cus;      // (one workgroup fills a CU)

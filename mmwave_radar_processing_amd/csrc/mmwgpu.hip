@@ -2012,13 +2012,11 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
             for (const auto &t : ctx->tail_bufs)
                 if (o.first < t.first + t.second && t.first < o.first + o.second) rd_first = false;
     }
-    // Range-Doppler of 256 x 128 batches with the planes handed out by TICKETS (the producer kernel of the overlapped schedule: it
-    // never waits for anybody; same arithmetic, sc1 stores): workgroups that finish early draw more -- 1.46 against 1.50 ms per
-    // 1250 frames for the statically strided launch -- and, behind a pending tail, a second launch of the same kernel can join in.
-    // The counters are an allocation of their own: the scratch belongs to the pending tail.
+    // Behind a pending tail the range-Doppler planes of a 256 x 128 batch are handed out by TICKETS (the producer kernel of the
+    // overlapped schedule: it never waits for anybody; same arithmetic, sc1 stores), so that a second launch of the same kernel can
+    // join in.  The counters are an allocation of their own: the scratch belongs to the pending tail.
     const int n_planes_all = n_frames * V;
-    const bool tickets = !overlap && fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && n_planes_all > 4 * ctx->num_cu &&
-                         opt_int(ctx, "MMW_DETECT_RD_TICKETS", 1) != 0;
+    const bool tickets = !overlap && fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0) && n_planes_all > 4 * ctx->num_cu;
     auto ticketed_rd = [&](int grid_main, int grid_help) -> int {
         const size_t words = CTL_CNT + (size_t)n_frames;
         MMW_TRY(ensure_help_sync(ctx, words));
@@ -2063,8 +2061,6 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
             // its CUs for the first ~0.7-1.0 ms only: a second launch, `leave` workgroups, sits in the tail's queue BEHIND the
             // tail -- when the tail is done its CUs draw tickets too.
             MMW_TRY(ticketed_rd(ctx->num_cu - leave, leave));
-        } else if (tickets) {
-            MMW_TRY(ticketed_rd(ctx->num_cu - leave, 0));
         } else {
             ctx->rd_leave_cus = leave;
             const int rc = range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1);
@@ -2077,10 +2073,7 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     MMW_HIP(hipMemsetAsync(a.ctl, 0, DCTL_WORDS * sizeof(int), ctx->stream));      // counters
     if (overlap) MMW_HIP(hipMemsetAsync(sync_words, 0, b_sync, ctx->stream));
     // range-Doppler of every antenna (float32) with the planes' L1 norms
-    if (!overlap && !rd_first) {
-        if (tickets) MMW_TRY(ticketed_rd(ctx->num_cu, 0));
-        else MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
-    }
+    if (!overlap && !rd_first) MMW_TRY(range_doppler_impl(ctx, d_cubes, d_rd, nullptr, n_frames, V, S, C, RawView{1, 0}, d_l1));
     const float eps = 5.9604645e-8f, div = argmax_bound_div(ctx);
     const int ulps = rd_error_ulps(S, C);
     a.rd = (const float2 *)d_rd;

@@ -81,6 +81,9 @@ def main():
         name, val = kv.split("=")
         ctx.set_option(name, int(val))
         measure(f"lists, defer=1, {kv}", True)
+        ctx.set_option("MMW_DETECT_DEFER_TAIL", 0)
+        measure(f"lists, defer=0, {kv}", True)
+        ctx.set_option("MMW_DETECT_DEFER_TAIL", 1)
         ctx.set_option(name, None)
 
 
