@@ -624,7 +624,9 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
                                                             int planes, const float *__restrict__ hann_s,
                                                             const float *__restrict__ hann_c,
                                                             const cplx<float> *__restrict__ tw256,
-                                                            const cplx<float> *__restrict__ tw128, RawView rv) {
+                                                            const cplx<float> *__restrict__ tw128, RawView rv, int nt_out) {
+    // nt_out: non-temporal stores (a stand-alone launch: the cube is written once and is larger than the caches; inside the
+    // event-schedule chain the output is a ring that is meant to stay cached: plain stores)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<float> *lds = reinterpret_cast<cplx<float> *>(smem);
     cplx<float> *tw128_l = lds + RD_LDS_MAIN;
@@ -715,6 +717,8 @@ __global__ __launch_bounds__(1024) void k_rd_fused_256x128(const f32x4 *__restri
                     if constexpr (ABL & 1) {
                         const float vx = val.x, vy = val.y;
                         asm volatile("" ::"v"(vx), "v"(vy));
+                    } else if (nt_out) {
+                        __builtin_nontemporal_store(val, &dst[kr * RD_C + kk]);
                     } else {
                         dst[kr * RD_C + kk] = val;
                     }
@@ -1259,7 +1263,7 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RD_LDS_BYTES);
             hipLaunchKernelGGL(kern, dim3((unsigned)raw_grid(planes, rv)), dim3(1024), RD_LDS_BYTES, ctx->stream,
                                (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                               (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
+                               (const cplx<float> *)t256, (const cplx<float> *)t128, rv, ctx->active_cus > 0 ? 0 : 1);
         };
         if (rv.i16) go(k_rd_fused_256x128<false, 0, true, true>);
         else go(k_rd_fused_256x128<false, 0, true>);
@@ -1289,14 +1293,9 @@ int launch_rd_fused(mmw_ctx *ctx, const void *d_in, void *d_out, int planes, int
         } else launch(k_rd_fused_256x128_persist<true, 6>);     // 6 rows prefetched: 8 no longer fit the register budget (spills)
         return check_launch("rd_fused_persist");
     }
-    if (1)
-        hipLaunchKernelGGL(k_rd_fused_256x128<true>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
-                           (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                           (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
-    else
-        hipLaunchKernelGGL(k_rd_fused_256x128<false>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
-                           (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
-                           (const cplx<float> *)t256, (const cplx<float> *)t128, rv);
+    hipLaunchKernelGGL(k_rd_fused_256x128<true>, dim3(blocks), dim3(1024), RD_LDS_BYTES, ctx->stream,
+                       (const f32x4 *)d_in, (cplx<float> *)d_out, planes, (const float *)hs, (const float *)hc,
+                       (const cplx<float> *)t256, (const cplx<float> *)t128, rv, ctx->active_cus > 0 ? 0 : 1);
     return check_launch("rd_fused");
 }
 #endif  // MMW_TU_RD
