@@ -116,13 +116,15 @@ def chain_plan(ctx, n_frames: int) -> dict:
 
 
 def insitu_ceiling(ctx, d_buf, nbytes: int) -> dict:
-    """What plain streaming kernels reach on this device, right now: 16-B/lane grid-stride kernels over up to 4 GiB of
-    the (already checked) output buffer, swept over the grid size, best of each kind reported -- the practical ceiling
-    next to the 8 TB/s spec peak.  mode 1 = plain stores, 3 = non-temporal stores, 0 = copy, 2 = read."""
+    """What plain streaming kernels reach on this device, right now: 16-B/lane grid-stride kernels over the whole (already
+    checked) output buffer -- up to 20 GiB: a launch as long as the kernels it is compared with; over 4 GiB, as in rounds
+    1-3, ramp-up and drain cost the write stream a tenth of its rate (5.1-5.2 against 5.8 TB/s) --, swept over the grid size,
+    best of each kind reported: the practical ceiling next to the 8 TB/s spec peak.  mode 1 = plain stores, 3 = non-temporal
+    stores, 6 = the angle kernel's store pattern without its arithmetic, 0 = copy, 2 = read."""
     from mmwave_radar_processing_amd import _lib
-    nb = min(nbytes, 4 << 30) // 64 * 64
+    nb = min(nbytes, 20 << 30) // (64 * 16384 * 16) * (64 * 16384 * 16)      # whole 16-MiB "frames" of the pattern kernel
     best = {}
-    for name, mode in (("write", 1), ("write_nt", 3), ("copy", 0), ("read", 2)):
+    for name, mode in (("write", 1), ("write_nt", 3), ("write_angle_pattern", 6), ("copy", 0), ("read", 2)):
         span = nb // 2 if mode == 0 else nb
         for per_cu in (2, 4, 8, 16, 32):
             blocks = per_cu * 256
