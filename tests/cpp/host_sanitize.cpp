@@ -56,20 +56,24 @@ int main() {
         for (int C : {16, 32, 50, 100, 127, 128, 256})
             for (int tr : {0, 1, 4, 5, 9})
                 for (int gr : {0, 2, 3, 4})
-                    for (int n_az : {0, 4, 8, 9}) {
-                        CHECK(mmw_diag_detect_plan(S, C, MMW_CFAR_CA, tr, tr, gr, gr > 2 ? 2 : gr, n_az, 4, 64, plan) == MMW_OK);
-                        const bool expect = mmw_detect_points_supported(S, C, MMW_CFAR_CA, tr, tr, gr, gr > 2 ? 2 : gr, n_az, 4) != 0;
+                    for (int n_az : {0, 4, 8, 9, 16, 17})
+                      for (int A : {64, 128}) {
+                        CHECK(mmw_diag_detect_plan(S, C, MMW_CFAR_CA, tr, tr, gr, gr > 2 ? 2 : gr, n_az, 4, A, plan) == MMW_OK);
+                        const bool expect = mmw_detect_points_supported(S, C, MMW_CFAR_CA, tr, tr, gr, gr > 2 ? 2 : gr, n_az, 4, A) != 0;
                         CHECK((plan[0] != 0) == expect);
                         if (plan[0]) {
                             CHECK(plan[1] == 1 && plan[5] > 0 && plan[5] <= 160 * 1024 && plan[7] >= 8);
                             // a band and its halo rows fit the loads a workgroup keeps in flight
                             CHECK(plan[3] >= 1 && plan[3] + 2 * (tr + gr) <= plan[2]);
                         }
-                        if (n_az > 8) CHECK(plan[0] == 0);
+                        // lists of 9 to 16 antennas: only with 64 angle bins (the late argmax); longer ones never
+                        if (n_az > 16 || (n_az > 8 && A != 64)) CHECK(plan[0] == 0);
                         ++planned;
                     }
-    CHECK(mmw_detect_points_supported(256, 128, MMW_CFAR_OS, 5, 5, 3, 2, 8, 4) == 0);      // (OS windows: float64 path)
-    CHECK(mmw_detect_points_supported(-1, 128, MMW_CFAR_CA, 4, 4, 2, 2, 8, 4) == 0);
+    CHECK(mmw_detect_points_supported(256, 128, MMW_CFAR_OS, 5, 5, 3, 2, 8, 4, 64) == 0);      // (OS windows: float64 path)
+    CHECK(mmw_detect_points_supported(-1, 128, MMW_CFAR_CA, 4, 4, 2, 2, 8, 4, 64) == 0);
+    CHECK(mmw_detect_points_supported(256, 128, MMW_CFAR_CA, 4, 4, 2, 2, 12, 9, 64) == 1);
+    CHECK(mmw_detect_points_supported(256, 128, MMW_CFAR_CA, 4, 4, 2, 2, 12, 9, 128) == 0);
     // chirp-z run splitter: uniform lists, lists with NaN holes, a step change, single bins, more bins than one transform holds
     for (int n_used : {16, 70, 100, 128, 256, 1000}) {
         for (int M : {1, 2, 63, 256, 700, 3000}) {
