@@ -1036,8 +1036,14 @@ __device__ __forceinline__ void detect_screen_frame(const DetectArgs &a, const l
                     else Xs[2 * i] = m0;
                 }
                 if (mg) {
-                    if (2 * i >= keep_lo && 2 * i < keep_hi) mg[base + 2 * i] = m0;
-                    if (two && 2 * i + 1 >= keep_lo && 2 * i + 1 < keep_hi) mg[base + 2 * i + 1] = m1;
+                    // (written once, read by the caller later: non-temporal; a pair never straddles the kept rows when C is even)
+                    const bool k0 = 2 * i >= keep_lo && 2 * i < keep_hi, k1 = two && 2 * i + 1 >= keep_lo && 2 * i + 1 < keep_hi;
+                    if (k0 && k1 && ((base + 2 * i) & 1) == 0)
+                        __builtin_nontemporal_store(f32x2{m0, m1}, reinterpret_cast<f32x2 *>(mg + base + 2 * i));
+                    else {
+                        if (k0) mg[base + 2 * i] = m0;
+                        if (k1) mg[base + 2 * i + 1] = m1;
+                    }
                 }
             }
         }
