@@ -335,7 +335,7 @@ def main():
                     help="record a HIP event pair around every n-th launch of each kernel inside the timed region; 0 = "
                          "auto: every launch when a step is one launch per stage, else every 7th (coprime with the "
                          "launches per step, so a short tail chunk is sampled in proportion)")
-    _tj = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")]
+    _tj = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")]
     ap.add_argument("--traffic-json", default=next((t for t in _tj if os.path.exists(t)), _tj[-1]))
     args = ap.parse_args()
 

@@ -41,7 +41,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes
                "MMW_ANGLE_QUEUES=1 -- counter collection serialises kernel dispatches, which the device-synchronised default schedule "
                "cannot run under (its two launches must overlap), so the traffic is measured on the event-mode kernels k_angle64 / "
                "k_rd_fused_256x128: the same loads and stores per frame as k_angle64_sync / the persistent RD kernel. Detection: "
-               "`bench.py --workload detect --steps 3 --warmup 0` (one stream). Counters are KiB summed over all launches; gfx950 "
+               "`bench.py --workload detect --steps 3 --warmup 0` with MMW_DETECT_DEFER_TAIL=0 (every call joins its own tail). Counters are KiB summed over all launches; gfx950 "
                "FETCH_SIZE of a wide coalesced read stream reports half the bytes (MI355X_MICROARCH.md, HBM) -> doubled. "
                "Infinity-Cache hits are counted by these L2-side counters. The chain kernels skip the two antennas whose Hann(12) "
                "weight is exactly zero: 10 of 12 planes are read and transformed.",
@@ -65,7 +65,7 @@ det = {}
 for k, v in de.items():
     if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
-    if not any(s in k for s in ("k_rd_fused", "k_detect_screen", "k_cfar_cell_exact", "k_detect_finish", "k_argmax_refine")):
+    if not any(s in k for s in ("k_rd_fused", "k_detect_screen", "k_cfar_cell_exact", "k_detect_insert", "k_angle_argmax_recs", "k_argmax_refine")):
         continue
     fetch, write = traffic(v, 2 * V * plane * frames)
     det[k] = {"launches": v["FETCH_SIZE"][0], "read_bytes_corrected_per_frame": fetch / frames, "write_bytes_per_frame": write / frames}
