@@ -742,7 +742,9 @@ int launch_rd_mixed_ct_sc(mmw_ctx *ctx, const void *d_in, long in_plane_stride, 
             MMW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), NT, lds_bytes));
             per_cu = nb > 0 ? nb : 1;
         }
-        const unsigned resident = (unsigned)((ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu) * per_cu);
+        // (rd_leave_cus: CUs left to a pending tail of mmw_detect_points that runs beside this launch)
+        const int cus = (ctx->active_cus > 0 ? ctx->active_cus : ctx->num_cu);
+        const unsigned resident = (unsigned)((cus > 2 * ctx->rd_leave_cus ? cus - ctx->rd_leave_cus : cus) * per_cu);
         if (grid > resident) grid = resident;
     }
     if (tune_int("MMW_PHASE_CLOCKS", 0)) {

@@ -2004,7 +2004,10 @@ int mmw_detect_points(mmw_ctx *ctx, const void *d_cubes, void *d_rd, float *d_l1
     // refinement: ~0.15 ms of latency-bound launches that leave the chip almost idle -- is still running on its side queues.
     // This call's range-Doppler kernel touches nothing the tail uses (the fused 256 x 128 kernel needs no scratch; its output
     // buffers are checked against the tail's), so it goes first and the tail is joined in front of the screening stage.
-    bool rd_first = !overlap && ctx->tail_pending && fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0);
+    // (the same holds for the compile-time mixed-radix kernels -- every shipped cfg's plane --: tables only, no scratch)
+    const bool rd_no_scratch = (fused_rd_ok(S, C) && !env_int("MMW_NO_FUSED_RD", 0)) ||
+                               (!fused_rd_ok(S, C) && rd_mixed_ct_supported(S, C) && !env_int("MMW_NO_MIXED_RD", 0));
+    bool rd_first = !overlap && ctx->tail_pending && rd_no_scratch;
     if (rd_first) {
         const std::pair<const char *, size_t> outs[2] = {{(const char *)d_rd, (size_t)n_frames * V * S * C * 8},
                                                          {(const char *)d_l1, (size_t)n_frames * V * sizeof(float)}};

@@ -1845,17 +1845,20 @@ def test_detect_points_edge_cases_and_pipeline_fallback(monkeypatch):
             np.testing.assert_allclose(pcs[f], pc_ref, rtol=0, atol=1e-9 * sc["range_max_m"])
 
 
-def test_detect_points_deferred_tail_back_to_back():
+@pytest.mark.parametrize("shape,F", [((12, 256, 128), 96), ((12, 63, 100), 300), ((8, 254, 50), 200)])
+def test_detect_points_deferred_tail_back_to_back(shape, F):
     """mmw_detect_points does not join its tail (exact cells, list insertion, float64 refinement) at the end of a call: the next
     call's range-Doppler launch runs beside it, every other entry point joins it first.  Back-to-back calls -- same buffers
     again, then other inputs into other buffers -- with the band widened (so that there ARE undecided cells and flagged
-    evaluations) leave exactly what calls that join their own tail leave (MMW_DETECT_DEFER_TAIL=0 / the statistics request)."""
-    shape, F, cap = (12, 256, 128), 96, 512
+    evaluations) leave exactly what calls that join their own tail leave (MMW_DETECT_DEFER_TAIL=0 / the statistics request).
+    256 x 128: the ticketed range-Doppler pair behind the tail; the shipped shapes: their compile-time mixed-radix kernels
+    (one workgroup per plane at 63 x 100, the persistent form at 254 x 50)."""
+    cap = 512
     V, S, C = shape
     ctx = _lib.Context(0)
     ctx.set_option("MMW_DETECT_BAND_MULT", 20)
     cfar = CaCFAR2D((4, 4), (2, 2), 1e-5)
-    az, el = list(range(8)), [8, 9, 10, 11]
+    az, el = list(range(min(8, V))), list(range(max(0, V - 4), V))
     a_az, n_az = _lib.int_array(az)
     a_el, n_el = _lib.int_array(el)
     d_a, d_b = ctx.alloc(F * V * S * C * 8), ctx.alloc(F * V * S * C * 8)
