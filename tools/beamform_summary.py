@@ -15,7 +15,9 @@ prev = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else {}
 LABELS = (("k_capon_batch", "k_capon_batch (32 frames per launch)"),
           ("k_capon_sweep", "k_capon_sweep (32 frames of 12 x 512 x 128, 181 angles per launch)"),
           ("k_cgemm_mfma", "k_cgemm_mfma (16 frames x 256 x 256 x 900 per launch)"),
-          ("k_bartlett_tile", "k_bartlett_tile (16 frames x 256 x 256 x 64 per launch, steering fused)"))
+          ("k_cgemm_bf16x3", "k_cgemm_bf16x3 (16 frames x 256 x 256 x 900 per launch, bf16 x 3 MFMAs)"),
+          ("k_bartlett_tile16", "k_bartlett_tile16 (1 frame x 256 x 256 x 64 per launch, 16 x 16 tiles, bf16 x 3)"),
+          ("k_bartlett_tile<", "k_bartlett_tile (16 frames x 256 x 256 x 64 per launch, steering fused)"))
 pmc = {}
 for kernel, counter, n, total in db.execute("select kernel_name, counter_name, count(distinct dispatch_id), sum(value) from "
                                             "counters_collection group by kernel_name, counter_name"):
