@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 import threading
 
 import numpy as np
@@ -20,6 +21,7 @@ MMW_OK = 0
 MMW_ERR_INVALID = -1
 MMW_ERR_TRUNCATED = -4
 MMW_ERR_UNSUPPORTED = -5
+RESULT_POOL_CAP = 1 << 30       # bytes of pinned result blocks the default context may hold (handed out + pooled)
 ABI_VERSION = 5          # include/mmwgpu.h MMWGPU_ABI_VERSION: the argtypes below are for exactly this revision
 CFAR_CA, CFAR_OS, CFAR_GO, CFAR_SO = 0, 1, 2, 3
 ANGLE_MAGNITUDE, ANGLE_NO_WINDOW, ANGLE_NO_SHIFT = 1, 2, 4
@@ -183,7 +185,7 @@ class DeviceBuffer:
         check(self.ctx.lib.mmw_memcpy_h2d(self.ctx.handle, self.ptr + byte_offset, arr.ctypes.data, arr.nbytes))
 
     def download(self, shape, dtype, byte_offset: int = 0) -> np.ndarray:
-        out = np.empty(shape, dtype=dtype)
+        out = self.ctx.result_array(shape, dtype)
         if byte_offset + out.nbytes > self.nbytes:
             raise ValueError("download exceeds device buffer")
         check(self.ctx.lib.mmw_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + byte_offset, out.nbytes))
@@ -195,7 +197,7 @@ class DeviceBuffer:
         dtypes oblige, one host core converting costs more than twice the bytes over PCIe."""
         narrow = np.dtype(dtype)
         wide = np.dtype(np.complex128 if narrow == np.complex64 else np.float64)
-        out = np.empty(shape, dtype=wide)
+        out = self.ctx.result_array(shape, wide)
         n_f32 = out.size * (2 if narrow == np.complex64 else 1)
         if byte_offset + n_f32 * 4 > self.nbytes or staging is None or staging.nbytes < out.nbytes:
             raise ValueError("download_widened: source or staging buffer too small")
@@ -224,6 +226,8 @@ class Context:
         self.handle = h
         self.device = int(device)
         self._cache = {}
+        self._result_pool = None        # pinned result blocks by size class (the process-wide default context only)
+        self._result_bytes = 0
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
@@ -246,6 +250,34 @@ class Context:
         """A tuning / test switch of this context (``mmw_diag_set_option``; INTEGRATION.md lists the names).  ``None`` removes
         the context's value again (the environment / the default applies)."""
         check(self.lib.mmw_diag_set_option(self.handle, name.encode(), -2**31 if value is None else int(value)))
+
+    def result_array(self, shape, dtype) -> np.ndarray:
+        """A fresh, caller-owned ndarray for a download.  On the process-wide default context, results of 1 MiB and more come
+        out of a pool of PINNED blocks: a device-to-host copy into pageable memory the caller has never touched pays page
+        faults and a bounce buffer (the 33 MB complex128 cube of ``compute_3d_windowed_fft``: 3.4 ms; pinned: the PCIe time).
+        A block goes back to the pool when the last view of the array is gone (the array's base object carries a
+        finalizer), so a frame loop that drops or overwrites its results allocates nothing after the first frames.  Contexts
+        that can be closed while their results are alive, small results and a pool grown past RESULT_POOL_CAP bytes use
+        ``np.empty``."""
+        dt = np.dtype(dtype)
+        count = int(np.prod(shape))
+        nbytes = count * dt.itemsize
+        if self._result_pool is None or nbytes < (1 << 20):
+            return np.empty(shape, dtype=dt)
+        size = 1 << (nbytes - 1).bit_length()
+        free = self._result_pool.setdefault(size, [])
+        if free:
+            ptr = free.pop()
+        else:
+            if self._result_bytes + size > RESULT_POOL_CAP:
+                return np.empty(shape, dtype=dt)
+            p = C.c_void_p()
+            check(self.lib.mmw_host_alloc(self.handle, C.byref(p), size))
+            ptr = p.value
+            self._result_bytes += size
+        buf = (C.c_char * size).from_address(ptr)
+        weakref.finalize(buf, free.append, ptr).atexit = False
+        return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
 
     def host_array(self, shape, dtype) -> np.ndarray:
         """Pinned host memory as an ndarray (freed with the context)."""
@@ -356,6 +388,8 @@ def default_context() -> Context:
         if n < 1:
             raise MmwGpuError("no HIP device visible: the MI355X HIP path is the only backend")
         _default_ctx = Context(dev % n)
+        if os.environ.get("MMW_PINNED_RESULTS", "1") != "0":
+            _default_ctx._result_pool = {}
     return _default_ctx
 
 

@@ -1551,6 +1551,40 @@ def test_raw_cube_device_synchronised_chain_on_shipped_shapes(monkeypatch, nrx, 
         buf.free()
 
 
+def test_download_results_come_from_a_pinned_pool_and_stay_caller_owned():
+    """Downloads of 1 MiB and more on the default context land in pooled pinned blocks (``Context.result_array``): every result
+    is a fresh, writable array of its own while it is alive (the reference hands out fresh ndarrays), and a dropped result's
+    block is what the next download of that size gets."""
+    import gc
+    ctx = _lib.default_context()
+    if ctx._result_pool is None:
+        pytest.skip("MMW_PINNED_RESULTS=0")
+    n = 3 << 20
+    d = ctx.alloc(n)
+    src = np.arange(n // 4, dtype=np.float32)
+    d.upload(src)
+    a = d.download((n // 4,), np.float32)
+    b = d.download((n // 4,), np.float32)
+    addr_a, addr_b = a.__array_interface__["data"][0], b.__array_interface__["data"][0]
+    assert addr_a != addr_b and a.flags.writeable and b.flags.writeable
+    np.testing.assert_array_equal(a, src)
+    a[:] = -1.0                                      # the caller owns it: b and the device copy are untouched
+    np.testing.assert_array_equal(b, src)
+    view = a[100:200]
+    del a
+    gc.collect()
+    c = d.download((n // 4,), np.float32)            # a view still holds the first block: a third one
+    assert c.__array_interface__["data"][0] not in (addr_a, addr_b) and float(view[0]) == -1.0
+    del view, c
+    gc.collect()
+    e = d.download((n // 4,), np.float32)            # now a released block comes back
+    assert e.__array_interface__["data"][0] != addr_b
+    np.testing.assert_array_equal(e, src)
+    small = d.download((16,), np.float32)            # small results: plain NumPy memory
+    assert small.base is None
+    d.free()
+
+
 def test_chirpz_plan_cache_eviction():
     """The context keeps at most 8 chirp-z plans (mmw_czt.h); a ninth frequency list drops the oldest.  Twelve lists in a
     row, then the first again: every result against the float64 sum."""
