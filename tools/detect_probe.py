@@ -65,7 +65,6 @@ def main():
 
     if args.settle:        # how many calls until the rate settles: the same case over and over, 5 calls each
         for i in range(12):
-            measure5 = reps
             measure(f"lists, defer=1, block {i} of {reps} calls", True)
         return
     for defer in (1, 0):
