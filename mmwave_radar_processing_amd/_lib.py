@@ -270,7 +270,14 @@ class Context:
             ptr = free.pop()
         else:
             if self._result_bytes + size > RESULT_POOL_CAP:
-                return np.empty(shape, dtype=dt)
+                # make room out of idle blocks of other sizes (a one-off large download must not end the pooling of the rest)
+                for other in sorted(self._result_pool, reverse=True):
+                    idle = self._result_pool[other]
+                    while idle and self._result_bytes + size > RESULT_POOL_CAP:
+                        check(self.lib.mmw_host_free(self.handle, C.c_void_p(idle.pop())))
+                        self._result_bytes -= other
+                if self._result_bytes + size > RESULT_POOL_CAP:
+                    return np.empty(shape, dtype=dt)
             p = C.c_void_p()
             check(self.lib.mmw_host_alloc(self.handle, C.byref(p), size))
             ptr = p.value

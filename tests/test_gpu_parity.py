@@ -1582,6 +1582,18 @@ def test_download_results_come_from_a_pinned_pool_and_stay_caller_owned():
     np.testing.assert_array_equal(e, src)
     small = d.download((16,), np.float32)            # small results: plain NumPy memory
     assert small.base is None
+    # a block larger than what the pool may still take frees idle blocks of other sizes instead of ending the pooling
+    del e, b
+    gc.collect()
+    held = ctx._result_bytes
+    assert held >= 3 * (4 << 20)                     # the three 4 MiB blocks of above, idle now
+    big_n = (_lib.RESULT_POOL_CAP - held + (1 << 20)) // 4
+    d_big = ctx.alloc(big_n * 4)
+    big = d_big.download((big_n,), np.float32)
+    assert big.base is not None and ctx._result_bytes <= _lib.RESULT_POOL_CAP
+    del big
+    gc.collect()
+    d_big.free()
     d.free()
 
 
